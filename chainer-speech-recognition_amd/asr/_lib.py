@@ -1,0 +1,67 @@
+"""ctypes binding of libasr_hip.so -- the only door from Python into the HIP kernels.
+
+The library is built in-tree by ``make -C chainer-speech-recognition_amd`` (or ``__graft_entry__.build()``).
+There is NO fallback: if the shared object is missing or a symbol is absent, importing an op raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libasr_hip.so")
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes).  Mirrors include/asr_hip.h one to one; tests/test_abi.py checks both ways.
+SIGNATURES = {
+    "asr_version": (c_int, []),
+    "asr_ctc_workspace_bytes": (c_size_t, [c_int] * 5),
+    "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
+    "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),
+    "asr_ctc_loss_grad": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float] + [c_void_p] * 4 + [c_size_t]),
+}
+
+_ERRORS = {-1: "bad argument", -2: "workspace too small", -3: "unsupported shape", -4: "kernel launch failed"}
+
+
+class AsrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise AsrHipError("%s not found: build it with `make -C %s` (hipcc, gfx950). There is no CPU fallback."
+                              % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AsrHipError("%s failed: %s (code %d)" % (what, _ERRORS.get(rc, "unknown error"), rc))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AsrHipError("libasr_hip operates on GPU tensors only (got %s); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise AsrHipError("non-contiguous tensor passed to libasr_hip")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

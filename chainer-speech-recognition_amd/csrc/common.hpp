@@ -1,0 +1,71 @@
+// Shared device/host helpers for libasr_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define ASR_OK 0
+#define ASR_ERR_BAD_ARG (-1)
+#define ASR_ERR_WORKSPACE (-2)
+#define ASR_ERR_UNSUPPORTED (-3)
+#define ASR_ERR_LAUNCH (-4)
+
+#define ASR_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return ASR_ERR_LAUNCH; \
+    } while (0)
+
+namespace asr {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide reductions through a small LDS scratch (>= 32 floats). All threads get the result.
+// blockDim.x must be a multiple of 64. Ends with a barrier so `scratch` can be reused at once.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_max(v);
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even f32 -> bf16 through the hardware conversion (keeps NaN a NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<uint16_t*>(&b);
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace asr
