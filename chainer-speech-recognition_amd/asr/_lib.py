@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libasr_hip.so")
 _lib = None
 
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+c_longlong = ctypes.c_longlong
 
 # name -> (restype, argtypes).  Mirrors include/asr_hip.h one to one; tests/test_abi.py checks both ways.
 SIGNATURES = {
@@ -22,6 +23,27 @@ SIGNATURES = {
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
     "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),
     "asr_ctc_loss_grad": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float] + [c_void_p] * 4 + [c_size_t]),
+    "asr_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 4),
+    "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
+    "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "asr_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong]),
+    "asr_permute4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 4 + [c_longlong] * 4),
+    "asr_im2col": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 9 + [c_void_p]),
+    "asr_col2im": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "asr_maxout2_fwd": (c_int, [c_void_p] * 3 + [c_longlong]),
+    "asr_maxout2_bwd": (c_int, [c_void_p] * 4 + [c_longlong]),
+    "asr_maxpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
+    "asr_maxpool_h_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int, c_int, c_int]),
+    "asr_add_bf16": (c_int, [c_void_p] * 4 + [c_longlong]),
+    "asr_colsum_acc": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
+    "asr_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_int]),
+    "asr_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 3 + [c_void_p, c_int, c_void_p, c_void_p,
+                                  c_longlong, c_int, c_int]),
+    "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
+    "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
+    "asr_fill_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_float]),
+    "asr_sqnorm_acc": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+    "asr_clip_decay_adam": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 7 + [c_void_p, c_int]),
 }
 
 _ERRORS = {-1: "bad argument", -2: "workspace too small", -3: "unsupported shape", -4: "kernel launch failed"}

@@ -1,0 +1,200 @@
+"""Thin, autograd-free Python faces of the C ABI (include/asr_hip.h): shape checks + pointer plumbing only.
+
+Everything numeric happens inside libasr_hip.so.  torch is used for allocation and stream handles.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _is_bf16(t):
+    if t.dtype == BF16:
+        return 1
+    if t.dtype == F32:
+        return 0
+    raise TypeError("expected float32 or bfloat16, got %s" % t.dtype)
+
+
+def gemm_nt(a, b, bias=None, out_dtype=BF16, out=None):
+    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias).  a, b bf16 with unit inner stride."""
+    assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2
+    assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] == b.shape[1]
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1
+    rc = _lib.lib().asr_gemm_nt(stream(), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                out.stride(0), ptr(bias), M, N, K, _is_bf16(out))
+    check(rc, "asr_gemm_nt")
+    return out
+
+
+def gemm_tn_acc(a, b, c):
+    """c[M,N] += a[K,M]^T @ b[K,N]; a, b bf16 row-major (unit inner stride), c f32."""
+    assert a.dtype == BF16 and b.dtype == BF16 and c.dtype == F32
+    assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.shape[0] == b.shape[0]
+    K, M = a.shape
+    N = b.shape[1]
+    assert c.shape == (M, N)
+    rc = _lib.lib().asr_gemm_tn_acc(stream(), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
+                                    c.stride(0), M, N, K)
+    check(rc, "asr_gemm_tn_acc")
+    return c
+
+
+def cast_bf16(src, transpose=False):
+    """f32 (rows, cols) -> bf16 copy, optionally transposed."""
+    assert src.dtype == F32 and src.is_contiguous()
+    s2 = src.reshape(src.shape[0], -1) if src.dim() != 2 else src
+    rows, cols = s2.shape
+    dst = torch.empty((cols, rows) if transpose else (rows, cols), dtype=BF16, device=src.device)
+    check(_lib.lib().asr_cast_bf16(stream(), ptr(s2), ptr(dst), rows, cols, int(transpose)), "asr_cast_bf16")
+    return dst
+
+
+def bf16_to_f32(src):
+    dst = torch.empty(src.shape, dtype=F32, device=src.device)
+    check(_lib.lib().asr_bf16_to_f32(stream(), ptr(src.contiguous()), ptr(dst), src.numel()), "asr_bf16_to_f32")
+    return dst
+
+
+def permute4(src, shape, strides, out_dtype):
+    """dense (d0,d1,d2,d3) tensor of `out_dtype` gathered from `src` storage with the given element strides."""
+    dst = torch.empty(shape, dtype=out_dtype, device=src.device)
+    rc = _lib.lib().asr_permute4(stream(), src.data_ptr(), _is_bf16(src), ptr(dst), _is_bf16(dst), *shape, *strides)
+    check(rc, "asr_permute4")
+    return dst
+
+
+def im2col(x, strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h):
+    Kp = (KH * KW * Cin + 7) // 8 * 8
+    Hout = Hin + 2 * pad_h - KH + 1
+    col = torch.empty((T * B * Hout, Kp), dtype=BF16, device=x.device)
+    rc = _lib.lib().asr_im2col(stream(), x.data_ptr(), _is_bf16(x), *strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h, Kp,
+                               ptr(col))
+    check(rc, "asr_im2col")
+    return col
+
+
+def col2im(dcol, T, B, Hin, Cin, KH, KW, pad_h):
+    Kp = dcol.shape[1]
+    dx = torch.empty((T, B, Hin, Cin), dtype=BF16, device=dcol.device)
+    check(_lib.lib().asr_col2im(stream(), ptr(dcol), T, B, Hin, Cin, KH, KW, pad_h, Kp, ptr(dx)), "asr_col2im")
+    return dx
+
+
+def maxout2_fwd(x):
+    assert x.dtype == BF16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    y = torch.empty(x.shape[:-1] + (x.shape[-1] // 2,), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_maxout2_fwd(stream(), ptr(x), ptr(y), y.numel()), "asr_maxout2_fwd")
+    return y
+
+
+def maxout2_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_maxout2_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), dy.numel()), "asr_maxout2_bwd")
+    return dx
+
+
+def pooled_height(Hin, k):
+    return 1 if Hin <= k else -(-(Hin - k) // k) + 1
+
+
+def maxpool_h_fwd(x, k):
+    """x (T, B, H, C) bf16 -> (T, B, Hout, C)."""
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    T, B, H, C = x.shape
+    y = torch.empty((T, B, pooled_height(H, k), C), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_maxpool_h_fwd(stream(), ptr(x), ptr(y), T * B, H, C, k), "asr_maxpool_h_fwd")
+    return y
+
+
+def maxpool_h_bwd(x, dy, k):
+    T, B, H, C = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_maxpool_h_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), T * B, H, C, k), "asr_maxpool_h_bwd")
+    return dx
+
+
+def add_bf16(a, b):
+    assert a.dtype == BF16 and b.dtype == BF16 and a.shape == b.shape
+    y = torch.empty_like(a, memory_format=torch.contiguous_format)
+    check(_lib.lib().asr_add_bf16(stream(), ptr(a.contiguous()), ptr(b.contiguous()), ptr(y), y.numel()), "asr_add_bf16")
+    return y
+
+
+def colsum_acc(x, out):
+    """out[c] += sum_r x[r][c]; x 2-d (unit inner stride), out f32."""
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == F32
+    rc = _lib.lib().asr_colsum_acc(stream(), x.data_ptr(), _is_bf16(x), x.shape[0], x.shape[1], x.stride(0), ptr(out))
+    check(rc, "asr_colsum_acc")
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, C, out_dtype):
+    """x (rows, D) f32/bf16; statistics per row; channel = index % C."""
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, D = x.shape
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=F32, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    rc = _lib.lib().asr_layernorm_fwd(stream(), ptr(x), _is_bf16(x), ptr(y), _is_bf16(y), ptr(gamma), ptr(beta),
+                                      ptr(mean), ptr(rstd), rows, D, C)
+    check(rc, "asr_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None, need_dx=True):
+    rows, D = x.shape
+    dy = dy.contiguous()
+    dx = torch.empty((rows, D), dtype=dx_dtype, device=x.device) if need_dx else None
+    rc = _lib.lib().asr_layernorm_bwd(stream(), ptr(x), _is_bf16(x), ptr(dy), _is_bf16(dy), ptr(gamma), ptr(mean),
+                                      ptr(rstd), ptr(dx), _is_bf16(dx) if need_dx else 0, ptr(dgamma), ptr(dbeta),
+                                      rows, D, C)
+    check(rc, "asr_layernorm_bwd")
+    return dx
+
+
+def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
+    dev = gi.device
+    hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
+    hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
+    gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
+    y = torch.empty((T * B, H), dtype=BF16, device=dev)
+    rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
+                                T, B, H, ndir)
+    check(rc, "asr_gru_fwd")
+    return y, hseq, hseq16, gates
+
+
+def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir):
+    dev = dy.device
+    dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
+    dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
+    carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
+    rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
+                                ptr(carry), T, B, H, ndir)
+    check(rc, "asr_gru_bwd")
+    return dgi, dgh
+
+
+def fill_(t, value):
+    assert t.dtype == F32 and t.is_contiguous()
+    check(_lib.lib().asr_fill_f32(stream(), ptr(t), t.numel(), float(value)), "asr_fill_f32")
+    return t
+
+
+def sqnorm_acc(g, out):
+    check(_lib.lib().asr_sqnorm_acc(stream(), ptr(g), g.numel(), ptr(out)), "asr_sqnorm_acc")
+    return out
+
+
+def clip_decay_adam(p, g, m, v, alpha, beta1, beta2, eps, weight_decay, clip, grad_scale, sqnorm, step):
+    rc = _lib.lib().asr_clip_decay_adam(stream(), ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), alpha, beta1, beta2, eps,
+                                        weight_decay, clip, grad_scale, ptr(sqnorm), int(step))
+    check(rc, "asr_clip_decay_adam")

@@ -1,0 +1,343 @@
+// HBM-bound layout / activation / pooling kernels of the conv front-end (gfx950).
+// Internal activation layout: (T, B, H, C) bf16 -- time-major, channel-last -- so that
+//   * maxout pairs (asr/nn/nn.py:45-50) are adjacent elements,
+//   * max-pooling over height (asr/nn/nn.py:95-103) and layer-norm over (C, H) (asr/nn/layernorm.py:42-45) stay
+//     inside one contiguous H*C block per (t, b),
+//   * the (B, C*H, T) reshape feeding the recurrent stack (run/ctc/sru/model.py:114) and the per-time-step split
+//     (asr/model/cnn.py:41-44) are free views.
+// The reference's logical (B, C, H, T) order is recovered by a permuted view on the Python side.
+#include "common.hpp"
+#include "../../include/asr_hip.h"
+
+namespace asr {
+namespace ew {
+
+constexpr int kThreads = 256;
+static inline int grid_for(long long n) {
+    long long g = (n + kThreads - 1) / kThreads;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------ cast / transpose
+__global__ void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = f32_to_bf16(src[i]);
+}
+// dst[c][r] = src[r][c]   (small weight matrices; 32x32 LDS tile)
+__global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dst[(size_t)c * rows + r] = f32_to_bf16(tile[tx][i]);
+    }
+}
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = bf16_to_f32(src[i]);
+}
+
+// generic 4-d permuting copy: dst is dense (d0,d1,d2,d3); src element strides given per dst dim
+template <typename SrcT, typename DstT>
+__global__ void permute4_kernel(const SrcT* __restrict__ src, DstT* __restrict__ dst, int d0, int d1, int d2, int d3,
+                                long long s0, long long s1, long long s2, long long s3) {
+    const long long n = (long long)d0 * d1 * d2 * d3;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int i3 = r % d3; r /= d3;
+        const int i2 = r % d2; r /= d2;
+        const int i1 = r % d1; r /= d1;
+        const int i0 = (int)r;
+        const SrcT v = src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+        float f;
+        if (sizeof(SrcT) == 2) f = bf16_to_f32((uint16_t)v); else f = (float)v;
+        if (sizeof(DstT) == 2) dst[i] = (DstT)f32_to_bf16(f); else dst[i] = (DstT)f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col / col2im
+// col[(t, b, ho)][(kh, kw, ci)] = x[t + kw - (KW-1), b, ho + kh - ph, ci]   (zero outside), row pitch Kp >= KH*KW*Cin
+template <typename SrcT>
+__global__ void im2col_kernel(const SrcT* __restrict__ x, long long sT, long long sB, long long sH, long long sC, int T,
+                              int B, int Hin, int Cin, int KH, int KW, int ph, int Hout, int Kp,
+                              uint16_t* __restrict__ col) {
+    const long long rows = (long long)T * B * Hout;
+    const long long n = rows * Kp;
+    const int Kreal = KH * KW * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        long long row = i / Kp;
+        uint16_t out = 0;
+        if (k < Kreal) {
+            const int ci = k % Cin;
+            const int kw = (k / Cin) % KW;
+            const int kh = k / (Cin * KW);
+            const int ho = (int)(row % Hout); row /= Hout;
+            const int b = (int)(row % B);
+            const int t = (int)(row / B);
+            const int ti = t + kw - (KW - 1), hi = ho + kh - ph;
+            if (ti >= 0 && hi >= 0 && hi < Hin) {
+                const SrcT v = x[ti * sT + b * sB + hi * sH + ci * sC];
+                if (sizeof(SrcT) == 2) out = (uint16_t)v; else out = f32_to_bf16((float)v);
+            }
+        }
+        col[i] = out;
+    }
+}
+// dx[t, b, h, ci] = sum_{kh,kw} dcol[(t - kw + KW-1, b, h - kh + ph)][(kh, kw, ci)]   (gather form, no atomics)
+__global__ void col2im_kernel(const uint16_t* __restrict__ dcol, int T, int B, int Hin, int Cin, int KH, int KW, int ph,
+                              int Hout, int Kp, uint16_t* __restrict__ dx) {
+    const long long n = (long long)T * B * Hin * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int ci = (int)(r % Cin); r /= Cin;
+        const int h = (int)(r % Hin); r /= Hin;
+        const int b = (int)(r % B);
+        const int t = (int)(r / B);
+        float acc = 0.f;
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ho = h - kh + ph;
+            if (ho < 0 || ho >= Hout) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int to = t - kw + (KW - 1);
+                if (to >= T) continue;
+                acc += bf16_to_f32(dcol[(((long long)to * B + b) * Hout + ho) * Kp + (kh * KW + kw) * Cin + ci]);
+            }
+        }
+        dx[i] = f32_to_bf16(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ maxout(2)
+// y[r][c] = max(x[r][2c], x[r][2c+1]); rows of width 2*C (x) / C (y).  n = rows * C outputs.
+__global__ void maxout2_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long n) {
+    const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t p = x2[i];
+        const float a = bf16_to_f32((uint16_t)(p & 0xffff)), b = bf16_to_f32((uint16_t)(p >> 16));
+        y[i] = (b > a) ? (uint16_t)(p >> 16) : (uint16_t)(p & 0xffff);     // ties -> first element (argmax)
+    }
+}
+__global__ void maxout2_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                   uint16_t* __restrict__ dx, long long n) {
+    const uint32_t* x2 = reinterpret_cast<const uint32_t*>(x);
+    uint32_t* dx2 = reinterpret_cast<uint32_t*>(dx);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t p = x2[i];
+        const float a = bf16_to_f32((uint16_t)(p & 0xffff)), b = bf16_to_f32((uint16_t)(p >> 16));
+        const uint32_t g = dy[i];
+        dx2[i] = (b > a) ? (g << 16) : g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ max-pool over H
+// x (R, Hin, C) -> y (R, Hout, C); window k, stride k, cover_all (window may overhang the end)
+__global__ void maxpool_h_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long R, int Hin,
+                                     int Hout, int C, int k) {
+    const long long n = R * Hout * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ho = (int)((i / C) % Hout);
+        const long long r = i / ((long long)C * Hout);
+        const uint16_t* src = x + (r * Hin) * C + c;
+        float m = -INFINITY;
+        uint16_t mv = 0xff80;   // -inf in bf16
+        for (int j = 0; j < k; ++j) {
+            const int h = ho * k + j;
+            if (h >= Hin) break;
+            const uint16_t v = src[(long long)h * C];
+            const float f = bf16_to_f32(v);
+            if (f > m) { m = f; mv = v; }
+        }
+        y[i] = mv;
+    }
+}
+__global__ void maxpool_h_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                     uint16_t* __restrict__ dx, long long R, int Hin, int Hout, int C, int k) {
+    const long long n = R * Hout * C;     // one thread per window: writes its k inputs
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ho = (int)((i / C) % Hout);
+        const long long r = i / ((long long)C * Hout);
+        const uint16_t* src = x + (r * Hin) * C + c;
+        uint16_t* dst = dx + (r * Hin) * C + c;
+        float m = -INFINITY;
+        int am = 0;
+        for (int j = 0; j < k; ++j) {
+            const int h = ho * k + j;
+            if (h >= Hin) break;
+            const float f = bf16_to_f32(src[(long long)h * C]);
+            if (f > m) { m = f; am = j; }
+        }
+        const uint16_t g = dy[i];
+        for (int j = 0; j < k; ++j) {
+            const int h = ho * k + j;
+            if (h >= Hin) break;
+            dst[(long long)h * C] = (j == am) ? g : (uint16_t)0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ add / column sum
+__global__ void add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y,
+                                long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = f32_to_bf16(bf16_to_f32(a[i]) + bf16_to_f32(b[i]));
+}
+// out[c] += sum_r x[r][c]; grid.x over column blocks of 64, grid.y over row chunks; one atomic per (block, column)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long long rows, int cols, int ld, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    const long long chunk = (rows + gridDim.y - 1) / gridDim.y;
+    const long long r0 = blockIdx.y * chunk, r1 = min(rows, r0 + chunk);
+    float s = 0.f;
+    if (c < cols)
+        for (long long r = r0 + w; r < r1; r += 4) {
+            const T v = x[r * ld + c];
+            s += sizeof(T) == 2 ? bf16_to_f32((uint16_t)v) : (float)v;
+        }
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+}  // namespace ew
+}  // namespace asr
+
+using namespace asr;
+using namespace asr::ew;
+
+extern "C" int asr_cast_bf16(void* stream, const float* src, void* dst, int rows, int cols, int transpose) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return ASR_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+        const long long n = (long long)rows * cols;
+        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, src, (uint16_t*)dst, n);
+    } else {
+        hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, src,
+                           (uint16_t*)dst, rows, cols);
+    }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_bf16_to_f32(void* stream, const void* src, float* dst, long long n) {
+    if (!src || !dst || n <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)src, dst, n);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_permute4(void* stream, const void* src, int src_bf16, void* dst, int dst_bf16, int d0, int d1, int d2,
+                            int d3, long long s0, long long s1, long long s2, long long s3) {
+    if (!src || !dst || d0 <= 0 || d1 <= 0 || d2 <= 0 || d3 <= 0) return ASR_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)d0 * d1 * d2 * d3;
+    const dim3 g(grid_for(n)), b(kThreads);
+    if (src_bf16 && dst_bf16)
+        hipLaunchKernelGGL((permute4_kernel<uint16_t, uint16_t>), g, b, 0, s, (const uint16_t*)src, (uint16_t*)dst, d0, d1, d2, d3, s0, s1, s2, s3);
+    else if (src_bf16)
+        hipLaunchKernelGGL((permute4_kernel<uint16_t, float>), g, b, 0, s, (const uint16_t*)src, (float*)dst, d0, d1, d2, d3, s0, s1, s2, s3);
+    else if (dst_bf16)
+        hipLaunchKernelGGL((permute4_kernel<float, uint16_t>), g, b, 0, s, (const float*)src, (uint16_t*)dst, d0, d1, d2, d3, s0, s1, s2, s3);
+    else
+        hipLaunchKernelGGL((permute4_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, d0, d1, d2, d3, s0, s1, s2, s3);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_im2col(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC,
+                          int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp, void* col) {
+    if (!x || !col || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || pad_h < 0) return ASR_ERR_BAD_ARG;
+    const int Hout = Hin + 2 * pad_h - KH + 1;
+    if (Hout <= 0 || Kp < KH * KW * Cin) return ASR_ERR_BAD_ARG;
+    const long long n = (long long)T * B * Hout * Kp;
+    hipStream_t s = (hipStream_t)stream;
+    if (x_bf16)
+        hipLaunchKernelGGL(im2col_kernel<uint16_t>, dim3(grid_for(n)), dim3(kThreads), 0, s, (const uint16_t*)x, sT, sB, sH,
+                           sC, T, B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)col);
+    else
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(n)), dim3(kThreads), 0, s, (const float*)x, sT, sB, sH, sC,
+                           T, B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)col);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, int KH, int KW, int pad_h,
+                          int Kp, void* dx) {
+    if (!dcol || !dx || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0) return ASR_ERR_BAD_ARG;
+    const int Hout = Hin + 2 * pad_h - KH + 1;
+    if (Hout <= 0 || Kp < KH * KW * Cin) return ASR_ERR_BAD_ARG;
+    const long long n = (long long)T * B * Hin * Cin;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)dcol, T,
+                       B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)dx);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out) {
+    if (!x || !y || n_out <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(maxout2_fwd_kernel, dim3(grid_for(n_out)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, n_out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out) {
+    if (!x || !dy || !dx || n_out <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(maxout2_bwd_kernel, dim3(grid_for(n_out)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, n_out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k) {
+    if (!x || !y || R <= 0 || Hin <= 0 || C <= 0 || k <= 0) return ASR_ERR_BAD_ARG;
+    const int Hout = Hin <= k ? 1 : cdiv(Hin - k, k) + 1;     // cover_all = True, stride = k
+    const long long n = R * Hout * C;
+    hipLaunchKernelGGL(maxpool_h_fwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, R, Hin, Hout, C, k);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_maxpool_h_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C,
+                                 int k) {
+    if (!x || !dy || !dx || R <= 0 || Hin <= 0 || C <= 0 || k <= 0) return ASR_ERR_BAD_ARG;
+    const int Hout = Hin <= k ? 1 : cdiv(Hin - k, k) + 1;
+    const long long n = R * Hout * C;
+    hipLaunchKernelGGL(maxpool_h_bwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, R, Hin, Hout, C, k);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_add_bf16(void* stream, const void* a, const void* b, void* y, long long n) {
+    if (!a || !b || !y || n <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)a,
+                       (const uint16_t*)b, (uint16_t*)y, n);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long rows, int cols, int ld, float* out) {
+    if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return ASR_ERR_BAD_ARG;
+    int chunks = (int)((rows + 255) / 256);
+    if (chunks > 128) chunks = 128;
+    const dim3 g(cdiv(cols, 64), chunks);
+    if (x_bf16)
+        hipLaunchKernelGGL(colsum_kernel<uint16_t>, g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, rows, cols, ld, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld, out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

@@ -1,0 +1,320 @@
+// bf16 MFMA GEMMs for the dense projections of the acoustic model (gfx950, wave64, v_mfma_f32_16x16x32_bf16).
+//
+//   NT:  C[M,N] = A[M,K] * B[N,K]^T (+ bias[N])      forward projections (x W^T) and backward-data (dy W, with W^T copy)
+//   TN:  C[M,N] += A[K,M]^T * B[K,N]                 weight gradients (dW = dy^T x), split-K, f32 atomics
+//
+// Replaces the cuBLAS/cuDNN calls behind chainer.links.Linear / ConvolutionND(ksize=1) (asr/nn/convolution_1d.py:7-38),
+// the SRU projection asr/nn/sru.py:340-341 (forward) / :421-429 (backward) and, through im2col, Convolution2D.
+//
+// Tile 128 x 128 x 64, 256 threads = 2 x 2 waves, each wave 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs).
+// NT: operands are k-contiguous -> LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7), fragments by ds_read_b128.
+// TN: operands are k-strided    -> LDS keeps the global [k][m] order (rows padded to 288 B), fragments by
+//     ds_read_b64_tr_b16 (hardware transpose).  The k slots of a fragment are permuted (same permutation for A and B).
+#include "common.hpp"
+#include "../../include/asr_hip.h"
+
+namespace asr {
+namespace gemm {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NT_LDS_BYTES = 2 * (BM + BN) * BK * 2;   // 64 KiB, double buffered
+
+union Frag {
+    bf16x8 v;
+    uint4 u;
+    bf16x4 h[2];
+};
+
+__device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <typename OutT>
+__device__ __forceinline__ void store_out(OutT* p, float v);
+template <>
+__device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store_out<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// ------------------------------------------------------------------------------------------------ NT
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict__ A, int lda,
+                                                      const uint16_t* __restrict__ B, int ldb, OutT* __restrict__ C,
+                                                      int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                      int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware order: consecutive workgroup ids of one XCD walk along N first (they share the A panel in that L2)
+    const int bid = blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    char* As = smem;                          // [2][BM][BK] bf16
+    char* Bs = smem + 2 * BM * BK * 2;        // [2][BN][BK] bf16
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            const int k = k0 + c * 8;
+            const int gm = m0 + row, gn = n0 + row;
+            ra[i] = (gm < M && k < K) ? ld16(A + (size_t)gm * lda + k) : make_uint4(0, 0, 0, 0);
+            rb[i] = (gn < N && k < K) ? ld16(B + (size_t)gn * ldb + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 3, c = id & 7;
+            const int off = row * (BK * 2) + ((c ^ (row & 7)) << 4);
+            *reinterpret_cast<uint4*>(As + buf * (BM * BK * 2) + off) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + buf * (BN * BK * 2) + off) = rb[i];
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_global((kt + 1) * BK);
+        const char* Ab = As + buf * (BM * BK * 2);
+        const char* Bb = Bs + buf * (BN * BK * 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag a[4], b[4];
+            const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ar = wm * 64 + i * 16 + (lane & 15);
+                a[i].u = *reinterpret_cast<const uint4*>(Ab + ar * (BK * 2) + ((chunk ^ (ar & 7)) << 4));
+                const int br = wn * 64 + i * 16 + (lane & 15);
+                b[i].u = *reinterpret_cast<const uint4*>(Bb + br * (BK * 2) + ((chunk ^ (br & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: stage 64 rows at a time through LDS (f32, row pitch 132 floats) and write whole rows
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CP = BN + 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * CP + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        // 64 rows x 128 cols, 4 columns per thread-iteration
+        for (int id = tid; id < 64 * (BN / 4); id += 256) {
+            const int row = id / (BN / 4), c4 = (id - row * (BN / 4)) * 4;
+            const int gm = m0 + half * 64 + row, gn = n0 + c4;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            OutT* dst = C + (size_t)gm * ldc + gn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (gn + e < N) {
+                    float x = vv[e];
+                    if (bias) x += bias[gn + e];
+                    vv[e] = x;
+                }
+            }
+            if (gn + 3 < N && ((((uintptr_t)dst) & (sizeof(OutT) * 4 - 1)) == 0)) {
+                if (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(vv[0]) | ((uint32_t)f32_to_bf16(vv[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(vv[2]) | ((uint32_t)f32_to_bf16(vv[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) store_out<OutT>(dst + e, vv[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ TN
+constexpr int TK = 32;               // k rows per LDS tile (one MFMA K step)
+constexpr int TP = BM + 16;          // padded row pitch in elements (288 B): 8 consecutive rows cover all 64 banks
+constexpr int TN_LDS_BYTES = 2 * 2 * TK * TP * 2;   // A and B tiles, double buffered = 36 KiB
+
+__device__ __forceinline__ bf16x4 lds_tr16(const uint16_t* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+                                                      const uint16_t* __restrict__ B, int ldb, float* __restrict__ C,
+                                                      int ldc, int M, int N, int K, int tiles_n, int k_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
+    uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
+    const int bid = blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    if (kbeg >= kend) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // a tile is 32 rows x 128 elements = 32 x 16 chunks of 16 B -> 2 chunks per thread per operand
+    uint4 ra[2], rb[2];
+    const bool a_vec = (lda & 7) == 0, b_vec = (ldb & 7) == 0;
+    auto load_one = [&](const uint16_t* P, int ld, bool vec, int gk, int gc, int lim) -> uint4 {
+        if (gk >= kend) return make_uint4(0, 0, 0, 0);
+        const uint16_t* src = P + (size_t)gk * ld + gc;
+        if (vec && gc + 8 <= lim && ((((uintptr_t)src) & 15) == 0)) return ld16(src);
+        union { uint4 u; uint16_t s[8]; } t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t.s[e] = (gc + e < lim) ? src[e] : (uint16_t)0;
+        return t.u;
+    };
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 4, c = id & 15;
+            ra[i] = load_one(A, lda, a_vec, k0 + row, m0 + c * 8, M);
+            rb[i] = load_one(B, ldb, b_vec, k0 + row, n0 + c * 8, N);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256;
+            const int row = id >> 4, c = id & 15;
+            *reinterpret_cast<uint4*>(As + (buf * TK + row) * TP + c * 8) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + (buf * TK + row) * TP + c * 8) = rb[i];
+        }
+    };
+
+    // transpose-read addressing: 16-lane group g = lane >> 4, lane 4q+p of the group points at row q, columns 4p..4p+3;
+    // first read covers k rows 4g..4g+3, second read 16+4g..16+4g+3 (k slots permuted identically for A and B)
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int trow0 = 4 * g + q, trow1 = 16 + 4 * g + q, tcol = 4 * p;
+
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    load_global(kbeg);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_global(kbeg + (kt + 1) * TK);
+        const uint16_t* Ab = As + buf * TK * TP;
+        const uint16_t* Bb = Bs + buf * TK * TP;
+        Frag a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ac = wm * 64 + i * 16 + tcol;
+            a[i].h[0] = lds_tr16(Ab + trow0 * TP + ac);
+            a[i].h[1] = lds_tr16(Ab + trow1 * TP + ac);
+            const int bc = wn * 64 + i * 16 + tcol;
+            b[i].h[0] = lds_tr16(Bb + trow0 * TP + bc);
+            b[i].h[1] = lds_tr16(Bb + trow1 * TP + bc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = n0 + wn * 64 + j * 16 + (lane & 15);
+                if (gm < M && gn < N) atomicAdd(C + (size_t)gm * ldc + gn, acc[i][j][r]);
+            }
+}
+
+}  // namespace gemm
+}  // namespace asr
+
+using namespace asr;
+using namespace asr::gemm;
+
+extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                           const float* bias, int M, int N, int K, int out_bf16) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
+    if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return ASR_ERR_BAD_ARG;
+    if ((((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return ASR_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr_set = true;
+    }
+    if (out_bf16)
+        hipLaunchKernelGGL(gemm_nt_kernel<uint16_t>, dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_n);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M,
+                               int N, int K) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
+    if (lda < M || ldb < N || ldc < N) return ASR_ERR_BAD_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    // split K so that about 4 workgroups per CU are in flight, each split a multiple of the k tile
+    int splits = cdiv(1024, tiles_m * tiles_n);
+    const int max_splits = cdiv(K, 8 * TK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int k_per_split = cdiv(cdiv(K, splits), TK) * TK;
+    splits = cdiv(K, k_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
+                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

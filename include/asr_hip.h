@@ -45,6 +45,75 @@ int asr_ctc_loss_grad(void* stream, const float* xs, const int32_t* label_unigra
                       const int32_t* x_len, const int32_t* l_len, int T, int B, int V, int Lmax, int blank, float scale,
                       float* loss_per_utt, float* loss_mean, float* grad, void* workspace, size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------------------- dense projections
+ * bf16 MFMA GEMMs (f32 accumulate).  Replace the BLAS/cuDNN calls behind chainer.links.Linear, the 1x1
+ * ConvolutionND of asr/nn/convolution_1d.py:7-38, the SRU projection asr/nn/sru.py:340-341,421-429 and -- through
+ * asr_im2col / asr_col2im -- chainer.links.Convolution2D (asr/nn/nn.py:235-238).
+ *   asr_gemm_nt      C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]);  A, B bf16 (k-contiguous, lda/ldb/K multiples of 8,
+ *                    16-byte aligned); C f32 (out_bf16 = 0) or bf16 (1)
+ *   asr_gemm_tn_acc  C[M,N] += A[K,M]^T * B[K,N];  A, B bf16 row-major; C f32, accumulated with atomics (split-K)
+ */
+int asr_gemm_nt(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                int M, int N, int K, int out_bf16);
+int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K);
+
+/* ---------------------------------------------------------------------------------------- layout / activations
+ * Internal activations are (T, B, H, C) bf16 (time-major, channel-last); see DESIGN.md "Data layout in HBM".
+ *   asr_cast_bf16     f32 (rows, cols) -> bf16, optionally transposed to (cols, rows)    [weight copies]
+ *   asr_permute4      dense dst (d0,d1,d2,d3) <- strided src (element strides s0..s3), f32/bf16 either side
+ *   asr_im2col        col[(t,b,ho)][(kh,kw,ci)] (row pitch Kp, zero padded) from x with element strides
+ *                     (sT,sB,sH,sC); causal in time: reads t+kw-(KW-1)  == pad (KW-1) both sides then x[..., :-pad]
+ *                     (run/ctc/cnn/model.py:43-44); pad_h rows of zero padding in height
+ *   asr_col2im        adjoint of asr_im2col for a (T,B,Hin,Cin) bf16 input gradient
+ *   asr_maxout2_*     nn.Maxout(2): asr/nn/nn.py:45-50 (pairs of adjacent channels; ties -> first)
+ *   asr_maxpool_h_*   nn.MaxPooling2D(ksize=(k,1)): asr/nn/nn.py:95-103, stride k, cover_all=True
+ *   asr_add_bf16      residual add (asr/nn/nn.py:322-328)
+ *   asr_colsum_acc    out[c] += sum_r x[r][c]   (bias gradients)
+ */
+int asr_cast_bf16(void* stream, const float* src, void* dst, int rows, int cols, int transpose);
+int asr_bf16_to_f32(void* stream, const void* src, float* dst, long long n);
+int asr_permute4(void* stream, const void* src, int src_bf16, void* dst, int dst_bf16, int d0, int d1, int d2, int d3,
+                 long long s0, long long s1, long long s2, long long s3);
+int asr_im2col(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,
+               int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp, void* col);
+int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp,
+               void* dx);
+int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);
+int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out);
+int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
+int asr_maxpool_h_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
+int asr_add_bf16(void* stream, const void* a, const void* b, void* y, long long n);
+int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long rows, int cols, int ld, float* out);
+
+/* ---------------------------------------------------------------------------------------- layer normalisation
+ * nn.LayerNormalization (asr/nn/nn.py:240-265) = NormalizeLayer (asr/nn/layernorm.py:29-64) + scale/bias on axis 1.
+ * rows = T*B, D = H*C contiguous per row, channel = index % C.  No epsilon (the reference ignores it).
+ */
+int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* y, int y_bf16, const float* gamma,
+                      const float* beta, float* mean, float* rstd, long long rows, int D, int C);
+int asr_layernorm_bwd(void* stream, const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma,
+                      const float* mean, const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta,
+                      long long rows, int D, int C);
+
+/* ---------------------------------------------------------------------------------------- (Bi)GRU recurrence
+ * nn.GRU / nn.NStepBiGRU reach the reference API through `from chainer.links import *` (asr/nn/nn.py:3); gate
+ * convention = cuDNN / torch.nn.GRU (r, z, n).  Layouts in csrc/gru.hip.  gi comes from asr_gemm_nt.
+ */
+int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
+                float* gates, void* y_bf16, int T, int B, int H, int ndir);
+int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
+                void* dgi_bf16, void* dgh_bf16, float* carry_ws, int T, int B, int H, int ndir);
+
+/* ---------------------------------------------------------------------------------------- optimiser step
+ * GradientClipping -> WeightDecay -> Adam over one flat buffer (run/ctc/cnn/train.py:142-147,200).
+ * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
+ */
+int asr_fill_f32(void* stream, float* p, long long n, float value);
+int asr_sqnorm_acc(void* stream, const float* g, long long n, float* out);
+int asr_clip_decay_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, float alpha,
+                        float beta1, float beta2, float eps, float weight_decay, float clip_threshold,
+                        float grad_scale, const float* sqnorm, int step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,258 @@
+"""Each HIP kernel (through the C ABI) against the CPU oracle / torch-CPU fp32 on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _bf(t):
+    """round an f32 CPU tensor to bf16 precision (keeps f32 dtype)"""
+    return t.to(BF16).to(F32)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 96, 72), (129, 130, 64), (1000, 1536, 384), (64, 3000, 320), (4096, 640, 512)])
+@pytest.mark.parametrize("out_dtype", [BF16, F32])
+def test_gemm_nt(device, M, N, K, out_dtype):
+    from asr import _ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g))
+    b = _bf(torch.randn(N, K, generator=g))
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ b.double().T + bias.double()
+    out = _ops.gemm_nt(a.to(device, BF16), b.to(device, BF16), bias.to(device), out_dtype).cpu().float()
+    tol = 1e-5 if out_dtype == F32 else 4e-3
+    assert _rel(out, ref) < tol
+    out2 = _ops.gemm_nt(a.to(device, BF16), b.to(device, BF16), None, F32).cpu()
+    assert _rel(out2, a.double() @ b.double().T) < 1e-5
+
+
+def test_gemm_nt_asymmetric_identity(device):
+    """A = I with an asymmetric B catches a transposed accumulator write (row/col swap)."""
+    from asr import _ops
+    n = 128
+    a = torch.eye(n)
+    b = torch.arange(n * n, dtype=F32).reshape(n, n) % 251 - 100     # exactly representable in bf16
+    out = _ops.gemm_nt(a.to(device, BF16), b.to(device, BF16), None, F32).cpu()
+    assert torch.equal(out, b.T.contiguous())
+
+
+@pytest.mark.parametrize("K,M,N", [(1000, 130, 70), (333, 48, 960), (4096, 1536, 512), (2048, 3000, 320)])
+def test_gemm_tn_acc(device, K, M, N):
+    from asr import _ops
+    g = torch.Generator().manual_seed(K + M + N)
+    a = _bf(torch.randn(K, M, generator=g))
+    b = _bf(torch.randn(K, N, generator=g))
+    c0 = torch.randn(M, N, generator=g)
+    ref = c0.double() + a.double().T @ b.double()
+    c = c0.to(device)
+    _ops.gemm_tn_acc(a.to(device, BF16), b.to(device, BF16), c)
+    assert _rel(c.cpu(), ref) < 1e-5
+
+
+def test_gemm_tn_exact_integers(device):
+    """small integers: exact in bf16 and f32, so any k-slot mix-up between A and B shows as a wrong integer."""
+    from asr import _ops
+    g = torch.Generator().manual_seed(0)
+    K, M, N = 96, 40, 24
+    a = torch.randint(-4, 5, (K, M), generator=g).float()
+    b = torch.randint(-4, 5, (K, N), generator=g).float()
+    c = torch.zeros(M, N, device=device)
+    _ops.gemm_tn_acc(a.to(device, BF16), b.to(device, BF16), c)
+    assert torch.equal(c.cpu(), a.T @ b)
+
+
+def test_gemm_tn_strided_views(device):
+    from asr import _ops
+    g = torch.Generator().manual_seed(3)
+    K, M, N = 500, 96, 64
+    big_a = _bf(torch.randn(K, 3 * M, generator=g))
+    big_b = _bf(torch.randn(K, 2 * N, generator=g))
+    c = torch.zeros(M, N, device=device)
+    _ops.gemm_tn_acc(big_a.to(device, BF16)[:, M:2 * M], big_b.to(device, BF16)[:, N:], c)
+    ref = big_a[:, M:2 * M].double().T @ big_b[:, N:].double()
+    assert _rel(c.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,Cin,Hin,T,Cout,pad_h,first", [(2, 3, 12, 37, 16, 0, True), (3, 8, 13, 50, 24, 0, False),
+                                                          (2, 16, 9, 33, 32, 1, False)])
+def test_conv_as_im2col_gemm(device, B, Cin, Hin, T, Cout, pad_h, first):
+    """forward, input gradient (col2im) and weight gradient of the causal conv vs torch conv2d."""
+    from asr import _ops
+    g = torch.Generator().manual_seed(T)
+    KH, KW = 3, 5
+    x = _bf(torch.randn(B, Cin, Hin, T, generator=g))
+    W = _bf(torch.randn(Cout, Cin, KH, KW, generator=g) * 0.2)
+    bias = torch.randn(Cout, generator=g)
+    xr = x.clone().requires_grad_(True)
+    Wr = W.clone().requires_grad_(True)
+    y_ref = onn.conv2d_causal(xr, Wr, bias, pad_h)
+    Hout = y_ref.shape[2]
+    gy = _bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy)
+    if first:   # reference layout (B, C, H, T) f32 straight from the loader
+        xd = x.to(device)
+        strides = (xd.stride(3), xd.stride(0), xd.stride(2), xd.stride(1))
+    else:       # internal layout (T, B, H, C) bf16
+        xd = x.permute(3, 0, 2, 1).contiguous().to(device, BF16)
+        strides = tuple(xd.stride())
+    col = _ops.im2col(xd, strides, T, B, Hin, Cin, KH, KW, pad_h)
+    Kp = col.shape[1]
+    Wm = torch.zeros(Cout, Kp)
+    Wm[:, :KH * KW * Cin] = W.permute(0, 2, 3, 1).reshape(Cout, -1)       # k = (kh, kw, ci)
+    y = _ops.gemm_nt(col, Wm.to(device, BF16), bias.to(device), F32)      # rows (t, b, ho)
+    y = y.reshape(T, B, Hout, Cout).permute(1, 3, 2, 0).cpu()
+    assert _rel(y, y_ref.detach()) < 1e-5
+    gyd = gy.permute(3, 0, 2, 1).reshape(T * B * Hout, Cout).contiguous().to(device, BF16)
+    dW = torch.zeros(Cout, Kp, device=device)
+    _ops.gemm_tn_acc(gyd, col, dW)
+    dW = dW[:, :KH * KW * Cin].reshape(Cout, KH, KW, Cin).permute(0, 3, 1, 2).cpu()
+    assert _rel(dW, Wr.grad) < 1e-5
+    dcol = _ops.gemm_nt(gyd, Wm.T.contiguous().to(device, BF16), None, BF16)
+    dx = _ops.col2im(dcol, T, B, Hin, Cin, KH, KW, pad_h).float().permute(1, 3, 2, 0).cpu()
+    assert _rel(dx, xr.grad) < 6e-3       # dcol is rounded to bf16 before the 15-tap gather
+
+
+def test_maxout_and_maxpool(device):
+    from asr import _ops
+    g = torch.Generator().manual_seed(9)
+    B, C, H, T = 3, 16, 11, 21
+    x = _bf(torch.randn(B, C, H, T, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = onn.maxout2(xr)
+    gy = _bf(torch.randn(y_ref.shape, generator=g))
+    y_ref.backward(gy)
+    xd = x.permute(3, 0, 2, 1).contiguous().to(device, BF16)
+    y = _ops.maxout2_fwd(xd)
+    assert torch.equal(y.float().permute(1, 3, 2, 0).cpu(), y_ref.detach())
+    dx = _ops.maxout2_bwd(xd, gy.permute(3, 0, 2, 1).contiguous().to(device, BF16))
+    assert torch.equal(dx.float().permute(1, 3, 2, 0).cpu(), xr.grad)
+    for k, Hin in ((3, 38), (2, 11), (2, 4), (3, 11)):
+        x = _bf(torch.randn(B, C, Hin, T, generator=g))
+        xr = x.clone().requires_grad_(True)
+        y_ref = onn.maxpool_h(xr, k)
+        gy = _bf(torch.randn(y_ref.shape, generator=g))
+        y_ref.backward(gy)
+        xd = x.permute(3, 0, 2, 1).contiguous().to(device, BF16)
+        y = _ops.maxpool_h_fwd(xd, k)
+        assert y.shape[2] == y_ref.shape[2]
+        assert torch.equal(y.float().permute(1, 3, 2, 0).cpu(), y_ref.detach())
+        dx = _ops.maxpool_h_bwd(xd, gy.permute(3, 0, 2, 1).contiguous().to(device, BF16), k)
+        assert torch.equal(dx.float().permute(1, 3, 2, 0).cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("B,C,H,T", [(5, 3, 40, 10), (2, 3000, 1, 7), (3, 64, 6, 9)])
+def test_layernorm(device, B, C, H, T):
+    """same shapes/ranges as the reference's own test (asr/nn/test_layernorm.py:30-43) plus the logit shape."""
+    from asr import _ops
+    rs = np.random.RandomState(C)
+    x = rs.uniform(-10, 10, (B, C, H, T)).astype(np.float32)
+    gy = rs.uniform(-1, 1, (B, C, H, T)).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rs.uniform(-1, 1, C).astype(np.float32)
+    y_ref, cache = onn.layer_normalization(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64))
+    dx_ref, dg_ref, db_ref = onn.layer_normalization_bwd(gy.astype(np.float64), gamma.astype(np.float64), cache)
+    xd = torch.tensor(x).permute(3, 0, 2, 1).reshape(T * B, H * C).contiguous().to(device)
+    gyd = torch.tensor(gy).permute(3, 0, 2, 1).reshape(T * B, H * C).contiguous().to(device)
+    gd, bd = torch.tensor(gamma).to(device), torch.tensor(beta).to(device)
+    y, mean, rstd = _ops.layernorm_fwd(xd, gd, bd, C, F32)
+    y = y.reshape(T, B, H, C).permute(1, 3, 2, 0).cpu().numpy()
+    np.testing.assert_allclose(y, y_ref, rtol=1e-3, atol=1e-3)       # tolerance of asr/nn/test_layernorm.py:45-50
+    np.testing.assert_allclose(y, y_ref, rtol=1e-5, atol=2e-5)
+    dgamma = torch.zeros(C, device=device)
+    dbeta = torch.zeros(C, device=device)
+    dx = _ops.layernorm_bwd(xd, gyd, gd, mean, rstd, C, F32, dgamma, dbeta)
+    dx = dx.reshape(T, B, H, C).permute(1, 3, 2, 0).cpu().numpy()
+    np.testing.assert_allclose(dx, dx_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), dg_ref, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("T,B,I,H,ndir", [(12, 4, 64, 64, 2), (9, 5, 96, 128, 1), (20, 32, 64, 512, 2), (7, 40, 32, 64, 2)])
+def test_gru_step_kernels(device, T, B, I, H, ndir):
+    """forward states and all gradients of the (Bi)GRU against torch.nn.GRU on CPU (weights rounded to bf16)."""
+    from asr import _ops
+    g = torch.Generator().manual_seed(T * H)
+    k = 1.0 / np.sqrt(H)
+    P = dict(w_ih=_bf(torch.empty(ndir, 3 * H, I).uniform_(-k, k, generator=g)),
+             w_hh=_bf(torch.empty(ndir, 3 * H, H).uniform_(-k, k, generator=g)),
+             b_ih=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g),
+             b_hh=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g))
+    x = _bf(torch.randn(T, B, I, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref, ref = onn.bigru_sum(xr, P, H, ndir)
+    gy = _bf(torch.randn(T, B, H, generator=g))
+    y_ref.backward(gy)
+    xd = x.reshape(T * B, I).to(device, BF16)
+    wih = P["w_ih"].reshape(ndir * 3 * H, I).to(device, BF16)
+    gi = _ops.gemm_nt(xd, wih, P["b_ih"].reshape(-1).to(device), F32)
+    whh = P["w_hh"].to(device, BF16).contiguous()
+    y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh, P["b_hh"].reshape(-1).to(device), T, B, H, ndir)
+    assert _rel(y.float().cpu().reshape(T, B, H), y_ref.detach()) < 6e-3
+    whhT = P["w_hh"].transpose(1, 2).contiguous().to(device, BF16)
+    dgi, dgh = _ops.gru_bwd(gy.reshape(T * B, H).to(device, BF16), gates, hseq, whhT, T, B, H, ndir)
+    dx = _ops.gemm_nt(dgi, wih.T.contiguous(), None, F32).cpu().reshape(T, B, I)
+    assert _rel(dx, xr.grad) < 2e-2
+    dwih = torch.zeros(ndir * 3 * H, I, device=device)
+    _ops.gemm_tn_acc(dgi, xd, dwih)
+    sufs = ["", "_reverse"][:ndir]
+    ref_dwih = torch.cat([getattr(ref, "weight_ih_l0" + s).grad for s in sufs])
+    assert _rel(dwih.cpu(), ref_dwih) < 2e-2
+    dbih = torch.zeros(ndir * 3 * H, device=device)
+    _ops.colsum_acc(dgi, dbih)
+    assert _rel(dbih.cpu(), torch.cat([getattr(ref, "bias_ih_l0" + s).grad for s in sufs])) < 2e-2
+    dbhh = torch.zeros(ndir * 3 * H, device=device)
+    _ops.colsum_acc(dgh, dbhh)
+    assert _rel(dbhh.cpu(), torch.cat([getattr(ref, "bias_hh_l0" + s).grad for s in sufs])) < 2e-2
+    for d, s in enumerate(sufs):
+        dwhh = torch.zeros(3 * H, H, device=device)
+        a = dgh[:, d * 3 * H:(d + 1) * 3 * H]       # strided 2-d views, rows are (t, b)
+        hb = hseq16[:, d * H:(d + 1) * H]
+        if d == 0:      # h_{t-1} pairs with step t
+            a, hb = a[B:], hb[:-B]
+        else:           # reverse direction: h_{t+1} pairs with step t
+            a, hb = a[:-B], hb[B:]
+        _ops.gemm_tn_acc(a, hb, dwhh)
+        assert _rel(dwhh.cpu(), getattr(ref, "weight_hh_l0" + s).grad) < 2e-2
+
+
+def test_clip_decay_adam(device):
+    from asr import _ops
+    rs = np.random.RandomState(0)
+    n = 100003
+    p = rs.randn(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pd, md, vd = (torch.tensor(a).to(device) for a in (p, m, v))
+    for step in (1, 2, 3):
+        gr = (rs.randn(n) * (10.0 if step == 2 else 0.001)).astype(np.float32)     # step 2 is clipped, the others not
+        gd = torch.tensor(gr).to(device)
+        sq = torch.zeros(1, device=device)
+        _ops.sqnorm_acc(gd, sq)
+        np.testing.assert_allclose(sq.item(), (gr.astype(np.float64) ** 2).sum(), rtol=1e-5)
+        _ops.clip_decay_adam(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0, 1.0, sq, step)
+        p, m, v = onn.clip_decay_adam(p.astype(np.float64), gr.astype(np.float64), m.astype(np.float64), v.astype(np.float64), step)
+        np.testing.assert_allclose(pd.cpu().numpy(), p, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-4, atol=1e-9)
+        p, m, v = (a.astype(np.float32) for a in (p, m, v))
+
+
+def test_cast_transpose_permute(device):
+    from asr import _ops
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(70, 45, generator=g)
+    assert torch.equal(_ops.cast_bf16(w.to(device)).cpu(), w.to(BF16))
+    assert torch.equal(_ops.cast_bf16(w.to(device), transpose=True).cpu(), w.T.contiguous().to(BF16))
+    x = torch.randn(3, 4, 5, 6, generator=g).to(device)
+    y = _ops.permute4(x, (6, 3, 5, 4), (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), BF16)
+    assert torch.equal(y.cpu(), x.permute(3, 0, 2, 1).contiguous().to(BF16).cpu())
