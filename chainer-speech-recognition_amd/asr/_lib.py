@@ -28,8 +28,15 @@ SIGNATURES = {
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "asr_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong]),
     "asr_permute4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 4 + [c_longlong] * 4),
-    "asr_im2col": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 9 + [c_void_p]),
-    "asr_col2im": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "asr_im2col": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 10 + [c_void_p]),
+    "asr_col2im": (c_int, [c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "asr_activation_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_float]),
+    "asr_activation_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int, c_float]),
+    "asr_glu_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int]),
+    "asr_glu_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int]),
+    "asr_dropout": (c_int, [c_void_p] * 3 + [c_longlong, c_float, ctypes.c_uint]),
+    "asr_conv_weight_pack": (c_int, [c_void_p] * 3 + [c_int] * 6),
+    "asr_conv_weight_grad_unpack": (c_int, [c_void_p] * 3 + [c_int] * 5),
     "asr_maxout2_fwd": (c_int, [c_void_p] * 3 + [c_longlong]),
     "asr_maxout2_bwd": (c_int, [c_void_p] * 4 + [c_longlong]),
     "asr_maxpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
@@ -41,8 +48,12 @@ SIGNATURES = {
                                   c_longlong, c_int, c_int]),
     "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
     "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
+    "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4),
+    "asr_sru_bwd": (c_int, [c_void_p] * 13 + [c_int] * 4),
+    "asr_sru_combine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),
     "asr_fill_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_float]),
     "asr_sqnorm_acc": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
+    "asr_clip_decay_sgd": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 5 + [c_void_p]),
     "asr_clip_decay_adam": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 7 + [c_void_p, c_int]),
 }
 

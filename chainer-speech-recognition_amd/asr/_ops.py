@@ -71,21 +71,85 @@ def permute4(src, shape, strides, out_dtype):
     return dst
 
 
-def im2col(x, strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h):
+def im2col(x, strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h, pad_t=None, Tout=None):
+    """pad_t defaults to KW-1 and Tout to T: the causal convolution."""
+    pad_t = KW - 1 if pad_t is None else pad_t
+    Tout = T if Tout is None else Tout
     Kp = (KH * KW * Cin + 7) // 8 * 8
     Hout = Hin + 2 * pad_h - KH + 1
-    col = torch.empty((T * B * Hout, Kp), dtype=BF16, device=x.device)
-    rc = _lib.lib().asr_im2col(stream(), x.data_ptr(), _is_bf16(x), *strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h, Kp,
-                               ptr(col))
+    col = torch.empty((Tout * B * Hout, Kp), dtype=BF16, device=x.device)
+    rc = _lib.lib().asr_im2col(stream(), x.data_ptr(), _is_bf16(x), *strides_tbhc, T, B, Hin, Cin, KH, KW, pad_h, pad_t,
+                               Tout, Kp, ptr(col))
     check(rc, "asr_im2col")
     return col
 
 
-def col2im(dcol, T, B, Hin, Cin, KH, KW, pad_h):
+def col2im(dcol, T, B, Hin, Cin, KH, KW, pad_h, pad_t=None, Tout=None):
+    pad_t = KW - 1 if pad_t is None else pad_t
+    Tout = T if Tout is None else Tout
     Kp = dcol.shape[1]
     dx = torch.empty((T, B, Hin, Cin), dtype=BF16, device=dcol.device)
-    check(_lib.lib().asr_col2im(stream(), ptr(dcol), T, B, Hin, Cin, KH, KW, pad_h, Kp, ptr(dx)), "asr_col2im")
+    check(_lib.lib().asr_col2im(stream(), ptr(dcol), T, B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Kp, ptr(dx)), "asr_col2im")
     return dx
+
+
+def conv_weight_pack(W, transpose=False):
+    """(Co, Ci, kh, kw) f32 -> bf16 (Co, Kp) [or (Kp, Co)], k = (kh, kw, ci), Kp = K rounded up to 8."""
+    assert W.dtype == F32 and W.is_contiguous() and W.dim() == 4
+    Co, Ci, KH, KW = W.shape
+    Kp = (KH * KW * Ci + 7) // 8 * 8
+    dst = torch.empty((Kp, Co) if transpose else (Co, Kp), dtype=BF16, device=W.device)
+    check(_lib.lib().asr_conv_weight_pack(stream(), ptr(W), ptr(dst), Co, Ci, KH, KW, Kp, int(transpose)), "asr_conv_weight_pack")
+    return dst
+
+
+def conv_weight_grad_unpack(scratch, gW):
+    Co, Ci, KH, KW = gW.shape
+    assert scratch.dtype == F32 and scratch.is_contiguous() and gW.is_contiguous()
+    check(_lib.lib().asr_conv_weight_grad_unpack(stream(), ptr(scratch), ptr(gW), Co, Ci, KH, KW, scratch.shape[1]),
+          "asr_conv_weight_grad_unpack")
+
+
+ACT_KINDS = {"relu": 0, "clipped_relu": 1, "leaky_relu": 2, "elu": 3, "sigmoid": 4, "tanh": 5, "hard_sigmoid": 6,
+             "softplus": 7}
+
+
+def activation_fwd(x, kind, alpha=0.0):
+    assert x.dtype == BF16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().asr_activation_fwd(stream(), ptr(x), ptr(y), x.numel(), ACT_KINDS[kind], float(alpha)), "asr_activation_fwd")
+    return y
+
+
+def activation_bwd(x, dy, kind, alpha=0.0):
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_activation_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), x.numel(), ACT_KINDS[kind],
+                                        float(alpha)), "asr_activation_bwd")
+    return dx
+
+
+def glu_fwd(x):
+    """x (..., 2C) bf16 -> (..., C): A * sigmoid(B)."""
+    assert x.dtype == BF16 and x.is_contiguous() and x.shape[-1] % 2 == 0
+    C = x.shape[-1] // 2
+    y = torch.empty(x.shape[:-1] + (C,), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_glu_fwd(stream(), ptr(x), ptr(y), x.numel() // (2 * C), C), "asr_glu_fwd")
+    return y
+
+
+def glu_bwd(x, dy):
+    C = x.shape[-1] // 2
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_glu_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), x.numel() // (2 * C), C), "asr_glu_bwd")
+    return dx
+
+
+def dropout(x, ratio, seed):
+    assert x.dtype == BF16
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().asr_dropout(stream(), ptr(x), ptr(y), x.numel(), float(ratio), int(seed) & 0xffffffff), "asr_dropout")
+    return y
 
 
 def maxout2_fwd(x):
@@ -198,3 +262,39 @@ def clip_decay_adam(p, g, m, v, alpha, beta1, beta2, eps, weight_decay, clip, gr
     rc = _lib.lib().asr_clip_decay_adam(stream(), ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), alpha, beta1, beta2, eps,
                                         weight_decay, clip, grad_scale, ptr(sqnorm), int(step))
     check(rc, "asr_clip_decay_adam")
+
+
+def sru_fwd(x, U, bias, c0, mask, use_tanh):
+    """x (T, B, D) bf16, U (T*B, 3D) f32 -> H bf16, C f32, cT (B, D) f32."""
+    T, B, D = x.shape
+    H = torch.empty_like(x)
+    C = torch.empty((T, B, D), dtype=F32, device=x.device)
+    cT = torch.empty((B, D), dtype=F32, device=x.device)
+    rc = _lib.lib().asr_sru_fwd(stream(), ptr(x), ptr(U), ptr(bias), ptr(c0), ptr(mask), ptr(H), ptr(C), ptr(cT), T, B, D,
+                                int(bool(use_tanh)))
+    check(rc, "asr_sru_fwd")
+    return H, C, cT
+
+
+def sru_bwd(x, U, bias, C, c0, mask, gH, gcT, gbias, use_tanh):
+    T, B, D = x.shape
+    gU = torch.empty((T * B, 3 * D), dtype=BF16, device=x.device)
+    gxh = torch.empty_like(x)
+    gc0 = torch.empty((B, D), dtype=F32, device=x.device)
+    rc = _lib.lib().asr_sru_bwd(stream(), ptr(x), ptr(U), ptr(bias), ptr(C), ptr(c0), ptr(mask), ptr(gH), ptr(gcT), ptr(gU),
+                                ptr(gxh), ptr(gbias), ptr(gc0), T, B, D, int(bool(use_tanh)))
+    check(rc, "asr_sru_bwd")
+    return gU, gxh, gc0
+
+
+def sru_combine(a, b, mask):
+    out = torch.empty_like(a)
+    BD = a.shape[-2] * a.shape[-1]
+    check(_lib.lib().asr_sru_combine(stream(), ptr(a), ptr(b), ptr(mask), ptr(out), a.numel(), BD), "asr_sru_combine")
+    return out
+
+
+def clip_decay_sgd(p, g, v, kind, lr, momentum, weight_decay, clip, grad_scale, sqnorm):
+    rc = _lib.lib().asr_clip_decay_sgd(stream(), ptr(p), ptr(g), ptr(v), p.numel(), int(kind), lr, momentum, weight_decay,
+                                       clip, grad_scale, ptr(sqnorm))
+    check(rc, "asr_clip_decay_sgd")

@@ -1,0 +1,526 @@
+"""Differentiable operators of the hot path: ``torch.autograd.Function`` shells around the C ABI.
+
+This module plays the role ``chainer.functions`` plays for the reference (``import chainer.functions as F`` in
+run/ctc/*/train.py and asr/model/*.py): a maintainer swaps that import for ``import asr.functions as F``.
+
+Conventions
+-----------
+* Tensors keep the reference's LOGICAL shapes -- images (B, C, H, T), sequences (B, D, T) -- but live in HBM
+  time-major / channel-last: the logical tensor is a permuted VIEW of a contiguous (T, B, H, C) or (T, B, D)
+  bf16 buffer ("physical" form).  Array manipulations below are views; nothing here computes with torch.
+* Parameter gradients are accumulated by the HIP kernels straight into ``param.grad`` (a slice of the optimiser's
+  flat gradient buffer); the Functions return ``None`` for parameters.
+"""
+import math
+
+import torch
+
+from . import _ops
+from .link import grad_buffer
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ---------------------------------------------------------------------------------------------- layout helpers
+class _ToPhys(torch.autograd.Function):
+    """any strided f32/bf16 tensor (logical order given by `perm`) -> contiguous bf16 in physical order."""
+
+    @staticmethod
+    def forward(ctx, x, perm):
+        p = x.permute(*perm)
+        shape = tuple(p.shape) + (1,) * (4 - p.dim())
+        strides = tuple(p.stride()) + (0,) * (4 - p.dim())
+        ctx.meta = (x.dtype, perm, tuple(p.shape))
+        return _ops.permute4(x, shape, strides, BF16).reshape(p.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, perm, pshape = ctx.meta
+        inv = [0] * len(perm)
+        for i, a in enumerate(perm):
+            inv[a] = i
+        g = g.contiguous()
+        if dtype == BF16:
+            return g.permute(*inv), None
+        return _ops.bf16_to_f32(g).permute(*inv), None
+
+
+def phys4(x):
+    """logical (B, C, H, T) -> contiguous (T, B, H, C) bf16 (no copy when it already is one)."""
+    if x.dim() != 4:
+        raise ValueError("expected a (B, C, H, T) tensor, got shape %s" % (tuple(x.shape),))
+    p = x.permute(3, 0, 2, 1)
+    if p.dtype == BF16 and p.is_contiguous():
+        return p
+    return _ToPhys.apply(x, (3, 0, 2, 1))
+
+
+def logical4(p):
+    return p.permute(1, 3, 2, 0)
+
+
+def phys3(x):
+    """logical (B, D, T) -> contiguous (T, B, D) bf16."""
+    if x.dim() != 3:
+        raise ValueError("expected a (B, D, T) tensor, got shape %s" % (tuple(x.shape),))
+    p = x.permute(2, 0, 1)
+    if p.dtype == BF16 and p.is_contiguous():
+        return p
+    return _ToPhys.apply(x, (2, 0, 1))
+
+
+def logical3(p):
+    return p.permute(1, 2, 0)
+
+
+def _phys_any(x):
+    """(physical tensor, restore-to-logical fn) for 3-d or 4-d logical input."""
+    if x.dim() == 4:
+        return phys4(x), logical4
+    if x.dim() == 3:
+        return phys3(x), logical3
+    if x.dim() == 2:
+        if x.dtype == BF16 and x.is_contiguous():
+            return x, (lambda p: p)
+        return _ToPhys.apply(x, (0, 1)), (lambda p: p)
+    raise ValueError("unsupported rank %d" % x.dim())
+
+
+# ---------------------------------------------------------------------------------------------- convolution
+class _Conv2D(torch.autograd.Function):
+    """x: ANY strided 4-d (B, C, H, T) tensor (f32 or bf16); W (Co, Ci, kh, kw) f32 master; b (Co) or None.
+    Output physical (Tout, B, Hout, Co) bf16 (or f32)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, w16, w16t, pad_h, pad_t, causal, out_f32):
+        B, Ci, Hin, T = x.shape
+        Co, _, KH, KW = W.shape
+        Tout = T if causal else T + 2 * pad_t - KW + 1
+        Hout = Hin + 2 * pad_h - KH + 1
+        pointwise = KH == 1 and KW == 1 and pad_h == 0 and pad_t == 0
+        xp = None
+        if pointwise:
+            xp = x.permute(3, 0, 2, 1)
+            if not (xp.dtype == BF16 and xp.is_contiguous()):
+                xp = _ops.permute4(x, (T, B, Hin, Ci), (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), BF16)
+            col = xp.reshape(T * B * Hin, Ci)
+            if Ci % 8:
+                pointwise = False
+        if not pointwise:
+            col = _ops.im2col(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, KH, KW, pad_h,
+                              pad_t, Tout)
+        y = _ops.gemm_nt(col, w16, b.detach() if b is not None else None, F32 if out_f32 else BF16)
+        ctx.save_for_backward(col, w16t)
+        ctx.params = (W, b)
+        ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, x.dtype, ctx.needs_input_grad[0])
+        return y.reshape(Tout, B, Hout, Co)
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, w16t = ctx.saved_tensors
+        W, b = ctx.params
+        B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx = ctx.meta
+        gy = gy.contiguous()
+        if gy.dtype != BF16:
+            gy = _ops.permute4(gy, (1, 1, gy.numel() // Co, Co), (0, 0, Co, 1), BF16)
+        g2 = gy.reshape(Tout * B * Hout, Co)
+        Kreal = KH * KW * Ci
+        Kp = col.shape[1]
+        gW = grad_buffer(W)
+        if Kp == Kreal and KH == 1 and KW == 1:
+            _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
+        else:
+            # weights are stored (Co, Ci, kh, kw); the GEMM produces (Co, (kh, kw, ci)): accumulate through a scratch
+            scratch = torch.empty((Co, Kp), dtype=F32, device=gy.device)
+            _ops.fill_(scratch, 0.0)
+            _ops.gemm_tn_acc(g2, col, scratch)
+            _ops.conv_weight_grad_unpack(scratch, gW)
+        if b is not None:
+            _ops.colsum_acc(g2, grad_buffer(b))
+        gx = None
+        if need_dx:
+            dcol = _ops.gemm_nt(g2, w16t, None, BF16)
+            if pointwise:
+                gp = dcol.reshape(T, B, Hin, Ci)
+            else:
+                gp = _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, pad_h, pad_t, Tout)
+            gx = gp.permute(1, 3, 2, 0)
+            if xdtype == F32:
+                gx = _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
+        return gx, None, None, None, None, None, None, None, None
+
+
+def conv_weight_matrix(W):
+    """(Co, Ci, kh, kw) f32 -> bf16 (Co, Kp) with k = (kh, kw, ci), zero padded to a multiple of 8."""
+    return _ops.conv_weight_pack(W.contiguous())
+
+
+def conv_weight_matrix_t(W):
+    """bf16 (Kp, Co): the transposed matrix used by the backward-data GEMM."""
+    return _ops.conv_weight_pack(W.contiguous(), transpose=True)
+
+
+def convolution_2d(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
+    """Cross-correlation over (height, time), stride 1 (asr/nn/nn.py:235-238 forces stride=1)."""
+    pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
+    w16 = link.compute_copy("w16", W, conv_weight_matrix)
+    w16t = link.compute_copy("w16t", W, conv_weight_matrix_t)
+    if x.dtype not in (F32, BF16):
+        raise TypeError("convolution input must be float32 or bfloat16")
+    y = _Conv2D.apply(x, W, b, w16, w16t, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+    return logical4(y)
+
+
+# ---------------------------------------------------------------------------------------------- dense (1x1 over time)
+class _Dense(torch.autograd.Function):
+    """rows (T*B, Din) bf16 @ W (Dout, Din)^T + b."""
+
+    @staticmethod
+    def forward(ctx, x2, W, b, w16, w16t, out_f32):
+        y = _ops.gemm_nt(x2, w16, b.detach() if b is not None else None, F32 if out_f32 else BF16)
+        ctx.save_for_backward(x2, w16t)
+        ctx.params = (W, b)
+        ctx.need_dx = ctx.needs_input_grad[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w16t = ctx.saved_tensors
+        W, b = ctx.params
+        gy = gy.contiguous()
+        if gy.dtype != BF16:
+            gy = _ops.permute4(gy, (1, 1, gy.shape[0], gy.shape[1]), (0, 0, gy.shape[1], 1), BF16).reshape(gy.shape)
+        _ops.gemm_tn_acc(gy, x2, grad_buffer(W).reshape(W.shape[0], -1))
+        if b is not None:
+            _ops.colsum_acc(gy, grad_buffer(b))
+        gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
+        return gx, None, None, None, None, None
+
+
+def dense(x2, W, b, link, out_f32=False):
+    w2 = W.reshape(W.shape[0], -1)
+    if w2.shape[1] % 8:
+        raise ValueError("dense input width must be a multiple of 8 (got %d)" % w2.shape[1])
+    w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1)))
+    w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1), transpose=True))
+    return _Dense.apply(x2, W, b, w16, w16t, bool(out_f32))
+
+
+def convolution_1d(x, W, b, link, out_f32=False):
+    """ConvolutionND with ksize 1 over (B, C, T) (asr/nn/convolution_1d.py:7-38): a per-frame affine map."""
+    p = phys3(x)
+    T, B, D = p.shape
+    y = dense(p.reshape(T * B, D), W, b, link, out_f32)
+    return logical3(y.reshape(T, B, -1))
+
+
+def linear(x, W, b, link):
+    """chainer.links.Linear on (N, D)."""
+    p, _ = _phys_any(x)
+    return dense(p, W, b, link)
+
+
+# ---------------------------------------------------------------------------------------------- activations / pooling
+class _Maxout2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p):
+        ctx.save_for_backward(p)
+        return _ops.maxout2_fwd(p)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        return _ops.maxout2_bwd(p, gy.contiguous())
+
+
+def maxout(x, pool_size=2, axis=1):
+    """chainer.functions.maxout(x, pool_size, axis=1): max over groups of adjacent channels (asr/nn/nn.py:45-50)."""
+    if pool_size != 2 or axis != 1:
+        raise NotImplementedError("only maxout(x, 2, axis=1) is on the HIP path (the reference uses nothing else)")
+    p, back = _phys_any(x)
+    return back(_Maxout2.apply(p))
+
+
+class _MaxPoolH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, k):
+        ctx.save_for_backward(p)
+        ctx.k = k
+        return _ops.maxpool_h_fwd(p, k)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        return _ops.maxpool_h_bwd(p, gy.contiguous(), ctx.k), None
+
+
+def max_pooling_2d(x, ksize, stride=None, pad=0, cover_all=True):
+    """chainer.functions.max_pooling_2d restricted to what the reference uses: ksize (k, 1), stride = ksize,
+    pad 0, cover_all True (asr/nn/nn.py:95-103 passes nothing else)."""
+    kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+    sh, sw = (kh, kw) if stride is None else ((stride, stride) if isinstance(stride, int) else stride)
+    if kw != 1 or sw != 1 or sh != kh or pad not in (0, (0, 0)) or not cover_all:
+        raise NotImplementedError("max_pooling_2d on the HIP path: ksize (k, 1), stride (k, 1), pad 0, cover_all")
+    return logical4(_MaxPoolH.apply(phys4(x), int(kh)))
+
+
+class _Activation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, kind, alpha):
+        ctx.save_for_backward(p)
+        ctx.meta = (kind, alpha)
+        return _ops.activation_fwd(p, kind, alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        kind, alpha = ctx.meta
+        return _ops.activation_bwd(p, gy.contiguous(), kind, alpha), None, None
+
+
+def _act(x, kind, alpha=0.0):
+    p, back = _phys_any(x)
+    return back(_Activation.apply(p, kind, float(alpha)))
+
+
+def relu(x):
+    return _act(x, "relu")
+
+
+def clipped_relu(x, z=20.0):
+    return _act(x, "clipped_relu", z)
+
+
+def leaky_relu(x, slope=0.2):
+    return _act(x, "leaky_relu", slope)
+
+
+def elu(x, alpha=1.0):
+    return _act(x, "elu", alpha)
+
+
+def sigmoid(x):
+    return _act(x, "sigmoid")
+
+
+def tanh(x):
+    return _act(x, "tanh")
+
+
+def hard_sigmoid(x):
+    return _act(x, "hard_sigmoid")
+
+
+def softplus(x, beta=1.0):
+    return _act(x, "softplus", beta)
+
+
+class _GLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p):
+        ctx.save_for_backward(p)
+        return _ops.glu_fwd(p)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        return _ops.glu_bwd(p, gy.contiguous())
+
+
+def glu(x):
+    """A, B = split_axis(x, 2, axis=1); A * sigmoid(B)  (asr/nn/nn.py:279-280)."""
+    p, back = _phys_any(x)
+    return back(_GLU.apply(p))
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, ratio, seed):
+        ctx.meta = (ratio, seed)
+        return _ops.dropout(p, ratio, seed)
+
+    @staticmethod
+    def backward(ctx, gy):
+        ratio, seed = ctx.meta
+        return _ops.dropout(gy.contiguous(), ratio, seed), None, None
+
+
+_dropout_counter = [0]
+train_mode = [True]          # chainer.config.train
+
+
+def dropout(x, ratio=0.5):
+    if ratio == 0 or not train_mode[0]:
+        return x
+    p, back = _phys_any(x)
+    _dropout_counter[0] += 1
+    seed = (torch.initial_seed() * 1000003 + _dropout_counter[0]) & 0xffffffff
+    return back(_Dropout.apply(p, float(ratio), seed))
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _ops.add_bf16(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """residual connection ``y += x`` (asr/nn/nn.py:322-328)."""
+    pa, back = _phys_any(a)
+    pb, _ = _phys_any(b)
+    return back(_Add.apply(pa, pb))
+
+
+# ---------------------------------------------------------------------------------------------- layer normalisation
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, gamma, beta, C, out_f32):
+        y, mean, rstd = _ops.layernorm_fwd(x2, gamma.detach(), beta.detach(), C, F32 if out_f32 else BF16)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params = (gamma, beta)
+        ctx.meta = (C, ctx.needs_input_grad[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        C, need_dx = ctx.meta
+        dx = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, x2.dtype, grad_buffer(gamma),
+                                grad_buffer(beta), need_dx)
+        return dx, None, None, None, None
+
+
+def layer_normalization(x, gamma, beta, out_f32=False):
+    """normalize_layer over axes (1, 2) + scale/bias on axis 1 (asr/nn/nn.py:260-265, asr/nn/layernorm.py:29-64)."""
+    if x.dim() == 4:
+        p = x.permute(3, 0, 2, 1)
+        if not (p.is_contiguous() and p.dtype in (BF16, F32)):
+            p = phys4(x)
+        T, B, H, C = p.shape
+        y = _LayerNorm.apply(p.reshape(T * B, H * C), gamma, beta, C, bool(out_f32))
+        return logical4(y.reshape(T, B, H, C))
+    if x.dim() == 3:
+        # (B, V, T): the reference normalises over V AND T jointly (axes 1, 2).  Physical rows are (t, b); joint
+        # statistics over time need the (B, T*V) arrangement: one row per utterance, channel = index % V.
+        Bn, V, T = x.shape
+        rows = x.permute(0, 2, 1)                # (B, T, V)
+        if not (rows.is_contiguous() and rows.dtype in (BF16, F32)):
+            rows = _ToPhys.apply(x, (0, 2, 1))
+        y = _LayerNorm.apply(rows.reshape(Bn, T * V), gamma, beta, V, bool(out_f32))
+        return y.reshape(Bn, T, V).permute(0, 2, 1)
+    raise ValueError("layer normalisation expects a 3-d or 4-d input")
+
+
+# ---------------------------------------------------------------------------------------------- GRU
+class _GRU(torch.autograd.Function):
+    """x rows (T*B, I) bf16 -> y rows (T*B, H) bf16 (directions summed)."""
+
+    @staticmethod
+    def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir):
+        wih16, wih16t, whh16, whh16t = copies
+        gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), F32)
+        y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, b_hh.detach().reshape(-1), T, B, H, ndir)
+        ctx.save_for_backward(x2, hseq, hseq16, gates, wih16t, whh16t)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.meta = (T, B, H, ndir, ctx.needs_input_grad[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, hseq, hseq16, gates, wih16t, whh16t = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        T, B, H, ndir, need_dx = ctx.meta
+        gy = gy.contiguous()
+        dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir)
+        _ops.gemm_tn_acc(dgi, x2, grad_buffer(w_ih).reshape(ndir * 3 * H, -1))
+        _ops.colsum_acc(dgi, grad_buffer(b_ih).reshape(-1))
+        _ops.colsum_acc(dgh, grad_buffer(b_hh).reshape(-1))
+        gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
+        if T > 1:
+            for d in range(ndir):
+                a = dgh[:, d * 3 * H:(d + 1) * 3 * H]
+                h = hseq16[:, d * H:(d + 1) * H]
+                if d == 0:
+                    _ops.gemm_tn_acc(a[B:], h[:-B], gwhh[d])
+                else:
+                    _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
+        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None
+        return gx, None, None, None, None, None, None, None, None, None
+
+
+def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
+    """x logical (B, I, T); parameters stacked over directions: w_ih (ndir, 3H, I), w_hh (ndir, 3H, H),
+    b_ih / b_hh (ndir, 3H).  Returns logical (B, H, T), the directions summed."""
+    p = phys3(x)
+    T, B, I = p.shape
+    H = w_hh.shape[2]
+    if I % 8:
+        raise ValueError("GRU input width must be a multiple of 8")
+    copies = (
+        link.compute_copy("wih16", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]))),
+        link.compute_copy("wih16t", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]), transpose=True)),
+        link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape)),
+        link.compute_copy("whh16t", w_hh, lambda w: torch.stack([_ops.cast_bf16(w[d], transpose=True) for d in range(w.shape[0])])),
+    )
+    y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir)
+    return logical3(y.reshape(T, B, H))
+
+
+# ---------------------------------------------------------------------------------------------- array manipulation (views)
+def reshape(x, shape):
+    """chainer.functions.reshape.  Merging (C, H) of a physical image -- run/ctc/sru/model.py:114
+    ``reshape(out, (B, -1, T))`` -- is a free view; the merged feature order is (h, c) instead of (c, h), a fixed
+    permutation of the next layer's input columns."""
+    shape = tuple(shape)
+    if x.dim() == 4 and len(shape) == 3:
+        p = x.permute(3, 0, 2, 1)
+        B, C, H, T = x.shape
+        if p.is_contiguous() and shape[0] == B and shape[2] == T and shape[1] in (-1, C * H):
+            return p.reshape(T, B, H * C).permute(1, 2, 0)
+    return x.reshape(shape)
+
+
+def swapaxes(x, a, b):
+    return x.transpose(a, b)
+
+
+def transpose(x, axes):
+    return x.permute(*axes)
+
+
+def squeeze(x, axis=None):
+    return x.squeeze() if axis is None else x.squeeze(axis)
+
+
+def expand_dims(x, axis):
+    return x.unsqueeze(axis)
+
+
+def split_axis(x, indices_or_sections, axis):
+    if isinstance(indices_or_sections, int):
+        return torch.chunk(x, indices_or_sections, dim=axis)
+    return torch.tensor_split(x, list(indices_or_sections), dim=axis)
+
+
+def flatten(x):
+    return x.reshape(-1)
+
+
+def broadcast_to(x, shape):
+    return x.expand(*shape)
+
+
+def tile(x, reps):
+    return x.repeat(*reps) if not isinstance(reps, int) else x.repeat(reps)
+
+
+def rollaxis(x, axis, start=0):
+    return torch.movedim(x, axis, start if start <= axis else start - 1)
+
+
+from .loss.ctc import connectionist_temporal_classification, gram_ctc  # noqa: E402,F401

@@ -1,0 +1,184 @@
+"""Link / Chain / Parameter: the slice of Chainer's object model the reference's `asr.nn` relies on.
+
+The reference builds its models from ``chainer.Link`` / ``chainer.Chain`` (asr/nn/nn.py:240,296,330;
+asr/nn/sru.py:441; asr/nn/convolution_2d.py:127).  Here they sit on ``torch.nn.Module`` (parameter
+registry, device moves, state_dict); no arithmetic lives in this file.
+"""
+import contextlib
+import math
+
+import torch
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+# bumped by the optimisers after every in-place parameter update done behind torch's back (HIP kernels)
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
+class Parameter(torch.nn.Parameter):
+    """``chainer.variable.Parameter``: ``.data`` and ``.grad`` as in Chainer; float32 master copy."""
+
+    def __new__(cls, data=None):
+        if data is None:
+            data = torch.empty(0, dtype=F32)
+        return super().__new__(cls, data, requires_grad=True)
+
+
+class Link(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_compute_cache", {})
+
+    @contextlib.contextmanager
+    def init_scope(self):
+        yield
+
+    # -- Chainer-style surface ---------------------------------------------------------------------
+    @property
+    def xp(self):
+        return torch
+
+    def params(self):
+        return self.parameters()
+
+    def namedparams(self):
+        for name, p in self.named_parameters():
+            yield "/" + name.replace(".", "/"), p
+
+    def to_gpu(self, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.to(dev)
+        return self
+
+    def to_cpu(self):
+        self.to("cpu")
+        return self
+
+    def cleargrads(self):
+        for p in self.parameters():
+            if p.grad is not None:
+                p.grad = None
+
+    # -- compute copies ------------------------------------------------------------------------------
+    def compute_copy(self, key, param, maker):
+        """bf16 (possibly re-laid-out) copy of a parameter, rebuilt only when the parameter changed."""
+        stamp = (_WEIGHT_EPOCH[0], param._version, param.data_ptr())
+        hit = self._compute_cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        with torch.no_grad():
+            value = maker(param.detach())
+        self._compute_cache[key] = (stamp, value)
+        return value
+
+
+class Chain(Link):
+    pass
+
+
+_GRAD_LISTENER = [None]      # asr.parallel.Communicator hooks in here to overlap the all-reduce with backward
+
+
+def grad_buffer(param):
+    """The f32 buffer the backward kernels accumulate this parameter's gradient into (param.grad)."""
+    if _GRAD_LISTENER[0] is not None:
+        _GRAD_LISTENER[0](param)
+    if param.grad is None:
+        from . import _ops
+        g = torch.empty_like(param, memory_format=torch.contiguous_format)
+        _ops.fill_(g.detach(), 0.0)
+        param.grad = g
+    return param.grad
+
+
+# ---------------------------------------------------------------------------------------------- initialisers
+# (parameter initialisation happens once on the host; plain torch RNG, no kernels of ours involved)
+class Initializer(object):
+    def __call__(self, shape):
+        raise NotImplementedError
+
+
+class Constant(Initializer):
+    def __init__(self, value):
+        self.value = value
+
+    def __call__(self, shape):
+        return torch.full(shape, float(self.value), dtype=F32)
+
+
+class Normal(Initializer):
+    """chainer.initializers.Normal(scale) -- used by run/ctc/cnn/model.py:145,162,170,182."""
+
+    def __init__(self, scale=0.05):
+        self.scale = scale
+
+    def __call__(self, shape):
+        return torch.randn(shape, dtype=F32) * self.scale
+
+
+def _fans(shape):
+    fan_out = shape[0]
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return fan_in, fan_out
+
+
+class LeCunNormal(Initializer):
+    """Chainer's default weight initialiser: N(0, scale * sqrt(1 / fan_in))."""
+
+    def __init__(self, scale=1.0):
+        self.scale = scale
+
+    def __call__(self, shape):
+        fan_in, _ = _fans(shape)
+        return torch.randn(shape, dtype=F32) * (self.scale * math.sqrt(1.0 / fan_in))
+
+
+class HeNormal(Initializer):
+    """chainer.initializers.HeNormal(scale): N(0, scale * sqrt(2 / fan_in))  (asr/nn/nn.py:269-270)."""
+
+    def __init__(self, scale=1.0):
+        self.scale = scale
+
+    def __call__(self, shape):
+        fan_in, _ = _fans(shape)
+        return torch.randn(shape, dtype=F32) * (self.scale * math.sqrt(2.0 / fan_in))
+
+
+class Uniform(Initializer):
+    def __init__(self, scale=0.05):
+        self.scale = scale
+
+    def __call__(self, shape):
+        return (torch.rand(shape, dtype=F32) * 2 - 1) * self.scale
+
+
+def get_initializer(init):
+    """chainer.initializers._get_initializer: None -> LeCunNormal, number -> Constant, tensor -> copy."""
+    if init is None:
+        return LeCunNormal()
+    if isinstance(init, Initializer):
+        return init
+    if isinstance(init, (int, float)):
+        return Constant(init)
+    if isinstance(init, torch.Tensor):
+        value = init.detach().to(F32)
+        return lambda shape: value.reshape(shape).clone()
+    if callable(init):
+        return init
+    raise TypeError("unsupported initialiser %r" % (init,))
+
+
+class initializers(object):     # namespace mirroring ``chainer.initializers``
+    Normal = Normal
+    HeNormal = HeNormal
+    LeCunNormal = LeCunNormal
+    Constant = Constant
+    Uniform = Uniform
+    _get_initializer = staticmethod(get_initializer)

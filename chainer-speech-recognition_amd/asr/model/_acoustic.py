@@ -1,0 +1,59 @@
+"""Shared tail of the AcousticModel classes: turn the stack's (B, V, 1, T) output into what the CTC losses take
+(asr/model/cnn.py:33-49, asr/model/sru.py:29-45) and atomic save / load (asr/model/cnn.py:51-63)."""
+import os
+import uuid
+
+import torch
+
+from .. import nn
+
+
+def mark_logit_layers(layers):
+    """The last normalisation / projection writes float32 logits straight in (T, B, V) order."""
+    last = None
+    for layer in layers:
+        if isinstance(layer, nn.Residual):
+            for sub in layer.layers:
+                if hasattr(sub, "output_float32"):
+                    last = sub
+        elif isinstance(layer, nn.GLU):
+            last = layer.W if hasattr(layer.W, "output_float32") else last
+        elif hasattr(layer, "output_float32"):
+            last = layer
+    if last is not None:
+        last.output_float32 = True
+        # a LayerNormalization reads the projection in front of it in float32 as well
+        prev = None
+        for layer in layers:
+            if layer is last and isinstance(last, nn.LayerNormalization) and prev is not None and hasattr(prev, "output_float32"):
+                prev.output_float32 = True
+            prev = layer
+
+
+def split_output(out_data, batchsize, seq_length, split_into_variables):
+    """out_data logical (B, V, 1, T) [or (B, V, T)] backed by a (T, B, 1, V) / (T, B, V) buffer."""
+    if out_data.dim() == 4:
+        assert out_data.shape[3] == seq_length
+        tbv = out_data.permute(3, 0, 2, 1).squeeze(2)        # (T, B, V) view of the physical buffer
+    else:
+        assert out_data.shape[2] == seq_length
+        tbv = out_data.permute(2, 0, 1)
+    if split_into_variables:
+        return tuple(tbv.unbind(0))                           # T views (B, V): swapaxes/reshape/split_axis of the reference
+    return tbv.permute(1, 0, 2)                               # (B, T, V)
+
+
+def save_atomic(module, filename):
+    tmp_filename = str(uuid.uuid4())
+    torch.save(module.state_dict(), tmp_filename)
+    if os.path.isfile(filename):
+        os.remove(filename)
+    os.rename(tmp_filename, filename)
+
+
+def load_if_exists(module, filename):
+    if os.path.isfile(filename):
+        print("Loading {} ...".format(filename))
+        module.load_state_dict(torch.load(filename, map_location="cpu"))
+        return True
+    return False

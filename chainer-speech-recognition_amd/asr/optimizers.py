@@ -1,0 +1,246 @@
+"""Optimisers of the train step on one flat parameter buffer.
+
+Mirrors asr/optimizers.py:1-75 (get/set learning rate and momentum, ``get_optimizer``, ``decay_learning_rate``)
+and the slice of ``chainer.optimizer`` the training scripts use (run/ctc/cnn/train.py:142-147,200):
+``setup(model)``, ``add_hook(GradientClipping(t))``, ``add_hook(WeightDecay(r))``, ``update(lossfun=lambda: loss)``.
+
+All parameters live in ONE float32 buffer (their ``.data`` / ``.grad`` are views), so the step is two HIP launches
+(squared norm for the global-norm clipping, fused clip + decay + update) and the data-parallel all-reduce is a few large
+RCCL calls over contiguous slices.
+"""
+import torch
+
+from . import _ops
+from .link import bump_weight_epoch
+
+F32 = torch.float32
+
+
+class GradientClipping(object):
+    """chainer.optimizer.GradientClipping(threshold): scale all gradients by threshold / ||g||_2 when that is < 1."""
+    name = "GradientClipping"
+
+    def __init__(self, threshold):
+        self.threshold = threshold
+
+
+class WeightDecay(object):
+    """chainer.optimizer.WeightDecay(rate): g += rate * p."""
+    name = "WeightDecay"
+
+    def __init__(self, rate):
+        self.rate = rate
+
+
+class Optimizer(object):
+    def __init__(self):
+        self.target = None
+        self.t = 0
+        self._hooks = []
+        self._flat = None
+        self.communicator = None
+
+    # -- Chainer surface ---------------------------------------------------------------------------
+    def setup(self, link):
+        self.target = link
+        self.t = 0
+        self._flat = None
+        return self
+
+    def add_hook(self, hook, name=None):
+        self._hooks.append(hook)
+
+    def set_communicator(self, comm):
+        """Data parallelism: gradients are summed over ranks (RCCL) before the step and scaled by 1/world."""
+        self.communicator = comm
+        self._flat = None
+
+    def update(self, lossfun=None, *args, **kwds):
+        if lossfun is not None:
+            loss = lossfun(*args, **kwds)
+            self.cleargrads()
+            if self.communicator is not None:
+                self.communicator.begin_backward(self)
+            loss.backward()
+        self._ensure_flat()
+        scale = 1.0
+        if self.communicator is not None:
+            self.communicator.finish_backward(self)
+            scale = 1.0 / self.communicator.size
+        self.t += 1
+        P, G = self._flat["P"], self._flat["G"]
+        clip, decay = 0.0, 0.0
+        for h in self._hooks:
+            if isinstance(h, GradientClipping):
+                clip = float(h.threshold)
+            elif isinstance(h, WeightDecay):
+                decay = float(h.rate)
+        sq = None
+        if clip > 0:
+            sq = self._flat["sq"]
+            _ops.fill_(sq, 0.0)
+            _ops.sqnorm_acc(G, sq)
+        self._step(P, G, clip, decay, scale, sq)
+        bump_weight_epoch()
+
+    # -- flat buffers ------------------------------------------------------------------------------
+    def _params(self):
+        return [p for p in self.target.parameters() if p.numel() > 0]
+
+    def _ensure_flat(self):
+        params = self._params()
+        if self._flat is not None and self._flat["ids"] == [id(p) for p in params] and \
+                all(p.data_ptr() == a for p, a in zip(params, self._flat["ptrs"])):
+            return
+        if len(params) == 0:
+            raise RuntimeError("optimizer.setup(model) was given a model without initialised parameters")
+        dev = params[0].device
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]           # 256-byte aligned slices
+        total = sum(sizes)
+        old = self._flat
+        P = torch.empty(total, dtype=F32, device=dev)
+        G = torch.empty(total, dtype=F32, device=dev)
+        _ops.fill_(P, 0.0)
+        _ops.fill_(G, 0.0)
+        offs, o = [], 0
+        for p, n in zip(params, sizes):
+            offs.append(o)
+            view = P[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)                      # one-time host-driven move of the master weights
+            if p.grad is not None:
+                G[o:o + p.numel()].view(p.shape).copy_(p.grad)
+            p.data = view
+            p.grad = G[o:o + p.numel()].view(p.shape)
+            o += n
+        self._flat = dict(P=P, G=G, ids=[id(p) for p in params], ptrs=[p.data_ptr() for p in params], offsets=offs,
+                          sizes=sizes, sq=torch.empty(1, dtype=F32, device=dev))
+        self._init_state(total, dev, old)
+        bump_weight_epoch()
+        if self.communicator is not None:
+            self.communicator.broadcast(P)
+            bump_weight_epoch()
+
+    def cleargrads(self):
+        """model.cleargrads() of Chainer: here one fill of the flat gradient buffer."""
+        self._ensure_flat()
+        _ops.fill_(self._flat["G"], 0.0)
+        for p, o in zip(self._params(), self._flat["offsets"]):
+            if p.grad is None or p.grad.data_ptr() != self._flat["G"].data_ptr() + 4 * o:
+                p.grad = self._flat["G"][o:o + p.numel()].view(p.shape)
+
+    def flat_gradients(self):
+        self._ensure_flat()
+        return self._flat["G"]
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._flat["P"]
+
+    def _init_state(self, total, dev, old):
+        pass
+
+    def _step(self, P, G, clip, decay, scale, sq):
+        raise NotImplementedError
+
+
+class Adam(Optimizer):
+    def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
+        super().__init__()
+        self.alpha, self.beta1, self.beta2, self.eps = alpha, beta1, beta2, eps
+
+    def _init_state(self, total, dev, old):
+        self.m = torch.empty(total, dtype=F32, device=dev)
+        self.v = torch.empty(total, dtype=F32, device=dev)
+        _ops.fill_(self.m, 0.0)
+        _ops.fill_(self.v, 0.0)
+
+    def _step(self, P, G, clip, decay, scale, sq):
+        _ops.clip_decay_adam(P, G, self.m, self.v, self.alpha, self.beta1, self.beta2, self.eps, decay, clip, scale, sq, self.t)
+
+
+class SGD(Optimizer):
+    kind = 0
+
+    def __init__(self, lr=0.01):
+        super().__init__()
+        self.lr = lr
+        self.momentum = 0.0
+        self.vel = None
+
+    def _init_state(self, total, dev, old):
+        if self.kind:
+            self.vel = torch.empty(total, dtype=F32, device=dev)
+            _ops.fill_(self.vel, 0.0)
+
+    def _step(self, P, G, clip, decay, scale, sq):
+        _ops.clip_decay_sgd(P, G, self.vel, self.kind, self.lr, self.momentum, decay, clip, scale, sq)
+
+
+class MomentumSGD(SGD):
+    kind = 1
+
+    def __init__(self, lr=0.01, momentum=0.9):
+        super().__init__(lr)
+        self.momentum = momentum
+
+
+class NesterovAG(SGD):
+    kind = 2
+
+    def __init__(self, lr=0.01, momentum=0.9):
+        super().__init__(lr)
+        self.momentum = momentum
+
+
+class optimizers(object):       # namespace mirroring ``chainer.optimizers``
+    Adam, SGD, MomentumSGD, NesterovAG = Adam, SGD, MomentumSGD, NesterovAG
+
+
+# ---- asr/optimizers.py:3-75 -----------------------------------------------------------------------
+def get_learning_rate(opt):
+    if isinstance(opt, Adam):
+        return opt.alpha
+    if isinstance(opt, SGD):
+        return opt.lr
+    raise NotImplementedError()
+
+
+def set_learning_rate(opt, lr):
+    if isinstance(opt, Adam):
+        opt.alpha = lr
+        return
+    if isinstance(opt, SGD):
+        opt.lr = lr
+        return
+    raise NotImplementedError()
+
+
+def set_momentum(opt, momentum):
+    if isinstance(opt, Adam):
+        opt.beta1 = momentum
+        return
+    if isinstance(opt, (MomentumSGD, NesterovAG)):
+        opt.momentum = momentum
+        return
+    if isinstance(opt, SGD):
+        return
+    raise NotImplementedError()
+
+
+def get_optimizer(name, lr, momentum):
+    if name == "sgd":
+        return SGD(lr=lr)
+    if name == "msgd":
+        return MomentumSGD(lr=lr, momentum=momentum)
+    if name == "nesterov":
+        return NesterovAG(lr=lr, momentum=momentum)
+    if name == "adam":
+        return Adam(alpha=lr, beta1=momentum)
+    raise NotImplementedError()
+
+
+def decay_learning_rate(opt, factor, final_value):
+    lr = get_learning_rate(opt)
+    if lr <= final_value:
+        return final_value
+    set_learning_rate(opt, lr * factor)

@@ -64,12 +64,13 @@ __global__ void permute4_kernel(const SrcT* __restrict__ src, DstT* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ im2col / col2im
-// col[(t, b, ho)][(kh, kw, ci)] = x[t + kw - (KW-1), b, ho + kh - ph, ci]   (zero outside), row pitch Kp >= KH*KW*Cin
+// col[(t, b, ho)][(kh, kw, ci)] = x[t + kw - pt, b, ho + kh - ph, ci]   (zero outside), row pitch Kp >= KH*KW*Cin,
+// t in [0, Tout).  pt = KW-1, Tout = T is the causal convolution; Tout = T + KW-1 the reference's padded output.
 template <typename SrcT>
 __global__ void im2col_kernel(const SrcT* __restrict__ x, long long sT, long long sB, long long sH, long long sC, int T,
-                              int B, int Hin, int Cin, int KH, int KW, int ph, int Hout, int Kp,
+                              int B, int Hin, int Cin, int KH, int KW, int ph, int pt, int Tout, int Hout, int Kp,
                               uint16_t* __restrict__ col) {
-    const long long rows = (long long)T * B * Hout;
+    const long long rows = (long long)Tout * B * Hout;
     const long long n = rows * Kp;
     const int Kreal = KH * KW * Cin;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -83,8 +84,8 @@ __global__ void im2col_kernel(const SrcT* __restrict__ x, long long sT, long lon
             const int ho = (int)(row % Hout); row /= Hout;
             const int b = (int)(row % B);
             const int t = (int)(row / B);
-            const int ti = t + kw - (KW - 1), hi = ho + kh - ph;
-            if (ti >= 0 && hi >= 0 && hi < Hin) {
+            const int ti = t + kw - pt, hi = ho + kh - ph;
+            if (ti >= 0 && ti < T && hi >= 0 && hi < Hin) {
                 const SrcT v = x[ti * sT + b * sB + hi * sH + ci * sC];
                 if (sizeof(SrcT) == 2) out = (uint16_t)v; else out = f32_to_bf16((float)v);
             }
@@ -92,9 +93,9 @@ __global__ void im2col_kernel(const SrcT* __restrict__ x, long long sT, long lon
         col[i] = out;
     }
 }
-// dx[t, b, h, ci] = sum_{kh,kw} dcol[(t - kw + KW-1, b, h - kh + ph)][(kh, kw, ci)]   (gather form, no atomics)
+// dx[t, b, h, ci] = sum_{kh,kw} dcol[(t - kw + pt, b, h - kh + ph)][(kh, kw, ci)]   (gather form, no atomics)
 __global__ void col2im_kernel(const uint16_t* __restrict__ dcol, int T, int B, int Hin, int Cin, int KH, int KW, int ph,
-                              int Hout, int Kp, uint16_t* __restrict__ dx) {
+                              int pt, int Tout, int Hout, int Kp, uint16_t* __restrict__ dx) {
     const long long n = (long long)T * B * Hin * Cin;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         long long r = i;
@@ -107,8 +108,8 @@ __global__ void col2im_kernel(const uint16_t* __restrict__ dcol, int T, int B, i
             const int ho = h - kh + ph;
             if (ho < 0 || ho >= Hout) continue;
             for (int kw = 0; kw < KW; ++kw) {
-                const int to = t - kw + (KW - 1);
-                if (to >= T) continue;
+                const int to = t - kw + pt;
+                if (to < 0 || to >= Tout) continue;
                 acc += bf16_to_f32(dcol[(((long long)to * B + b) * Hout + ho) * Kp + (kh * KW + kw) * Cin + ci]);
             }
         }
@@ -211,6 +212,111 @@ __global__ void colsum_kernel(const T* __restrict__ x, long long rows, int cols,
     if (w == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+
+// ------------------------------------------------------------------------------------------------ activations
+// kind: 0 relu, 1 clipped_relu(alpha = z), 2 leaky_relu(alpha = slope), 3 elu(alpha), 4 sigmoid, 5 tanh,
+//       6 hard_sigmoid, 7 softplus(alpha = beta)      (the activation wrappers of asr/nn/nn.py:11-73)
+__device__ __forceinline__ float act_f(int kind, float a, float x) {
+    switch (kind) {
+        case 0: return fmaxf(x, 0.f);
+        case 1: return fminf(fmaxf(x, 0.f), a);
+        case 2: return x >= 0.f ? x : a * x;
+        case 3: return x >= 0.f ? x : a * (__expf(x) - 1.f);
+        case 4: return 1.f / (1.f + __expf(-x));
+        case 5: return tanhf(x);
+        case 6: return fminf(fmaxf(0.2f * x + 0.5f, 0.f), 1.f);
+        default: { const float bx = a * x; return (bx > 20.f ? bx : log1pf(__expf(bx))) / a; }
+    }
+}
+__device__ __forceinline__ float act_df(int kind, float a, float x) {
+    switch (kind) {
+        case 0: return x > 0.f ? 1.f : 0.f;
+        case 1: return (x > 0.f && x < a) ? 1.f : 0.f;
+        case 2: return x >= 0.f ? 1.f : a;
+        case 3: return x >= 0.f ? 1.f : a * __expf(x);
+        case 4: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f - s); }
+        case 5: { const float t = tanhf(x); return 1.f - t * t; }
+        case 6: return (x > -2.5f && x < 2.5f) ? 0.2f : 0.f;
+        default: return 1.f / (1.f + __expf(-a * x));
+    }
+}
+__global__ void act_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long n, int kind, float a) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = f32_to_bf16(act_f(kind, a, bf16_to_f32(x[i])));
+}
+__global__ void act_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+                               long long n, int kind, float a) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dx[i] = f32_to_bf16(bf16_to_f32(dy[i]) * act_df(kind, a, bf16_to_f32(x[i])));
+}
+// GLU (asr/nn/nn.py:279-280): rows of 2C channels [A | B] -> C channels, H = A * sigmoid(B)
+__global__ void glu_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long rows, int C) {
+    const long long n = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        const float a = bf16_to_f32(x[r * 2 * C + c]), b = bf16_to_f32(x[r * 2 * C + C + c]);
+        y[i] = f32_to_bf16(a / (1.f + __expf(-b)));
+    }
+}
+__global__ void glu_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, uint16_t* __restrict__ dx,
+                               long long rows, int C) {
+    const long long n = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C;
+        const int c = (int)(i - r * C);
+        const float a = bf16_to_f32(x[r * 2 * C + c]), b = bf16_to_f32(x[r * 2 * C + C + c]);
+        const float s = 1.f / (1.f + __expf(-b)), g = bf16_to_f32(dy[i]);
+        dx[r * 2 * C + c] = f32_to_bf16(g * s);
+        dx[r * 2 * C + C + c] = f32_to_bf16(g * a * s * (1.f - s));
+    }
+}
+// dropout with a counter-based hash RNG (seed, element index) so that backward regenerates the mask
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ void dropout_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long n, float ratio,
+                               uint32_t seed) {
+    const float scale = 1.f / (1.f - ratio);
+    const uint32_t thr = (uint32_t)(ratio * 4294967296.0);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t r = hash32((uint32_t)i * 0x9e3779b9U + hash32(seed + (uint32_t)(i >> 32)));
+        y[i] = r >= thr ? f32_to_bf16(bf16_to_f32(x[i]) * scale) : (uint16_t)0;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ conv weight (un)packing
+// pack:   dst[co][k] (or dst[k][co] when transposed) = W[co][ci][kh][kw], k = (kh*KW + kw)*Ci + ci, zero for k >= K
+__global__ void conv_weight_pack_kernel(const float* __restrict__ W, uint16_t* __restrict__ dst, int Co, int Ci, int KH,
+                                        int KW, int Kp, int transpose) {
+    const long long n = (long long)Co * Kp;
+    const int K = KH * KW * Ci;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(i / Kp), k = (int)(i - (long long)co * Kp);
+        float v = 0.f;
+        if (k < K) {
+            const int ci = k % Ci, kw = (k / Ci) % KW, kh = k / (Ci * KW);
+            v = W[(((long long)co * Ci + ci) * KH + kh) * KW + kw];
+        }
+        if (transpose) dst[(long long)k * Co + co] = f32_to_bf16(v); else dst[i] = f32_to_bf16(v);
+    }
+}
+// unpack: gW[co][ci][kh][kw] += scratch[co][(kh*KW + kw)*Ci + ci]
+__global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch, float* __restrict__ gW, int Co, int Ci,
+                                               int KH, int KW, int Kp) {
+    const long long n = (long long)Co * Ci * KH * KW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); r /= KH;
+        const int ci = (int)(r % Ci);
+        const int co = (int)(r / Ci);
+        gW[i] += scratch[(long long)co * Kp + (kh * KW + kw) * Ci + ci];
+    }
+}
+
 }  // namespace ew
 }  // namespace asr
 
@@ -258,30 +364,31 @@ extern "C" int asr_permute4(void* stream, const void* src, int src_bf16, void* d
 }
 
 extern "C" int asr_im2col(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC,
-                          int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp, void* col) {
-    if (!x || !col || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || pad_h < 0) return ASR_ERR_BAD_ARG;
+                          int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int pad_t, int Tout, int Kp,
+                          void* col) {
+    if (!x || !col || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || pad_h < 0 || pad_t < 0) return ASR_ERR_BAD_ARG;
     const int Hout = Hin + 2 * pad_h - KH + 1;
-    if (Hout <= 0 || Kp < KH * KW * Cin) return ASR_ERR_BAD_ARG;
-    const long long n = (long long)T * B * Hout * Kp;
+    if (Hout <= 0 || Kp < KH * KW * Cin || Tout <= 0 || Tout > T + 2 * pad_t - KW + 1) return ASR_ERR_BAD_ARG;
+    const long long n = (long long)Tout * B * Hout * Kp;
     hipStream_t s = (hipStream_t)stream;
     if (x_bf16)
         hipLaunchKernelGGL(im2col_kernel<uint16_t>, dim3(grid_for(n)), dim3(kThreads), 0, s, (const uint16_t*)x, sT, sB, sH,
-                           sC, T, B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)col);
+                           sC, T, B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)col);
     else
         hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(n)), dim3(kThreads), 0, s, (const float*)x, sT, sB, sH, sC,
-                           T, B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)col);
+                           T, B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)col);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
 
 extern "C" int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, int KH, int KW, int pad_h,
-                          int Kp, void* dx) {
-    if (!dcol || !dx || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0) return ASR_ERR_BAD_ARG;
+                          int pad_t, int Tout, int Kp, void* dx) {
+    if (!dcol || !dx || T <= 0 || B <= 0 || Hin <= 0 || Cin <= 0 || pad_h < 0 || pad_t < 0) return ASR_ERR_BAD_ARG;
     const int Hout = Hin + 2 * pad_h - KH + 1;
-    if (Hout <= 0 || Kp < KH * KW * Cin) return ASR_ERR_BAD_ARG;
+    if (Hout <= 0 || Kp < KH * KW * Cin || Tout <= 0 || Tout > T + 2 * pad_t - KW + 1) return ASR_ERR_BAD_ARG;
     const long long n = (long long)T * B * Hin * Cin;
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)dcol, T,
-                       B, Hin, Cin, KH, KW, pad_h, Hout, Kp, (uint16_t*)dx);
+                       B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)dx);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -338,6 +445,60 @@ extern "C" int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long
         hipLaunchKernelGGL(colsum_kernel<uint16_t>, g, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, rows, cols, ld, out);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld, out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_activation_fwd(void* stream, const void* x, void* y, long long n, int kind, float alpha) {
+    if (!x || !y || n <= 0 || kind < 0 || kind > 7) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)y, n, kind, alpha);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_activation_bwd(void* stream, const void* x, const void* dy, void* dx, long long n, int kind,
+                                  float alpha) {
+    if (!x || !dy || !dx || n <= 0 || kind < 0 || kind > 7) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (const uint16_t*)dy, (uint16_t*)dx, n, kind, alpha);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_glu_fwd(void* stream, const void* x, void* y, long long rows, int C) {
+    if (!x || !y || rows <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(rows * C)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, rows, C);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_glu_bwd(void* stream, const void* x, const void* dy, void* dx, long long rows, int C) {
+    if (!x || !dy || !dx || rows <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, rows, C);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_dropout(void* stream, const void* x, void* y, long long n, float ratio, unsigned int seed) {
+    if (!x || !y || n <= 0 || ratio < 0.f || ratio >= 1.f) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (uint16_t*)y, n, ratio, seed);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_conv_weight_pack(void* stream, const float* W, void* dst, int Co, int Ci, int KH, int KW, int Kp,
+                                    int transpose) {
+    if (!W || !dst || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Kp < KH * KW * Ci) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid_for((long long)Co * Kp)), dim3(kThreads), 0, (hipStream_t)stream,
+                       W, (uint16_t*)dst, Co, Ci, KH, KW, Kp, transpose);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW,
+                                           int Kp) {
+    if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Kp < KH * KW * Ci) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(conv_weight_grad_unpack_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(kThreads), 0,
+                       (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -42,6 +42,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// kind 0: SGD  p -= lr g;  1: MomentumSGD  v = mu v - lr g, p += v;  2: NesterovAG  v = mu v - lr g, p += mu^2 v - (1+mu) lr g
+// (chainer.optimizers.SGD / MomentumSGD / NesterovAG update rules, selected by asr/optimizers.py:43-52)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                  long long n, int kind, float lr, float mu, float decay, float clip,
+                                                  float grad_scale, const float* __restrict__ sqnorm) {
+    float rate = grad_scale;
+    if (clip > 0.f && sqnorm) {
+        const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
+        const float r = clip / norm;
+        if (r < 1.f) rate *= r;
+    }
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * rate + decay * pi;
+        if (kind == 0) {
+            p[i] = pi - lr * gi;
+        } else {
+            const float vi = mu * v[i] - lr * gi;
+            v[i] = vi;
+            p[i] = kind == 1 ? pi + vi : pi + mu * mu * vi - (1.f + mu) * lr * gi;
+        }
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, long long n, float value) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = value;
 }
@@ -80,6 +104,16 @@ extern "C" int asr_clip_decay_adam(void* stream, float* p, const float* g, float
     const float lr_t = (float)(alpha * sqrt(fix2) / fix1);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, beta1,
                        beta2, eps, weight_decay, clip_threshold, grad_scale, sqnorm);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_clip_decay_sgd(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr,
+                                  float momentum, float weight_decay, float clip_threshold, float grad_scale,
+                                  const float* sqnorm) {
+    if (!p || !g || n <= 0 || kind < 0 || kind > 2 || (kind > 0 && !v)) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, n, kind, lr, momentum,
+                       weight_decay, clip_threshold, grad_scale, sqnorm);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

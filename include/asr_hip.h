@@ -62,8 +62,9 @@ int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb
  *   asr_cast_bf16     f32 (rows, cols) -> bf16, optionally transposed to (cols, rows)    [weight copies]
  *   asr_permute4      dense dst (d0,d1,d2,d3) <- strided src (element strides s0..s3), f32/bf16 either side
  *   asr_im2col        col[(t,b,ho)][(kh,kw,ci)] (row pitch Kp, zero padded) from x with element strides
- *                     (sT,sB,sH,sC); causal in time: reads t+kw-(KW-1)  == pad (KW-1) both sides then x[..., :-pad]
- *                     (run/ctc/cnn/model.py:43-44); pad_h rows of zero padding in height
+ *                     (sT,sB,sH,sC); reads x[t+kw-pad_t, b, ho+kh-pad_h, ci] for t in [0, Tout).  pad_t = KW-1 with
+ *                     Tout = T + KW-1 is the reference's conv (pad both sides), Tout = T its causal crop
+ *                     x[..., :-pad] (run/ctc/cnn/model.py:43-44)
  *   asr_col2im        adjoint of asr_im2col for a (T,B,Hin,Cin) bf16 input gradient
  *   asr_maxout2_*     nn.Maxout(2): asr/nn/nn.py:45-50 (pairs of adjacent channels; ties -> first)
  *   asr_maxpool_h_*   nn.MaxPooling2D(ksize=(k,1)): asr/nn/nn.py:95-103, stride k, cover_all=True
@@ -75,14 +76,26 @@ int asr_bf16_to_f32(void* stream, const void* src, float* dst, long long n);
 int asr_permute4(void* stream, const void* src, int src_bf16, void* dst, int dst_bf16, int d0, int d1, int d2, int d3,
                  long long s0, long long s1, long long s2, long long s3);
 int asr_im2col(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,
-               int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp, void* col);
-int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int Kp,
-               void* dx);
+               int B, int Hin, int Cin, int KH, int KW, int pad_h, int pad_t, int Tout, int Kp, void* col);
+int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, int KH, int KW, int pad_h, int pad_t,
+               int Tout, int Kp, void* dx);
+/* Convolution2D weights (Co, Ci, kh, kw) f32 <-> the GEMM's (Co, Kp) matrix with k = (kh, kw, ci) */
+int asr_conv_weight_pack(void* stream, const float* W, void* dst_bf16, int Co, int Ci, int KH, int KW, int Kp,
+                         int transpose);
+int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp);
 int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);
 int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out);
 int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
 int asr_maxpool_h_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
 int asr_add_bf16(void* stream, const void* a, const void* b, void* y, long long n);
+/* activations of asr/nn/nn.py:11-73 on bf16: kind 0 relu, 1 clipped_relu(alpha=z), 2 leaky_relu(alpha=slope),
+ * 3 elu(alpha), 4 sigmoid, 5 tanh, 6 hard_sigmoid, 7 softplus(alpha=beta); GLU asr/nn/nn.py:267-281 on rows [A|B];
+ * dropout (asr/nn/nn.py:211-218) with a counter-based mask that backward regenerates from the same seed. */
+int asr_activation_fwd(void* stream, const void* x, void* y, long long n, int kind, float alpha);
+int asr_activation_bwd(void* stream, const void* x, const void* dy, void* dx, long long n, int kind, float alpha);
+int asr_glu_fwd(void* stream, const void* x, void* y, long long rows, int C);
+int asr_glu_bwd(void* stream, const void* x, const void* dy, void* dx, long long rows, int C);
+int asr_dropout(void* stream, const void* x, void* y, long long n, float ratio, unsigned int seed);
 int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long rows, int cols, int ld, float* out);
 
 /* ---------------------------------------------------------------------------------------- layer normalisation
@@ -104,6 +117,20 @@ int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float
 int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
                 void* dgi_bf16, void* dgh_bf16, float* carry_ws, int T, int B, int H, int ndir);
 
+/* ---------------------------------------------------------------------------------------- SRU scan
+ * Replaces the CUDA kernels `forward` / `backward` of asr/nn/sru.py:17-73,75-191 (SRUFunction.forward_gpu :327-367,
+ * backward_gpu :372-433).  x, H, gH, gxh: (T, B, D) bf16;  U, gU: (T*B, 3D) [z | f | r] (U f32, gU bf16);
+ * C (T, B, D) f32; bias (2D) [b_f | b_r]; c0, cT, gcT, gc0, mask: (B, D) f32 (c0 / mask / gH / gcT may be NULL).
+ * asr_sru_combine: out = (a + b) * mask  (b NULL: out = a * mask) -- highway + projection gradient, input masking.
+ */
+int asr_sru_fwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* c0, const float* mask,
+                void* H_bf16, float* C, float* cT, int T, int B, int D, int use_tanh);
+int asr_sru_bwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* C, const float* c0,
+                const float* mask, const void* gH_bf16, const float* gcT, void* gU_bf16, void* gxh_bf16, float* gbias,
+                float* gc0, int T, int B, int D, int use_tanh);
+int asr_sru_combine(void* stream, const void* a_bf16, const void* b_bf16, const float* mask, void* out_bf16, long long n,
+                    int BD);
+
 /* ---------------------------------------------------------------------------------------- optimiser step
  * GradientClipping -> WeightDecay -> Adam over one flat buffer (run/ctc/cnn/train.py:142-147,200).
  * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
@@ -113,6 +140,9 @@ int asr_sqnorm_acc(void* stream, const float* g, long long n, float* out);
 int asr_clip_decay_adam(void* stream, float* p, const float* g, float* m, float* v, long long n, float alpha,
                         float beta1, float beta2, float eps, float weight_decay, float clip_threshold,
                         float grad_scale, const float* sqnorm, int step);
+/* kind 0 SGD, 1 MomentumSGD, 2 NesterovAG (asr/optimizers.py:43-52), same clipping / decay front end */
+int asr_clip_decay_sgd(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,
+                       float weight_decay, float clip_threshold, float grad_scale, const float* sqnorm);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,130 @@
+"""The DS2-style model and its train step on the HIP path against the torch-CPU oracle (same parameters, same batch).
+
+Activations and MFMA operands are bf16 (BASELINE.json config: "1xMI355X bf16"), so the model-level tolerances are
+bf16 tolerances; the CTC loss/gradient itself is checked to 1e-4 in tests/test_ctc_gpu.py on identical logits."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def _build(device, V=29, conv=16, rnn=64, dense=32, nrnn=2, bidir=True, seed=0):
+    from asr.model import ds2
+    torch.manual_seed(seed)
+    cfg = ds2.configure()
+    cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers, cfg.bidirectional = V, conv, rnn, dense, nrnn, bidir
+    model = ds2.Model(cfg)
+    model.to_gpu()
+    return cfg, model
+
+
+@pytest.mark.parametrize("B,T,bidir", [(3, 60, True), (4, 41, False)])
+def test_forward_backward_matches_oracle(device, B, T, bidir):
+    from asr.loss import connectionist_temporal_classification
+    V = 29
+    cfg, model = _build(device, V=V, bidir=bidir)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=1, ragged=True)
+    ys = model(x.to(device))
+    assert isinstance(ys, tuple) and len(ys) == T and ys[0].shape == (B, V) and ys[0].dtype == torch.float32
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+    loss.backward()
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir)
+    logits_ref = ref(x)
+    loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+    loss_ref.backward()
+    logits = torch.stack(ys).detach().cpu()
+    assert _cos(logits, logits_ref.detach()) > 0.999
+    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 2e-2
+    grads = dict(model.named_parameters())
+    worst = 1.0
+    for name, p in grads.items():
+        g_ref = ref.g(name).grad
+        assert p.grad is not None, name
+        c = _cos(p.grad.cpu(), g_ref)
+        worst = min(worst, c)
+        assert c > 0.97, (name, c)
+        ratio = p.grad.cpu().norm().item() / (g_ref.norm().item() + 1e-30)
+        assert 0.9 < ratio < 1.1, (name, ratio)
+    assert worst > 0.97
+
+
+def test_train_steps_follow_oracle(device):
+    """three optimiser steps (clip 1, decay 1e-5, Adam 1e-3): losses and parameters stay with the CPU oracle's."""
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import Adam, GradientClipping, WeightDecay
+    B, T, V = 4, 50, 29
+    cfg, model = _build(device, V=V, seed=3)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=2)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+    model(xd)       # materialise lazily-sized parameters
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True)
+    m = [torch.zeros_like(p) for p in ref.parameters()]
+    v = [torch.zeros_like(p) for p in ref.parameters()]
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    opt.add_hook(WeightDecay(1e-5))
+    for step in (1, 2, 3):
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
+        loss_ref, _ = omodel.train_step(ref, m, v, step, x, labels, x_len, l_len)
+        assert abs(loss.item() - loss_ref) / abs(loss_ref) < 3e-2, (step, loss.item(), loss_ref)
+    for name, p in model.named_parameters():
+        d = (p.detach().cpu() - ref.g(name).detach()).abs().max().item()
+        assert d < 4e-3, (name, d)       # three Adam steps move each weight by <= 3e-3
+
+
+def test_reference_style_stream_model(device):
+    """A 'zhang'-style nn.Stream stack exactly as run/ctc/cnn/model.py:40-89 writes it (explicit pad + slice lambda,
+    Maxout, MaxPooling2D, kernel_height conv, 1x1 convs, LayerNormalization) runs and back-propagates."""
+    import math
+    import asr.nn as nn
+    from asr.model.cnn import AcousticModel
+    from asr.loss import connectionist_temporal_classification
+    torch.manual_seed(0)
+    ndim_h, ndim_dense, V, nmel = 16, 24, 13, 40
+    ks, pad = (3, 5), 4
+    kernel_height = int(math.ceil((nmel - 2) / 3))
+    model = AcousticModel()
+    model.layer(nn.Convolution2D(3, ndim_h * 2, ks, stride=1, pad=(0, pad)), lambda x: x[..., :-pad], nn.Maxout(2),
+                nn.Dropout(0), nn.MaxPooling2D(ksize=(3, 1)))
+    model.layer(nn.Residual(nn.Convolution2D(ndim_h, ndim_h * 2, ks, stride=1, pad=(1, pad)), lambda x: x[..., :-pad],
+                            nn.Maxout(2), nn.Dropout(0)))
+    model.layer(nn.Convolution2D(ndim_h, ndim_dense * 2, ksize=(kernel_height, 1), stride=1, pad=0), nn.Maxout(2), nn.Dropout(0))
+    model.layer(nn.Convolution2D(ndim_dense, ndim_dense * 2, ksize=1, stride=1, pad=0), nn.Maxout(2), nn.Dropout(0))
+    model.layer(nn.Convolution2D(ndim_dense, V, ksize=1, stride=1, pad=0), nn.LayerNormalization(None))
+    model.to_gpu()
+    B, T = 3, 30
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=2, Lmax=5, seed=4)
+    ys = model(x.to(device))
+    assert len(ys) == T and ys[0].shape == (B, V)
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+    loss.backward()
+    assert np.isfinite(loss.item())
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    y2 = model(x.to(device), split_into_variables=False)
+    assert y2.shape == (B, T, V)
+    # torch-CPU restatement of the same stack
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    from oracle import nn as onn
+    h = onn.maxpool_h(onn.maxout2(onn.conv2d_causal(x, sd["layer_0.W"], sd["layer_0.b"], 0)), 3)
+    h = onn.maxout2(onn.conv2d_causal(h, sd["layer_5_0.W"], sd["layer_5_0.b"], 1)) + h
+    h = onn.maxout2(torch.nn.functional.conv2d(h, sd["layer_6.W"], sd["layer_6.b"]))
+    h = onn.maxout2(torch.nn.functional.conv2d(h, sd["layer_9.W"], sd["layer_9.b"]))
+    h = torch.nn.functional.conv2d(h, sd["layer_12.W"], sd["layer_12.b"])
+    yr, _ = onn.layer_normalization(h.numpy().astype(np.float64), sd["layer_13.gamma"].numpy().astype(np.float64),
+                                    sd["layer_13.beta"].numpy().astype(np.float64))
+    got = y2.detach().cpu().numpy()                      # (B, T, V)
+    want = yr[:, :, 0, :].transpose(0, 2, 1)
+    assert _cos(torch.tensor(got), torch.tensor(want)) > 0.999
