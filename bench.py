@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/sec of one CTC train step (T=1000, 40x3 features, |V|=3000) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward (2 x conv + 4 x BiGRU-512 + dense + LayerNorm) + CTC loss + backward + gradient all-reduce (N > 1) +
+GradientClipping(1) + WeightDecay(1e-5) + Adam -- BASELINE.json configs[1] (configs[2] per GPU when N > 1), synthetic
+batch resident in HBM, random-init weights.  One JSON line on rank 0 (see the task contract): value = utterances of
+all ranks / max-over-ranks time; `roofline` = the dominant kernel by time, measured with HIP events in this process;
+`cpu_baseline` = the CPU oracle (oracle/model.py, torch-CPU fp32) timed on this host on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
+    ap.add_argument("--frames", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-census", action="store_true")
+    return ap.parse_args()
+
+
+class Census(object):
+    """Per-op-class device time of ONE extra step, HIP events recorded on the launch stream around every C-ABI call."""
+
+    def __init__(self):
+        self.events = []
+
+    def wrap(self, ops):
+        self._orig = {}
+        for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd",
+                     "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "clip_decay_adam",
+                     "sqnorm_acc", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack"):
+            fn = getattr(ops, name)
+            self._orig[name] = fn
+            setattr(ops, name, self._timed(name, fn))
+        self._ops = ops
+
+    def _timed(self, name, fn):
+        def inner(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            self.events.append((name, e0, e1))
+            return r
+        return inner
+
+    def unwrap(self):
+        for name, fn in self._orig.items():
+            setattr(self._ops, name, fn)
+
+    def totals(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.events:
+            ms, n = out.get(name, (0.0, 0))
+            out[name] = (ms + e0.elapsed_time(e1), n + 1)
+        return out
+
+
+def time_ctc(lib_mod, ops, T, B, V, L, x_len, l_len, labels, dev):
+    """HIP-event time of the CTC kernels alone (forward: prep+rows+lattice, backward: grad)."""
+    from asr import _lib
+    lib = _lib.lib()
+    xs = torch.randn(T, B, V, device=dev)
+    n = lib.asr_ctc_workspace_bytes(T, B, V, L, 0)
+    ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    loss = torch.empty(B, device=dev)
+    grad = torch.empty_like(xs)
+    s = torch.cuda.current_stream()
+
+    def fwd():
+        assert lib.asr_ctc_forward(s.cuda_stream, xs.data_ptr(), labels.data_ptr(), None, x_len.data_ptr(), l_len.data_ptr(), T, B, V,
+                                   L, 0, loss.data_ptr(), None, ws.data_ptr(), n) == 0
+
+    def bwd():
+        assert lib.asr_ctc_backward(s.cuda_stream, xs.data_ptr(), x_len.data_ptr(), T, B, V, L, 0, None, 0, 1.0 / B, grad.data_ptr(),
+                                    ws.data_ptr(), n) == 0
+    res = {}
+    for name, fn in (("ctc_forward", fwd), ("ctc_grad", bwd)):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(5):
+            fn()
+        e1.record(s)
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 5
+    return res
+
+
+def cpu_baseline(cfg, T, V, seconds_budget=25.0):
+    """The CPU oracle (torch-CPU fp32 restatement, oracle/model.py) on a bounded sample of the same workload."""
+    from asr.model import ds2
+    from oracle import model as omodel
+    torch.manual_seed(0)
+    B = 4
+    m = ds2.Model(cfg)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, seed=0)
+    # materialise the lazily-sized parameters with the shapes the HIP model would infer
+    feat = cfg.ndim_conv * 6
+    m.rnn_blocks.layers[0]._initialize_params(feat)
+    for i in range(1, cfg.num_rnn_layers):
+        m.rnn_blocks.layers[2 * i]._initialize_params(cfg.ndim_rnn)
+    m.dense_blocks.layers[0]._initialize_params(cfg.ndim_rnn)
+    m.dense_blocks.layers[7].norm._initialize_params(V)
+    state = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, cfg.bidirectional)
+    mm = [torch.zeros_like(p) for p in ref.parameters()]
+    vv = [torch.zeros_like(p) for p in ref.parameters()]
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    omodel.train_step(ref, mm, vv, 1, x, labels, x_len, l_len)           # warm-up (allocations, oneDNN primitives)
+    warm = time.time() - t0
+    n = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for s in range(n):
+        omodel.train_step(ref, mm, vv, 2 + s, x, labels, x_len, l_len)
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of B=%d utterances (T=%d, V=%d, same model, fp32, torch-CPU oracle) after 1 warm-up; %.2f s/step"
+                      % (n, B, T, V, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from asr import _lib, _ops
+    from asr.loss import connectionist_temporal_classification
+    from asr.model import ds2
+    from asr.optimizers import Adam, GradientClipping, WeightDecay
+    from oracle.model import synthetic_batch
+    _lib.lib()      # fail loudly if the HIP library is missing
+
+    comm = None
+    if world > 1:
+        from asr.parallel import Communicator
+        comm = Communicator("nccl")
+
+    B, T, V = args.batch, args.frames, args.vocab
+    cfg = ds2.configure()
+    cfg.vocab_size = V
+    torch.manual_seed(0)                         # identical initial weights on every rank (also broadcast below)
+    model = ds2.Model(cfg).to_gpu(local_rank)
+    x, labels, x_len, l_len = synthetic_batch(B, T, V, seed=rank)
+    x, labels, x_len, l_len = x.to(dev), labels.to(dev), x_len.to(dev), l_len.to(dev)
+
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    opt.add_hook(WeightDecay(1e-5))
+    if comm is not None:
+        opt.set_communicator(comm)
+
+    def step():
+        loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
+        opt.update(lossfun=lambda: loss)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if comm is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = tmax.item()
+    loss_value = loss.item()
+
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    out = {"metric": "utterances/sec (T=1000, 40x3 feat, |V|~3000) CTC train step", "value": value, "unit": "utterances/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
+                                  "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V),
+                      "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
+                      "final_loss": loss_value}}
+
+    if not args.no_census:
+        census = Census()
+        census.wrap(_ops)
+        step()
+        tot = census.totals()
+        census.unwrap()
+        ctc = time_ctc(_lib, _ops, T, B, V, labels.shape[1], x_len, l_len, labels, dev)
+        tot["ctc_forward"] = (ctc["ctc_forward"], 1)
+        tot["ctc_grad"] = (ctc["ctc_grad"], 1)
+        breakdown = {k: {"ms": round(ms, 3), "calls": n} for k, (ms, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])}
+        out["kernel_ms_per_step"] = breakdown
+        H, nl = cfg.ndim_rnn, cfg.num_rnn_layers
+        # dominant kernel class: the GRU step kernels.  One launch = one time step of one layer, both directions.
+        gru_ms = tot["gru_fwd"][0] + tot["gru_bwd"][0]
+        launches = 2 * nl * T
+        per_launch_s = gru_ms * 1e-3 / launches
+        # algorithmic bytes of a forward step launch: W_hh bf16 (2 x 3H x H), gi f32 (B x 6H), h in bf16 + out f32/bf16,
+        # saved gates f32 (B x 2 x 4H); backward: W_hh^T, dgh in, gates in, dgi/dgh out
+        fwd_bytes = 2 * 3 * H * H * 2 + B * 6 * H * 4 + B * 2 * H * (2 + 4 + 2) + B * 2 * 4 * H * 4
+        bwd_bytes = 2 * 3 * H * H * 2 + B * 6 * H * 2 + B * 2 * 4 * H * 4 + B * H * 2 + 2 * B * 6 * H * 2 + B * 2 * H * 4 * 3
+        alg = 0.5 * (fwd_bytes + bwd_bytes)
+        out["roofline"] = {"bound": "hbm", "kernel": "gru fwd_step_kernel / bwd_step_kernel (one launch per time step)",
+                           "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                           "us_per_launch": per_launch_s * 1e6, "launches_per_step": launches,
+                           "note": "latency-bound recurrence: operands are L2-resident, neither roofline binds (DESIGN.md)"}
+        ctc_bytes = 2.0 * T * B * V * 4
+        ctc_ms = ctc["ctc_forward"] + ctc["ctc_grad"]
+        out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": ctc_bytes / (ctc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                     "ms": ctc_ms, "algorithmic_bytes": ctc_bytes}
+        frames = T * B
+        macs_fwd = frames * 15.25e6
+        gemm_ms = tot["gemm_nt"][0] + tot["gemm_tn_acc"][0]
+        rec_flops = 2 * (2 * nl * T) * (B * H * 3 * H * 2)      # recurrent MFMA work runs inside the GRU kernels
+        gemm_flops = 3 * 2 * macs_fwd - rec_flops
+        out["roofline_gemm"] = {"bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                "ms": gemm_ms}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, T, V)
+        out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

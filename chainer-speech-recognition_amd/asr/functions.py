@@ -198,9 +198,6 @@ class _Dense(torch.autograd.Function):
 
 
 def dense(x2, W, b, link, out_f32=False):
-    w2 = W.reshape(W.shape[0], -1)
-    if w2.shape[1] % 8:
-        raise ValueError("dense input width must be a multiple of 8 (got %d)" % w2.shape[1])
     w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1)))
     w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1), transpose=True))
     return _Dense.apply(x2, W, b, w16, w16t, bool(out_f32))
@@ -459,8 +456,6 @@ def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
     p = phys3(x)
     T, B, I = p.shape
     H = w_hh.shape[2]
-    if I % 8:
-        raise ValueError("GRU input width must be a multiple of 8")
     copies = (
         link.compute_copy("wih16", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]))),
         link.compute_copy("wih16t", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]), transpose=True)),

@@ -61,15 +61,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     uint4 ra[4], rb[4];
+    // 16-byte loads need K, the row pitch and the base address to be multiples of 8 elements; otherwise (odd
+    // vocabulary sizes such as 119) fall back to element loads for that operand
+    const bool a_vec = ((K & 7) == 0) && ((lda & 7) == 0) && ((((uintptr_t)A) & 15) == 0);
+    const bool b_vec = ((K & 7) == 0) && ((ldb & 7) == 0) && ((((uintptr_t)B) & 15) == 0);
+    auto load_row = [&](const uint16_t* P, int ld, bool vec, int g, int lim, int k) -> uint4 {
+        if (g >= lim || k >= K) return make_uint4(0, 0, 0, 0);
+        const uint16_t* src = P + (size_t)g * ld + k;
+        if (vec) return ld16(src);
+        union { uint4 u; uint16_t s[8]; } t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t.s[e] = (k + e < K) ? src[e] : (uint16_t)0;
+        return t.u;
+    };
     auto load_global = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + i * 256;
             const int row = id >> 3, c = id & 7;
             const int k = k0 + c * 8;
-            const int gm = m0 + row, gn = n0 + row;
-            ra[i] = (gm < M && k < K) ? ld16(A + (size_t)gm * lda + k) : make_uint4(0, 0, 0, 0);
-            rb[i] = (gn < N && k < K) ? ld16(B + (size_t)gn * ldb + k) : make_uint4(0, 0, 0, 0);
+            ra[i] = load_row(A, lda, a_vec, m0 + row, M, k);
+            rb[i] = load_row(B, ldb, b_vec, n0 + row, N, k);
         }
     };
     auto store_lds = [&](int buf) {
@@ -280,8 +292,7 @@ using namespace asr::gemm;
 extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                            const float* bias, int M, int N, int K, int out_bf16) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
-    if ((K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N) return ASR_ERR_BAD_ARG;
-    if ((((uintptr_t)A) & 15) || (((uintptr_t)B) & 15)) return ASR_ERR_BAD_ARG;
+    if (lda < K || ldb < K || ldc < N) return ASR_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     static bool attr_set = false;

@@ -49,8 +49,8 @@ int asr_ctc_loss_grad(void* stream, const float* xs, const int32_t* label_unigra
  * bf16 MFMA GEMMs (f32 accumulate).  Replace the BLAS/cuDNN calls behind chainer.links.Linear, the 1x1
  * ConvolutionND of asr/nn/convolution_1d.py:7-38, the SRU projection asr/nn/sru.py:340-341,421-429 and -- through
  * asr_im2col / asr_col2im -- chainer.links.Convolution2D (asr/nn/nn.py:235-238).
- *   asr_gemm_nt      C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]);  A, B bf16 (k-contiguous, lda/ldb/K multiples of 8,
- *                    16-byte aligned); C f32 (out_bf16 = 0) or bf16 (1)
+ *   asr_gemm_nt      C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]);  A, B bf16, k-contiguous (fast path: lda/ldb/K multiples
+ *                    of 8 and 16-byte aligned bases; anything else takes element loads); C f32 (out_bf16 = 0) or bf16 (1)
  *   asr_gemm_tn_acc  C[M,N] += A[K,M]^T * B[K,N];  A, B bf16 row-major; C f32, accumulated with atomics (split-K)
  */
 int asr_gemm_nt(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,

@@ -20,7 +20,8 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 96, 72), (129, 130, 64), (1000, 1536, 384), (64, 3000, 320), (4096, 640, 512)])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 72), (129, 130, 64), (1000, 1536, 384), (64, 3000, 320), (4096, 640, 512),
+                                   (300, 64, 119), (77, 29, 45)])
 @pytest.mark.parametrize("out_dtype", [BF16, F32])
 def test_gemm_nt(device, M, N, K, out_dtype):
     from asr import _ops
