@@ -27,6 +27,11 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
+def log(msg):
+    sys.stderr.write("[bench] %s\n" % msg)
+    sys.stderr.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,10 +135,18 @@ def cpu_baseline(cfg, T, V, seconds_budget=25.0):
     ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, cfg.bidirectional)
     mm = [torch.zeros_like(p) for p in ref.parameters()]
     vv = [torch.zeros_like(p) for p in ref.parameters()]
-    cores = torch.get_num_threads()
+    # the GPU box shares its host: use the CPUs this process may run on, at most 16 (the 1-GPU share)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail, torch.get_num_threads()))
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d threads" % cores)
     t0 = time.time()
     omodel.train_step(ref, mm, vv, 1, x, labels, x_len, l_len)           # warm-up (allocations, oneDNN primitives)
     warm = time.time() - t0
+    log("cpu_baseline: warm-up step %.1f s" % warm)
     n = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
     t0 = time.time()
     for s in range(n):
@@ -186,9 +199,11 @@ def main():
         opt.update(lossfun=lambda: loss)
         return loss
 
+    log("rank %d/%d: model built, warm-up" % (rank, world))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    log("timing %d steps" % args.steps)
     if comm is not None:
         comm.barrier()
     torch.cuda.synchronize()
@@ -218,7 +233,9 @@ def main():
                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
                       "final_loss": loss_value}}
 
+    log("%.2f ms/step, %.1f utt/s" % (ms_per_step, value))
     if not args.no_census:
+        log("kernel census")
         census = Census()
         census.wrap(_ops)
         step()
