@@ -46,8 +46,8 @@ SIGNATURES = {
     "asr_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_int]),
     "asr_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 3 + [c_void_p, c_int, c_void_p, c_void_p,
                                   c_longlong, c_int, c_int]),
-    "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
-    "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4),
+    "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
+    "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
     "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4),
     "asr_sru_bwd": (c_int, [c_void_p] * 13 + [c_int] * 4),
     "asr_sru_combine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),

@@ -224,16 +224,31 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
     return dx
 
 
+GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only
+
+
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
+    sync = torch.zeros(4, dtype=torch.int32, device=dev)
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
     y = torch.empty((T * B, H), dtype=BF16, device=dev)
     rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
-                                T, B, H, ndir)
+                                T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_fwd")
+    LAST_SYNC[0] = sync
     return y, hseq, hseq16, gates
+
+
+LAST_SYNC = [None]
+
+
+def gru_check_sync():
+    """(debug / tests) synchronise and raise if the last persistent GRU launch abandoned an in-launch wait"""
+    s = LAST_SYNC[0]
+    if s is not None and int(s.cpu()[2]) != 0:
+        raise _lib.AsrHipError("persistent GRU kernel timed out waiting for another workgroup")
 
 
 def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir):
@@ -241,9 +256,11 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir):
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
+    sync = torch.zeros(4, dtype=torch.int32, device=dev)
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
-                                ptr(carry), T, B, H, ndir)
+                                ptr(carry), T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_bwd")
+    LAST_SYNC[0] = sync
     return dgi, dgh
 
 

@@ -36,6 +36,10 @@ __device__ __forceinline__ float tanhf_(float x) {
 
 constexpr int MT = 2;   // 16-row batch tiles per pass (32 utterances); larger batches loop
 
+// Every step is latency-bound (a few hundred KB from L2 / Infinity Cache, ~100 MFMAs): all global loads of a step --
+// the MFMA fragments of this wave's K slices AND the element-wise operands -- are issued up front, so a step pays one
+// memory round trip instead of one per K slice.  KSW = K slices (of 32) per wave, unrolled at compile time.
+template <int KSW>
 __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
                                                        const float* __restrict__ bhh, float* __restrict__ hseq,
                                                        uint16_t* __restrict__ hseq16, float* __restrict__ gates, int T,
@@ -49,30 +53,53 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
     const int nks = H >> 5;
     const size_t hs = (size_t)ndir * H;
     for (int b0 = 0; b0 < B; b0 += 16 * MT) {
+        // ---- element-wise operands of this thread's (b, j) pairs: issue the loads now, use them after the MFMAs
+        float e_gi[MT][3], e_hp[MT], e_bh[MT][3];
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int idx = tid + q * 256;
+            const int bl = idx >> 4, j = idx & 15;
+            const int b = b0 + bl;
+            const bool ok = b < B;
+            const size_t rowi = (size_t)t * B + (ok ? b : 0);
+            const float* gir = gi + rowi * (3 * hs) + (size_t)d * 3 * H + j0 + j;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                e_gi[q][g] = ok ? gir[g * H] : 0.f;
+                e_bh[q][g] = bhh[(d * 3 + g) * H + j0 + j];
+            }
+            e_hp[q] = (ok && !first) ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : 0.f;
+        }
         if (!first) {
+            Frag a[KSW][MT], bb[KSW][3];
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) {
+                const int ks = w * KSW + i;
+                const bool kok = ks < nks;
+                const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = b0 + m * 16 + (lane & 15);
+                    a[i][m].u = (kok && row < B) ? *reinterpret_cast<const uint4*>(hseq16 + ((size_t)tp * B + row) * hs + d * H + k)
+                                                 : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    bb[i][g].u = kok ? *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + g) * H + j0 + (lane & 15)) * H + k)
+                                     : make_uint4(0, 0, 0, 0);
+            }
             f32x4 acc[MT][3];
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int ks = w; ks < nks; ks += 4) {
-                const int k = ks * 32 + 8 * (lane >> 4);
-                Frag a[MT], bb[3];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = b0 + m * 16 + (lane & 15);
-                    a[m].u = row < B ? *reinterpret_cast<const uint4*>(hseq16 + ((size_t)tp * B + row) * hs + d * H + k)
-                                     : make_uint4(0, 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    bb[g].u = *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + g) * H + j0 + (lane & 15)) * H + k);
+            for (int i = 0; i < KSW; ++i)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v, bb[g].v, acc[m][g], 0, 0, 0);
-            }
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i][g].v, acc[m][g], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -80,7 +107,9 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
                     part[((w * MT + m) * 3 + g) * 64 + lane] = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
         }
         __syncthreads();
-        for (int idx = tid; idx < MT * 256; idx += 256) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int idx = tid + q * 256;
             const int bl = idx >> 4, j = idx & 15;
             const int b = b0 + bl;
             if (b >= B) continue;
@@ -89,7 +118,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
             float gh[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                float sum = bhh[(d * 3 + g) * H + j0 + j];
+                float sum = e_bh[q][g];
                 if (!first) {
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) {
@@ -100,12 +129,10 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
                 gh[g] = sum;
             }
             const size_t rowi = (size_t)t * B + b;
-            const float* gir = gi + rowi * (3 * hs) + (size_t)d * 3 * H + j0 + j;
-            const float r = sigmoidf_(gir[0] + gh[0]);
-            const float z = sigmoidf_(gir[H] + gh[1]);
-            const float n = tanhf_(gir[2 * H] + r * gh[2]);
-            const float hp = first ? 0.f : hseq[((size_t)tp * B + b) * hs + d * H + j0 + j];
-            const float h = (1.0f - z) * n + z * hp;
+            const float r = sigmoidf_(e_gi[q][0] + gh[0]);
+            const float z = sigmoidf_(e_gi[q][1] + gh[1]);
+            const float n = tanhf_(e_gi[q][2] + r * gh[2]);
+            const float h = (1.0f - z) * n + z * e_hp[q];
             hseq[rowi * hs + d * H + j0 + j] = h;
             hseq16[rowi * hs + d * H + j0 + j] = f32_to_bf16(h);
             float* gs = gates + (rowi * ndir + d) * 4 * H + j0 + j;
@@ -116,6 +143,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
 }
 
 // backward step: dh_t = dy_t + carry + dgh_{next} W_hh ; gate gradients ; carry <- dh_t * z_t
+template <int KSW>
 __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
                                                        const float* __restrict__ hseq,
                                                        const uint16_t* __restrict__ whhT, uint16_t* __restrict__ dgi,
@@ -132,55 +160,80 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
     const int nks = (3 * H) >> 5;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
     for (int b0 = 0; b0 < B; b0 += 16 * MT) {
+        float e_dy[MT], e_c[MT], e_g[MT][4], e_hp[MT];
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int idx = tid + q * 256;
+            const int bl = idx >> 4, j = idx & 15;
+            const int b = b0 + bl;
+            const bool ok = b < B;
+            const size_t rowi = (size_t)t * B + (ok ? b : 0);
+            e_dy[q] = ok ? bf16_to_f32(dy[rowi * H + j0 + j]) : 0.f;
+            e_c[q] = (ok && !first) ? carry[((size_t)d * B + b) * H + j0 + j] : 0.f;
+            const float* gs = gates + (rowi * ndir + d) * 4 * H + j0 + j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[q][g] = ok ? gs[g * H] : 0.f;
+            e_hp[q] = (ok && has_prev) ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : 0.f;
+        }
         if (!first) {
             f32x4 acc[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int ks = w; ks < nks; ks += 4) {
-                const int k = ks * 32 + 8 * (lane >> 4);
-                Frag a[MT], bb;
+            for (int base = 0; base * 4 < nks; base += KSW) {      // one pass when 4 * KSW >= nks
+                Frag a[KSW][MT], bb[KSW];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = b0 + m * 16 + (lane & 15);
-                    a[m].u = row < B ? *reinterpret_cast<const uint4*>(dgh + ((size_t)tn * B + row) * gs3 + (size_t)d * 3 * H + k)
-                                     : make_uint4(0, 0, 0, 0);
+                for (int i = 0; i < KSW; ++i) {
+                    const int ks = (base + i) * 4 + w;
+                    const bool kok = ks < nks;
+                    const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int row = b0 + m * 16 + (lane & 15);
+                        a[i][m].u = (kok && row < B)
+                                        ? *reinterpret_cast<const uint4*>(dgh + ((size_t)tn * B + row) * gs3 + (size_t)d * 3 * H + k)
+                                        : make_uint4(0, 0, 0, 0);
+                    }
+                    bb[i].u = kok ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k)
+                                  : make_uint4(0, 0, 0, 0);
                 }
-                bb.u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v, bb.v, acc[m], 0, 0, 0);
+                for (int i = 0; i < KSW; ++i)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i].v, acc[m], 0, 0, 0);
             }
 #pragma unroll
             for (int m = 0; m < MT; ++m)
                 part[(w * MT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
         }
         __syncthreads();
-        for (int idx = tid; idx < MT * 256; idx += 256) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int idx = tid + q * 256;
             const int bl = idx >> 4, j = idx & 15;
             const int b = b0 + bl;
             if (b >= B) continue;
             const int m = bl >> 4, row = bl & 15;
             const int pl = (row >> 2) * 16 + j, pr = row & 3;
             const size_t rowi = (size_t)t * B + b;
-            float dh = bf16_to_f32(dy[rowi * H + j0 + j]);
-            float* cp = carry + ((size_t)d * B + b) * H + j0 + j;
+            float dh = e_dy[q];
             if (!first) {
-                dh += *cp;
+                dh += e_c[q];
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) {
                     const float4 v = part[(ww * MT + m) * 64 + pl];
                     dh += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
                 }
             }
-            const float* gs = gates + (rowi * ndir + d) * 4 * H + j0 + j;
-            const float r = gs[0], z = gs[H], n = gs[2 * H], q = gs[3 * H];
-            const float hp = has_prev ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : 0.f;
+            const float r = e_g[q][0], z = e_g[q][1], n = e_g[q][2], qq = e_g[q][3];
+            const float hp = e_hp[q];
             const float dn = dh * (1.0f - z);
             const float dz = dh * (hp - n);
             const float dan = dn * (1.0f - n * n);
             const float daz = dz * z * (1.0f - z);
             const float dq = dan * r;
-            const float dar = dan * q * r * (1.0f - r);
-            *cp = dh * z;
+            const float dar = dan * qq * r * (1.0f - r);
+            carry[((size_t)d * B + b) * H + j0 + j] = dh * z;
             uint16_t* gi_o = dgi + rowi * gs3 + (size_t)d * 3 * H + j0 + j;
             uint16_t* gh_o = dgh + rowi * gs3 + (size_t)d * 3 * H + j0 + j;
             const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz);
@@ -188,6 +241,290 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
             gh_o[0] = ar; gh_o[H] = az; gh_o[2 * H] = f32_to_bf16(dq);
         }
         __syncthreads();
+    }
+}
+
+// ================================================================================================ persistent form
+// One launch per layer: every workgroup keeps its W_hh slice in registers for all T steps and the workgroups of a
+// direction hand h_t (forward) / dgh_t (backward) to each other through HBM-side memory inside the launch:
+//   producer: payload stored write-through (sc1) -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier ->
+//             ONE lane: agent-scope atomic add on the direction's step counter
+//   consumer: ONE lane polls the counter with relaxed agent-scope (sc1) loads, bounded, -> workgroup barrier ->
+//             every load of the payload is an sc1 buffer load to registers
+// (MI355X_MICROARCH.md "Valid forms", first row of the sc1 table; placement independent).  One workgroup per CU is
+// forced by the LDS request; a grid of at most 128 workgroups is always co-resident on 256 CUs.  Every spin is bounded:
+// on time-out the workgroup raises the abort word, which all pollers watch, and the launch drains.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kSpinLimit = 1u << 19;
+constexpr int kPersistLds = 96 * 1024;
+
+#define ASR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// returns false when the wait was abandoned (abort raised here or elsewhere)
+__device__ __forceinline__ bool wait_counter(unsigned* counter, unsigned target, unsigned* abort_word) {
+    unsigned spins = 0;
+    for (;;) {
+        if (__hip_atomic_load(counter, ASR_RLX_AGENT) >= target) return true;
+        if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+        if (++spins > kSpinLimit) {
+            __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int KSW>
+__global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __restrict__ gi,
+                                                             const uint16_t* __restrict__ whh,
+                                                             const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                             uint16_t* hseq16, float* __restrict__ gates,
+                                                             unsigned* sync, int T, int B, int H, int ndir) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MT][3][64]
+    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * MT * 3 * 64);
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, nwg = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nks = H >> 5;
+    const size_t hs = (size_t)ndir * H;
+    unsigned* counter = sync + d;
+    unsigned* abort_word = sync + 2;
+    const __amdgpu_buffer_rsrc_t h16rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
+
+    // stationary operand: this wave's K slices of the workgroup's 3 x 16 rows of W_hh
+    Frag bb[KSW][3];
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        const int ks = w * KSW + i;
+        const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            bb[i][g].u = ks < nks ? *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + g) * H + j0 + (lane & 15)) * H + k)
+                                  : make_uint4(0, 0, 0, 0);
+    }
+    // element-wise role: batch row b, hidden units j0 + 2*jp, j0 + 2*jp + 1
+    const int b = tid >> 3, jp = tid & 7, j = j0 + 2 * jp;
+    const bool act = b < B;
+    float bh[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bh[g][0] = bhh[(d * 3 + g) * H + j];
+        bh[g][1] = bhh[(d * 3 + g) * H + j + 1];
+    }
+    float hprev[2] = {0.f, 0.f};
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        const size_t rowi = (size_t)t * B + (act ? b : 0);
+        float2 egi[3];
+        {
+            const float* gir = gi + rowi * (3 * hs) + (size_t)d * 3 * H + j;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) egi[g] = act ? *reinterpret_cast<const float2*>(gir + g * H) : make_float2(0.f, 0.f);
+        }
+        float gh[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { gh[g][0] = bh[g][0]; gh[g][1] = bh[g][1]; }
+        if (s > 0) {
+            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
+            __syncthreads();
+            if (*s_abort) break;
+            f32x4 acc[MT][3];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Frag a[KSW][MT];
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) {
+                const int ks = w * KSW + i;
+                const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = m * 16 + (lane & 15);
+                    const bool ok = ks < nks && row < B;
+                    const unsigned off = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * hs + d * H + (ok ? k : 0)) * 2);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                    a[i][m].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KSW; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i][g].v, acc[m][g], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    part[((w * MT + m) * 3 + g) * 64 + lane] = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+            __syncthreads();
+            if (act) {
+                const int m = b >> 4, row = b & 15, pr = row & 3;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pl = (row >> 2) * 16 + 2 * jp + e;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+#pragma unroll
+                        for (int ww = 0; ww < 4; ++ww) {
+                            const float4 v = part[((ww * MT + m) * 3 + g) * 64 + pl];
+                            gh[g][e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
+                        }
+                }
+            }
+        }
+        if (act) {
+            float r[2], z[2], n[2], h[2];
+            const float gir[3][2] = {{egi[0].x, egi[0].y}, {egi[1].x, egi[1].y}, {egi[2].x, egi[2].y}};
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                r[e] = sigmoidf_(gir[0][e] + gh[0][e]);
+                z[e] = sigmoidf_(gir[1][e] + gh[1][e]);
+                n[e] = tanhf_(gir[2][e] + r[e] * gh[2][e]);
+                h[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
+                hprev[e] = h[e];
+            }
+            const size_t o = rowi * hs + d * H + j;
+            const unsigned packed = (unsigned)f32_to_bf16(h[0]) | ((unsigned)f32_to_bf16(h[1]) << 16);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
+            *reinterpret_cast<float2*>(hseq + o) = make_float2(h[0], h[1]);
+            float* gs = gates + (rowi * ndir + d) * 4 * H + j;
+            *reinterpret_cast<float2*>(gs) = make_float2(r[0], r[1]);
+            *reinterpret_cast<float2*>(gs + H) = make_float2(z[0], z[1]);
+            *reinterpret_cast<float2*>(gs + 2 * H) = make_float2(n[0], n[1]);
+            *reinterpret_cast<float2*>(gs + 3 * H) = make_float2(gh[2][0], gh[2][1]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the signal
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+    }
+}
+
+template <int KSW>
+__global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __restrict__ dy,
+                                                             const float* __restrict__ gates,
+                                                             const float* __restrict__ hseq,
+                                                             const uint16_t* __restrict__ whhT,
+                                                             uint16_t* __restrict__ dgi, uint16_t* dgh, unsigned* sync,
+                                                             int T, int B, int H, int ndir) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MT][64]
+    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * MT * 64);
+    const int d = blockIdx.y, j0 = blockIdx.x * 16, nwg = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nks = (3 * H) >> 5;
+    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
+    unsigned* counter = sync + d;
+    unsigned* abort_word = sync + 2;
+    const __amdgpu_buffer_rsrc_t dghrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
+
+    Frag bb[KSW];
+#pragma unroll
+    for (int i = 0; i < KSW; ++i) {
+        const int ks = i * 4 + w;
+        const int k = ks * 32 + 8 * (lane >> 4);
+        bb[i].u = ks < nks ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k)
+                           : make_uint4(0, 0, 0, 0);
+    }
+    const int b = tid >> 3, jp = tid & 7, j = j0 + 2 * jp;
+    const bool act = b < B;
+    float carry[2] = {0.f, 0.f};
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? t + 1 : t - 1;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        const bool has_prev = d == 0 ? t > 0 : t < T - 1;
+        const size_t rowi = (size_t)t * B + (act ? b : 0);
+        // operands that do not depend on the other workgroups: issue before the wait
+        const unsigned dyp = act ? *reinterpret_cast<const unsigned*>(dy + rowi * H + j) : 0u;
+        const float* gs = gates + (rowi * ndir + d) * 4 * H + j;
+        float2 eg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) eg[g] = act ? *reinterpret_cast<const float2*>(gs + g * H) : make_float2(0.f, 0.f);
+        const float2 ehp = (act && has_prev) ? *reinterpret_cast<const float2*>(hseq + ((size_t)tp * B + b) * hs + d * H + j)
+                                             : make_float2(0.f, 0.f);
+        float dh[2] = {bf16_to_f32((uint16_t)(dyp & 0xffff)) + carry[0], bf16_to_f32((uint16_t)(dyp >> 16)) + carry[1]};
+        if (s > 0) {
+            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
+            __syncthreads();
+            if (*s_abort) break;
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Frag a[KSW][MT];
+#pragma unroll
+            for (int i = 0; i < KSW; ++i) {
+                const int ks = i * 4 + w;
+                const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = m * 16 + (lane & 15);
+                    const bool ok = ks < nks && row < B;
+                    const unsigned off = (unsigned)((((size_t)tn * B + (ok ? row : 0)) * gs3 + (size_t)d * 3 * H + (ok ? k : 0)) * 2);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                    a[i][m].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KSW; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i].v, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                part[(w * MT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+            __syncthreads();
+            if (act) {
+                const int m = b >> 4, row = b & 15, pr = row & 3;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int pl = (row >> 2) * 16 + 2 * jp + e;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const float4 v = part[(ww * MT + m) * 64 + pl];
+                        dh[e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
+                    }
+                }
+            }
+        }
+        if (act) {
+            const float r[2] = {eg[0].x, eg[0].y}, z[2] = {eg[1].x, eg[1].y}, n[2] = {eg[2].x, eg[2].y}, qq[2] = {eg[3].x, eg[3].y};
+            const float hp[2] = {ehp.x, ehp.y};
+            uint16_t ar[2], az[2], an[2], aq[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float dn = dh[e] * (1.0f - z[e]);
+                const float dz = dh[e] * (hp[e] - n[e]);
+                const float dan = dn * (1.0f - n[e] * n[e]);
+                const float daz = dz * z[e] * (1.0f - z[e]);
+                const float dq = dan * r[e];
+                const float dar = dan * qq[e] * r[e] * (1.0f - r[e]);
+                carry[e] = dh[e] * z[e];
+                ar[e] = f32_to_bf16(dar); az[e] = f32_to_bf16(daz); an[e] = f32_to_bf16(dan); aq[e] = f32_to_bf16(dq);
+            }
+            const size_t o = rowi * gs3 + (size_t)d * 3 * H + j;
+            const unsigned pr_ = (unsigned)ar[0] | ((unsigned)ar[1] << 16), pz_ = (unsigned)az[0] | ((unsigned)az[1] << 16);
+            const unsigned pn_ = (unsigned)an[0] | ((unsigned)an[1] << 16), pq_ = (unsigned)aq[0] | ((unsigned)aq[1] << 16);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);           // sc1 payload
+            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
+            *reinterpret_cast<unsigned*>(dgi + o) = pr_;
+            *reinterpret_cast<unsigned*>(dgi + o + H) = pz_;
+            *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pn_;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
     }
 }
 
@@ -216,16 +553,44 @@ static int check_dims(int T, int B, int H, int ndir) {
     return ASR_OK;
 }
 
+// persistent form applies when one pass covers the batch (B <= 32), the grid is surely co-resident (<= 128 workgroups)
+// and the offsets fit the 32-bit buffer descriptors
+static bool can_persist(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
+    if (mode == 1 || !sync_ws) return false;
+    if (B > 16 * MT || (H / 16) * ndir > 128 || H > 1024) return false;
+    if ((size_t)T * B * ndir * 3 * H * 2 >= ((size_t)1 << 31)) return false;
+    return true;
+}
+
 extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq,
-                           void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir) {
+                           void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
+                           int mode) {
     if (!gi || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(H / 16, ndir), block(256);
-    for (int s = 0; s < T; ++s)
-        hipLaunchKernelGGL(fwd_step_kernel, grid, block, 0, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,
-                           (uint16_t*)hseq_bf16, gates, T, B, H, ndir, s);
+    const int ksw = (H / 32 + 3) / 4;
+    if (ksw > 8) return ASR_ERR_UNSUPPORTED;      // H <= 1024
+    const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
+    if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
+    if (persist) {
+        if (hipMemsetAsync(sync_ws, 0, 16, st) != hipSuccess) return ASR_ERR_LAUNCH;
+#define ASR_FWDP(K)                                                                                                       \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL(fwd_persistent_kernel<K>, grid, block, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,      \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir);                                      \
+    } while (0)
+        if (ksw <= 1) ASR_FWDP(1); else if (ksw <= 2) ASR_FWDP(2); else if (ksw <= 4) ASR_FWDP(4); else ASR_FWDP(8);
+#undef ASR_FWDP
+    } else
+    for (int s = 0; s < T; ++s) {
+#define ASR_FWD(K) hipLaunchKernelGGL(fwd_step_kernel<K>, grid, block, 0, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                                      (uint16_t*)hseq_bf16, gates, T, B, H, ndir, s)
+        if (ksw <= 1) ASR_FWD(1); else if (ksw <= 2) ASR_FWD(2); else if (ksw <= 4) ASR_FWD(4); else ASR_FWD(8);
+#undef ASR_FWD
+    }
     ASR_LAUNCH_CHECK();
     if (y_bf16) {
         const long long n = (long long)T * B * H;
@@ -240,15 +605,32 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
 
 extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq,
                            const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, int T, int B, int H,
-                           int ndir) {
+                           int ndir, void* sync_ws, int mode) {
     if (!dy_bf16 || !gates || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(H / 16, ndir), block(256);
-    for (int s = 0; s < T; ++s)
-        hipLaunchKernelGGL(bwd_step_kernel, grid, block, 0, st, (const uint16_t*)dy_bf16, gates, hseq,
-                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s);
+    const int ksw = (3 * H / 32 + 3) / 4;
+    const bool persist = can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12;
+    if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
+    if (persist) {
+        if (hipMemsetAsync(sync_ws, 0, 16, st) != hipSuccess) return ASR_ERR_LAUNCH;
+#define ASR_BWDP(K)                                                                                                       \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)bwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL(bwd_persistent_kernel<K>, grid, block, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq,         \
+                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, (unsigned*)sync_ws, T, B, H, ndir); \
+    } while (0)
+        if (ksw <= 2) ASR_BWDP(2); else if (ksw <= 6) ASR_BWDP(6); else ASR_BWDP(12);
+#undef ASR_BWDP
+    } else
+    for (int s = 0; s < T; ++s) {
+#define ASR_BWD(K) hipLaunchKernelGGL(bwd_step_kernel<K>, grid, block, 0, st, (const uint16_t*)dy_bf16, gates, hseq, \
+                                      (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s)
+        if (ksw <= 2) ASR_BWD(2); else if (ksw <= 6) ASR_BWD(6); else ASR_BWD(12);
+#undef ASR_BWD
+    }
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
