@@ -265,12 +265,14 @@ __device__ __forceinline__ bool wait_counter(unsigned* counter, unsigned target,
     unsigned spins = 0;
     for (;;) {
         if (__hip_atomic_load(counter, ASR_RLX_AGENT) >= target) return true;
-        if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
-        if (++spins > kSpinLimit) {
-            __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
-            return false;
+        ++spins;
+        if ((spins & 63u) == 0u) {          // the abort word is looked at once per 64 polls: the poll itself stays one load
+            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+                return false;
+            }
         }
-        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -380,8 +382,8 @@ __global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __rest
                 }
             }
         }
-        if (act) {
-            float r[2], z[2], n[2], h[2];
+        float r[2], z[2], n[2], h[2];
+        {
             const float gir[3][2] = {{egi[0].x, egi[0].y}, {egi[1].x, egi[1].y}, {egi[2].x, egi[2].y}};
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -391,9 +393,17 @@ __global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __rest
                 h[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
                 hprev[e] = h[e];
             }
-            const size_t o = rowi * hs + d * H + j;
+        }
+        const size_t o = rowi * hs + d * H + j;
+        if (act) {
             const unsigned packed = (unsigned)f32_to_bf16(h[0]) | ((unsigned)f32_to_bf16(h[1]) << 16);
             __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its payload before the signal
+        __syncthreads();                                    // (barriers stay in uniform control flow)
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+        if (act) {
+            // what only the backward pass reads goes out after the signal (drained by the next step's wait)
             *reinterpret_cast<float2*>(hseq + o) = make_float2(h[0], h[1]);
             float* gs = gates + (rowi * ndir + d) * 4 * H + j;
             *reinterpret_cast<float2*>(gs) = make_float2(r[0], r[1]);
@@ -401,9 +411,6 @@ __global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __rest
             *reinterpret_cast<float2*>(gs + 2 * H) = make_float2(n[0], n[1]);
             *reinterpret_cast<float2*>(gs + 3 * H) = make_float2(gh[2][0], gh[2][1]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the signal
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
     }
 }
 
@@ -497,7 +504,8 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
                 }
             }
         }
-        if (act) {
+        unsigned pr_, pz_, pn_, pq_;
+        {
             const float r[2] = {eg[0].x, eg[0].y}, z[2] = {eg[1].x, eg[1].y}, n[2] = {eg[2].x, eg[2].y}, qq[2] = {eg[3].x, eg[3].y};
             const float hp[2] = {ehp.x, ehp.y};
             uint16_t ar[2], az[2], an[2], aq[2];
@@ -512,19 +520,23 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
                 carry[e] = dh[e] * z[e];
                 ar[e] = f32_to_bf16(dar); az[e] = f32_to_bf16(daz); an[e] = f32_to_bf16(dan); aq[e] = f32_to_bf16(dq);
             }
-            const size_t o = rowi * gs3 + (size_t)d * 3 * H + j;
-            const unsigned pr_ = (unsigned)ar[0] | ((unsigned)ar[1] << 16), pz_ = (unsigned)az[0] | ((unsigned)az[1] << 16);
-            const unsigned pn_ = (unsigned)an[0] | ((unsigned)an[1] << 16), pq_ = (unsigned)aq[0] | ((unsigned)aq[1] << 16);
+            pr_ = (unsigned)ar[0] | ((unsigned)ar[1] << 16); pz_ = (unsigned)az[0] | ((unsigned)az[1] << 16);
+            pn_ = (unsigned)an[0] | ((unsigned)an[1] << 16); pq_ = (unsigned)aq[0] | ((unsigned)aq[1] << 16);
+        }
+        const size_t o = rowi * gs3 + (size_t)d * 3 * H + j;
+        if (act) {
             __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);           // sc1 payload
             __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
             __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
-            *reinterpret_cast<unsigned*>(dgi + o) = pr_;
-            *reinterpret_cast<unsigned*>(dgi + o + H) = pz_;
-            *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pn_;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+        if (act) {
+            *reinterpret_cast<unsigned*>(dgi + o) = pr_;
+            *reinterpret_cast<unsigned*>(dgi + o + H) = pz_;
+            *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pn_;
+        }
     }
 }
 
