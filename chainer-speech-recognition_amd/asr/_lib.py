@@ -23,6 +23,10 @@ SIGNATURES = {
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
     "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),
     "asr_ctc_loss_grad": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float] + [c_void_p] * 4 + [c_size_t]),
+    "asr_specgram": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_int, c_void_p]),
+    "asr_logmel": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_void_p]),
+    "asr_deltas": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     "asr_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
@@ -46,6 +50,11 @@ SIGNATURES = {
     "asr_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_int]),
     "asr_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 3 + [c_void_p, c_int, c_void_p, c_void_p,
                                   c_longlong, c_int, c_int]),
+    "asr_weightnorm_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int]),
+    "asr_weightnorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int]),
+    "asr_channel_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
+    "asr_channel_affine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),
+    "asr_weightnorm_init": (c_int, [c_void_p] * 5 + [c_int]),
     "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
     "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
     "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4),

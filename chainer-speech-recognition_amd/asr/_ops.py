@@ -315,3 +315,41 @@ def clip_decay_sgd(p, g, v, kind, lr, momentum, weight_decay, clip, grad_scale, 
     rc = _lib.lib().asr_clip_decay_sgd(stream(), ptr(p), ptr(g), ptr(v), p.numel(), int(kind), lr, momentum, weight_decay,
                                        clip, grad_scale, ptr(sqnorm))
     check(rc, "asr_clip_decay_sgd")
+
+
+def weightnorm_fwd(V, g):
+    """V (Co, ...) f32, g (Co, 1, 1, 1) -> W (same shape as V) f32, norm (Co)."""
+    Co = V.shape[0]
+    K = V.numel() // Co
+    W = torch.empty_like(V, memory_format=torch.contiguous_format)
+    norm = torch.empty(Co, dtype=F32, device=V.device)
+    check(_lib.lib().asr_weightnorm_fwd(stream(), ptr(V.contiguous()), ptr(g.contiguous()), ptr(W), ptr(norm), Co, K), "asr_weightnorm_fwd")
+    return W, norm
+
+
+def weightnorm_bwd(gW, V, g, norm, gV, gg):
+    Co = V.shape[0]
+    K = V.numel() // Co
+    rc = _lib.lib().asr_weightnorm_bwd(stream(), ptr(gW), ptr(V.contiguous()), ptr(g.contiguous()), ptr(norm), ptr(gV), ptr(gg), Co, K)
+    check(rc, "asr_weightnorm_bwd")
+
+
+def channel_mean_std(x2):
+    rows, C = x2.shape
+    mean = torch.empty(C, dtype=F32, device=x2.device)
+    std = torch.empty(C, dtype=F32, device=x2.device)
+    check(_lib.lib().asr_channel_stats(stream(), ptr(x2), rows, C, ptr(mean), ptr(std)), "asr_channel_stats")
+    return mean, std
+
+
+def weightnorm_init(mean, std):
+    g = torch.empty_like(mean)
+    b = torch.empty_like(mean)
+    check(_lib.lib().asr_weightnorm_init(stream(), ptr(mean), ptr(std), ptr(g), ptr(b), mean.numel()), "asr_weightnorm_init")
+    return g, b
+
+
+def channel_affine(x2, scale, shift):
+    y = torch.empty(x2.shape, dtype=BF16, device=x2.device)
+    check(_lib.lib().asr_channel_affine(stream(), ptr(x2), ptr(scale), ptr(shift), ptr(y), x2.numel(), x2.shape[1]), "asr_channel_affine")
+    return y

@@ -126,7 +126,12 @@ class _Conv2D(torch.autograd.Function):
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
         Kp = col.shape[1]
-        gW = grad_buffer(W)
+        w_is_param = isinstance(W, torch.nn.Parameter)
+        if w_is_param:
+            gW = grad_buffer(W)
+        else:       # a derived weight (weight normalisation): hand its gradient back to the tape
+            gW = torch.empty(W.shape, dtype=F32, device=gy.device)
+            _ops.fill_(gW, 0.0)
         if Kp == Kreal and KH == 1 and KW == 1:
             _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
         else:
@@ -147,7 +152,7 @@ class _Conv2D(torch.autograd.Function):
             gx = gp.permute(1, 3, 2, 0)
             if xdtype == F32:
                 gx = _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
-        return gx, None, None, None, None, None, None, None, None
+        return gx, (None if w_is_param else gW), None, None, None, None, None, None, None
 
 
 def conv_weight_matrix(W):
@@ -167,6 +172,17 @@ def convolution_2d(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
     w16t = link.compute_copy("w16t", W, conv_weight_matrix_t)
     if x.dtype not in (F32, BF16):
         raise TypeError("convolution input must be float32 or bfloat16")
+    y = _Conv2D.apply(x, W, b, w16, w16t, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+    return logical4(y)
+
+
+def convolution_2d_given_weight(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
+    """the same convolution with a weight that is itself a function of parameters (weight normalisation): the bf16
+    matrices are rebuilt on every call"""
+    pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
+    with torch.no_grad():
+        w16 = conv_weight_matrix(W.detach())
+        w16t = conv_weight_matrix_t(W.detach())
     y = _Conv2D.apply(x, W, b, w16, w16t, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
     return logical4(y)
 

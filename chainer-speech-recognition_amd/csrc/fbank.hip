@@ -1,0 +1,185 @@
+// Log-mel filterbank features on the GPU, batched over utterances (gfx950).
+//
+// Replaces the per-utterance float64 NumPy loop of Processor.extract_batch_features (asr/data/processing.py:67-111):
+//   fft.get_specgram   asr/fft.py:52-56  -> python_speech_features.sigproc.preemphasis / framesig / powspec
+//                       (absent third party; published algorithm: y[0]=x[0], y[n]=x[n]-c*x[n-1]; frames of frame_len
+//                        every frame_step, numframes = 1 + ceil((N - frame_len)/frame_step), zero padded, times window;
+//                        |rfft_nfft|^2 / nfft)
+//   fft.compute_logmel asr/fft.py:58-66  feat = pspec . fbank^T, exact zeros -> DBL eps, log
+//   fft.compute_deltas asr/fft.py:6-19,90-99   delta[t] = (x[t+1] - x[t-1]) / 2 with edge padding, delta of delta, last 2 frames dropped
+//   Loader normalisation asr/data/loaders/base.py:22-24   (x - mean) / std per (channel, mel)
+//
+// specgram: one workgroup (256 threads) per frame: samples -> LDS with pre-emphasis and window, radix-2 FFT in LDS
+// (nfft/2 butterflies per stage, one barrier per stage), power spectrum, optional mel + log in the same kernel.
+// deltas:   one thread per (utterance, mel, t): reads 5 neighbouring log-mel frames, writes the three channels of the
+// reference's (B, 3, nmel, Tmax) float32 minibatch (zero padded beyond each utterance's length, asr/data/processing.py:124).
+#include "common.hpp"
+#include "../../include/asr_hip.h"
+
+namespace asr {
+namespace fbank {
+
+constexpr int kMaxFft = 1024;
+constexpr float kPi = 3.14159265358979323846f;
+
+__device__ __forceinline__ int bitrev(int x, int bits) { return (int)(__brev((unsigned)x) >> (32 - bits)); }
+
+template <typename SigT>
+__global__ __launch_bounds__(256) void specgram_kernel(const SigT* __restrict__ signals, const int* __restrict__ lengths,
+                                                       long long sig_pitch, int frame_len, int frame_step, int nfft,
+                                                       int logn, float preemph, const float* __restrict__ window,
+                                                       const int* __restrict__ nframes, int Fmax,
+                                                       float* __restrict__ pspec_out,        // (B, Fmax, nfft/2+1) or null
+                                                       const float* __restrict__ fbank, int nfilt,
+                                                       float* __restrict__ logmel_out) {     // (B, Fmax, nfilt) or null
+    __shared__ float re[kMaxFft], im[kMaxFft];
+    __shared__ float ps[kMaxFft / 2 + 1];
+    const int b = blockIdx.y, f = blockIdx.x;
+    if (f >= nframes[b]) return;
+    const SigT* sig = signals + (size_t)b * sig_pitch;
+    const int N = lengths[b];
+    const int start = f * frame_step;
+    for (int i = threadIdx.x; i < nfft; i += blockDim.x) {
+        float v = 0.f;
+        if (i < frame_len) {
+            const int n = start + i;
+            if (n < N) {
+                const float x = (float)sig[n];
+                v = n == 0 ? x : x - preemph * (float)sig[n - 1];
+                v *= window[i];
+            }
+        }
+        const int r = bitrev(i, logn);
+        re[r] = v;
+        im[r] = 0.f;
+    }
+    __syncthreads();
+    for (int s = 1; s <= logn; ++s) {
+        const int half = 1 << (s - 1);
+        for (int k = threadIdx.x; k < (nfft >> 1); k += blockDim.x) {
+            const int grp = k / half, pos = k - grp * half;
+            const int i0 = grp * (half << 1) + pos, i1 = i0 + half;
+            float sn, cs;
+            sincosf(-kPi * (float)pos / (float)half, &sn, &cs);
+            const float tr = re[i1] * cs - im[i1] * sn, ti = re[i1] * sn + im[i1] * cs;
+            const float ur = re[i0], ui = im[i0];
+            re[i0] = ur + tr; im[i0] = ui + ti;
+            re[i1] = ur - tr; im[i1] = ui - ti;
+        }
+        __syncthreads();
+    }
+    const int nbins = (nfft >> 1) + 1;
+    const size_t frame = (size_t)b * Fmax + f;
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const float p = (re[k] * re[k] + im[k] * im[k]) / (float)nfft;
+        ps[k] = p;
+        if (pspec_out) pspec_out[frame * nbins + k] = p;
+    }
+    if (logmel_out) {
+        __syncthreads();
+        for (int m = threadIdx.x; m < nfilt; m += blockDim.x) {
+            const float* w = fbank + (size_t)m * nbins;
+            float acc = 0.f;
+            for (int k = 0; k < nbins; ++k) acc += ps[k] * w[k];
+            if (acc == 0.f) acc = 2.220446049250313e-16f;          // np.finfo(float).eps (asr/fft.py:64)
+            logmel_out[frame * nfilt + m] = logf(acc);
+        }
+    }
+}
+
+// log(pspec . fbank^T) for a caller-supplied power spectrum (F, nbins) -> (F, nfilt)
+__global__ void logmel_kernel(const float* __restrict__ pspec, const float* __restrict__ fbank, long long F, int nbins,
+                              int nfilt, float* __restrict__ out) {
+    const long long n = F * nfilt;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / nfilt;
+        const int m = (int)(i - f * nfilt);
+        const float* p = pspec + f * nbins;
+        const float* w = fbank + (size_t)m * nbins;
+        float acc = 0.f;
+        for (int k = 0; k < nbins; ++k) acc += p[k] * w[k];
+        if (acc == 0.f) acc = 2.220446049250313e-16f;
+        out[i] = logf(acc);
+    }
+}
+
+// x[b][c][m][t] for c = static, delta, delta-delta; t < nframes[b] - 2, zero beyond; optional (x - mean) / std
+__global__ void deltas_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes, int Fmax, int nfilt,
+                              int Tmax, const float* __restrict__ mean, const float* __restrict__ stdv,
+                              float* __restrict__ out, int B) {
+    const long long n = (long long)B * nfilt * Tmax;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i % Tmax);
+        const int m = (int)((i / Tmax) % nfilt);
+        const int b = (int)(i / ((long long)Tmax * nfilt));
+        const int F = nframes[b];
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (t < F - 2) {
+            const float* lm = logmel + (size_t)b * Fmax * nfilt + m;
+            auto at = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return lm[(size_t)q * nfilt]; };
+            auto dl = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return (at(q + 1) - at(q - 1)) * 0.5f; };
+            v0 = at(t);
+            v1 = dl(t);
+            v2 = (dl(t + 1) - dl(t - 1)) * 0.5f;
+        }
+        if (mean) {     // the reference normalises the zero padding as well (asr/data/loaders/base.py:24)
+            v0 = (v0 - mean[m]) / stdv[m];
+            v1 = (v1 - mean[nfilt + m]) / stdv[nfilt + m];
+            v2 = (v2 - mean[2 * nfilt + m]) / stdv[2 * nfilt + m];
+        }
+        float* o = out + ((size_t)b * 3 * nfilt + m) * Tmax + t;
+        o[0] = v0;
+        o[(size_t)nfilt * Tmax] = v1;
+        o[(size_t)2 * nfilt * Tmax] = v2;
+    }
+}
+
+}  // namespace fbank
+}  // namespace asr
+
+using namespace asr;
+using namespace asr::fbank;
+
+extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch,
+                            int B, int frame_len, int frame_step, int nfft, float preemph, const float* window,
+                            const int32_t* nframes, int Fmax, float* pspec_out, const float* fbank, int nfilt,
+                            float* logmel_out) {
+    if (!signals || !lengths || !window || !nframes || B <= 0 || Fmax <= 0 || frame_step <= 0) return ASR_ERR_BAD_ARG;
+    if (!pspec_out && !logmel_out) return ASR_ERR_BAD_ARG;
+    if (logmel_out && (!fbank || nfilt <= 0)) return ASR_ERR_BAD_ARG;
+    int logn = 0;
+    while ((1 << logn) < nfft) ++logn;
+    if ((1 << logn) != nfft || nfft > kMaxFft || nfft < 64 || frame_len > nfft || frame_len <= 0) return ASR_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(Fmax, B), block(256);
+    if (sig_is_f32)
+        hipLaunchKernelGGL(specgram_kernel<float>, grid, block, 0, s, (const float*)signals, lengths, sig_pitch, frame_len,
+                           frame_step, nfft, logn, preemph, window, nframes, Fmax, pspec_out, fbank, nfilt, logmel_out);
+    else
+        hipLaunchKernelGGL(specgram_kernel<short>, grid, block, 0, s, (const short*)signals, lengths, sig_pitch, frame_len,
+                           frame_step, nfft, logn, preemph, window, nframes, Fmax, pspec_out, fbank, nfilt, logmel_out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_logmel(void* stream, const float* pspec, const float* fbank, long long F, int nbins, int nfilt,
+                          float* out) {
+    if (!pspec || !fbank || !out || F <= 0 || nbins <= 0 || nfilt <= 0) return ASR_ERR_BAD_ARG;
+    long long g = (F * nfilt + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pspec, fbank, F, nbins, nfilt, out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B, int Fmax, int nfilt, int Tmax,
+                          const float* mean, const float* stdv, float* out) {
+    if (!logmel || !nframes || !out || B <= 0 || Fmax <= 0 || nfilt <= 0 || Tmax <= 0) return ASR_ERR_BAD_ARG;
+    if ((mean == nullptr) != (stdv == nullptr)) return ASR_ERR_BAD_ARG;
+    long long g = ((long long)B * nfilt * Tmax + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(deltas_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, logmel, nframes, Fmax, nfilt, Tmax,
+                       mean, stdv, out, B);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

@@ -156,3 +156,103 @@ extern "C" int asr_layernorm_bwd(void* stream, const void* x, int x_bf16, const 
     if (dy_bf16) return launch_bwd<float, uint16_t>(s, x, dy, gamma, mean, rstd, dx, dx_bf16, dgamma, dbeta, rows, D, C);
     return launch_bwd<float, float>(s, x, dy, gamma, mean, rstd, dx, dx_bf16, dgamma, dbeta, rows, D, C);
 }
+
+// ------------------------------------------------------------------------------------------------ weight normalisation
+// asr/nn/convolution_2d.py:21-25,62-64: W = g * V / (||V|| + 1e-9), norm over everything but the output channel.
+// One workgroup per output channel (rows of K = Ci*kh*kw floats).
+namespace asr {
+namespace wn {
+
+__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ V, const float* __restrict__ g,
+                                                  float* __restrict__ W, float* __restrict__ norm_out, int K) {
+    __shared__ float scratch[32];
+    const int co = blockIdx.x;
+    const float* v = V + (size_t)co * K;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) s += v[i] * v[i];
+    const float norm = sqrtf(block_sum(s, scratch)) + 1e-9f;
+    if (threadIdx.x == 0) norm_out[co] = norm;
+    const float sc = g[co] / norm;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) W[(size_t)co * K + i] = v[i] * sc;
+}
+// asr/nn/convolution_2d.py:92-93: gg = sum(gW * Vn), gV = g * (gW - gg * Vn) / norm   (accumulated)
+__global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ gW, const float* __restrict__ V,
+                                                  const float* __restrict__ g, const float* __restrict__ norm,
+                                                  float* __restrict__ gV, float* __restrict__ gg, int K) {
+    __shared__ float scratch[32];
+    const int co = blockIdx.x;
+    const float nr = norm[co], gc = g[co];
+    const float* v = V + (size_t)co * K;
+    const float* w = gW + (size_t)co * K;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) s += w[i] * v[i] / nr;
+    const float ggc = block_sum(s, scratch);
+    if (threadIdx.x == 0) gg[co] += ggc;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) gV[(size_t)co * K + i] += gc * (w[i] - ggc * v[i] / nr) / nr;
+}
+// per-channel mean and (population) standard deviation of x (rows, C) f32: data-dependent init (:152-167)
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long long rows, int C,
+                                                            float* __restrict__ mean, float* __restrict__ stdv) {
+    __shared__ float scratch[32];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (long long r = threadIdx.x; r < rows; r += blockDim.x) s += x[r * C + c];
+    const float m = block_sum(s, scratch) / (float)rows;
+    float v = 0.f;
+    for (long long r = threadIdx.x; r < rows; r += blockDim.x) { const float d = x[r * C + c] - m; v += d * d; }
+    const float var = block_sum(v, scratch) / (float)rows;
+    if (threadIdx.x == 0) { mean[c] = m; stdv[c] = sqrtf(var); }
+}
+// y = x * scale[c] + shift[c]  (f32 in, bf16 out)
+__global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, uint16_t* __restrict__ y, long long n, int C) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        y[i] = f32_to_bf16(x[i] * scale[c] + shift[c]);
+    }
+}
+// g = 1 / std, b = -mean / std
+__global__ void init_kernel(const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ g,
+                            float* __restrict__ b, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { g[c] = 1.f / stdv[c]; b[c] = -mean[c] / stdv[c]; }
+}
+
+}  // namespace wn
+}  // namespace asr
+
+extern "C" int asr_weightnorm_fwd(void* stream, const float* V, const float* g, float* W, float* norm, int Co, int K) {
+    if (!V || !g || !W || !norm || Co <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(asr::wn::fwd_kernel, dim3(Co), dim3(256), 0, (hipStream_t)stream, V, g, W, norm, K);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_weightnorm_bwd(void* stream, const float* gW, const float* V, const float* g, const float* norm,
+                                  float* gV, float* gg, int Co, int K) {
+    if (!gW || !V || !g || !norm || !gV || !gg || Co <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(asr::wn::bwd_kernel, dim3(Co), dim3(256), 0, (hipStream_t)stream, gW, V, g, norm, gV, gg, K);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_channel_stats(void* stream, const float* x, long long rows, int C, float* mean, float* stdv) {
+    if (!x || !mean || !stdv || rows <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(asr::wn::channel_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, rows, C, mean, stdv);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_channel_affine(void* stream, const float* x, const float* scale, const float* shift, void* y_bf16,
+                                  long long n, int C) {
+    if (!x || !scale || !shift || !y_bf16 || n <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    long long gsz = (n + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(asr::wn::channel_affine_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       (uint16_t*)y_bf16, n, C);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, float* g, float* b, int C) {
+    if (!mean || !stdv || !g || !b || C <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(asr::wn::init_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, stdv, g, b, C);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

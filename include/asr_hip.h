@@ -45,6 +45,25 @@ int asr_ctc_loss_grad(void* stream, const float* xs, const int32_t* label_unigra
                       const int32_t* x_len, const int32_t* l_len, int T, int B, int V, int Lmax, int blank, float scale,
                       float* loss_per_utt, float* loss_mean, float* grad, void* workspace, size_t workspace_bytes);
 
+/* ---------------------------------------------------------------------------------------- log-mel features
+ * Replace fft.get_specgram / compute_logmel / compute_deltas (asr/fft.py:52-66, 6-19, 90-99), the per-utterance loop of
+ * Processor.extract_batch_features (asr/data/processing.py:67-111) and the Loader's normalisation
+ * (asr/data/loaders/base.py:22-24), batched over utterances.
+ *   asr_specgram  signals (B, sig_pitch) int16 or f32, lengths (B); frame f of utterance b covers samples
+ *                 [f*frame_step, f*frame_step+frame_len) zero padded, pre-emphasised, times window (frame_len);
+ *                 nframes (B) frames are produced per utterance (grid is Fmax x B).  Writes the power spectrum
+ *                 (B, Fmax, nfft/2+1) and/or log(pspec . fbank^T) (B, Fmax, nfilt); nfft a power of two <= 1024.
+ *   asr_logmel    log-mel of a caller-supplied power spectrum (F, nbins) with fbank (nfilt, nbins)
+ *   asr_deltas    (B, Fmax, nfilt) log-mel -> the minibatch x (B, 3, nfilt, Tmax) f32: static / delta / delta-delta,
+ *                 T_b = nframes[b] - 2 frames, zero beyond; mean/std (3, nfilt) optional
+ */
+int asr_specgram(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch, int B,
+                 int frame_len, int frame_step, int nfft, float preemph, const float* window, const int32_t* nframes,
+                 int Fmax, float* pspec_out, const float* fbank, int nfilt, float* logmel_out);
+int asr_logmel(void* stream, const float* pspec, const float* fbank, long long F, int nbins, int nfilt, float* out);
+int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B, int Fmax, int nfilt, int Tmax,
+               const float* mean, const float* stdv, float* out);
+
 /* ---------------------------------------------------------------------------------------- dense projections
  * bf16 MFMA GEMMs (f32 accumulate).  Replace the BLAS/cuDNN calls behind chainer.links.Linear, the 1x1
  * ConvolutionND of asr/nn/convolution_1d.py:7-38, the SRU projection asr/nn/sru.py:340-341,421-429 and -- through
@@ -107,6 +126,17 @@ int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* y, int y_bf
 int asr_layernorm_bwd(void* stream, const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma,
                       const float* mean, const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta,
                       long long rows, int D, int C);
+
+/* weight normalisation of asr/nn/convolution_2d.py: W = g V / (||V|| + 1e-9) per output channel (:21-25,62-64), its
+ * gradient (:92-93, accumulated into gV / gg), and the data-dependent initialisation g = 1/std_t, b = -mean_t/std_t
+ * from the first batch's g=1 output (:152-167,177-187). */
+int asr_weightnorm_fwd(void* stream, const float* V, const float* g, float* W, float* norm, int Co, int K);
+int asr_weightnorm_bwd(void* stream, const float* gW, const float* V, const float* g, const float* norm, float* gV,
+                       float* gg, int Co, int K);
+int asr_channel_stats(void* stream, const float* x, long long rows, int C, float* mean, float* stdv);
+int asr_channel_affine(void* stream, const float* x, const float* scale, const float* shift, void* y_bf16, long long n,
+                       int C);
+int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, float* g, float* b, int C);
 
 /* ---------------------------------------------------------------------------------------- (Bi)GRU recurrence
  * nn.GRU / nn.NStepBiGRU reach the reference API through `from chainer.links import *` (asr/nn/nn.py:3); gate

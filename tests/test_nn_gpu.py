@@ -1,0 +1,238 @@
+"""asr.nn / asr.fft operators on the HIP path against the CPU oracle (reference layouts in, reference layouts out)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fft as offt
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _bf(t):
+    return t.to(BF16).to(F32)
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------------ features
+def test_logfbank_batch_matches_oracle(device):
+    from asr import fft
+    rs = np.random.RandomState(0)
+    sigs = [np.round(rs.randn(n) * 3000).astype(np.int16) for n in (16000, 9000, 12345, 700)]
+    proc = fft.Processor(device=device)
+    x, xl = proc.logfbank_batch(sigs)
+    xr, xlr = offt.logfbank_minibatch(sigs)
+    assert x.shape == xr.shape and x.dtype == F32
+    assert np.array_equal(xl.cpu().numpy(), xlr)
+    np.testing.assert_allclose(x.cpu().numpy(), xr, rtol=0, atol=2e-4)          # log-mel ~ 13 +- 1, f32 FFT vs f64
+    mean = rs.randn(3, 40).astype(np.float32)
+    std = (rs.rand(3, 40) + 0.5).astype(np.float32)
+    xn, _ = proc.logfbank_batch(sigs, mean, std)
+    xrn, _ = offt.logfbank_minibatch(sigs, mean=mean, std=std)
+    np.testing.assert_allclose(xn.cpu().numpy(), xrn, rtol=0, atol=5e-4)
+
+
+def test_fft_functions_match_reference_goldens(device, golden_dir):
+    """the reference's own outputs (asr/fft.py on a seeded power spectrum) through the device functions"""
+    from asr import fft
+    g = np.load(os.path.join(golden_dir, "fft.npz"))
+    assert np.array_equal(fft.get_filterbanks(40, 512, 16000), g["fbank"])
+    pspec = torch.tensor(g["pspec"], dtype=F32, device=device)
+    lm = fft.compute_logmel(pspec, 16000, fbank=g["fbank"], nfft=512, nfilt=40)
+    np.testing.assert_allclose(lm.cpu().numpy(), g["logmel_full"], atol=2e-5)
+    a, d, dd = fft.compute_deltas(lm)
+    np.testing.assert_allclose(a.cpu().numpy(), g["logmel"], atol=2e-5)
+    np.testing.assert_allclose(d.cpu().numpy(), g["delta"], atol=2e-5)
+    np.testing.assert_allclose(dd.cpu().numpy(), g["delta_delta"], atol=2e-5)
+    np.testing.assert_allclose(fft.compute_delta(lm).cpu().numpy(), offt.compute_delta(g["logmel_full"]), atol=2e-5)
+    sig = np.round(np.random.RandomState(3).randn(4000) * 2000).astype(np.int16)
+    ps = fft.get_specgram(torch.tensor(sig, device=device), 16000, 0.032, 0.01, 512, 0.97, np.hanning)
+    ref = offt.get_specgram(sig, 16000, 0.032, 0.01, 512, 0.97, np.hanning)
+    np.testing.assert_allclose(ps.cpu().numpy(), ref, rtol=2e-4, atol=ref.max() * 1e-6)
+
+
+def test_full_size_feature_batch(device):
+    """BASELINE shape: 160672 samples -> 1002 frames -> T = 1000."""
+    from asr import fft
+    rs = np.random.RandomState(1)
+    sigs = [np.round(rs.randn(160672) * 3000).astype(np.int16) for _ in range(4)]
+    x, xl = fft.Processor(device=device).logfbank_batch(sigs)
+    assert x.shape == (4, 3, 40, 1000) and (xl.cpu().numpy() == 1000).all()
+    xr, _ = offt.logfbank_minibatch(sigs[:1])
+    np.testing.assert_allclose(x[0].cpu().numpy(), xr[0], atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------ SRU
+@pytest.mark.parametrize("name", ["tanh", "linear"])
+def test_sru_forward_golden(device, golden_dir, name):
+    """reference forward_cpu outputs (asr/nn/sru.py:289-324) through nn.sru on the GPU"""
+    from asr.nn.sru import sru
+    from asr.link import Parameter
+    g = np.load(os.path.join(golden_dir, "sru.npz"))
+    X, W, B, c0 = (torch.tensor(g["%s.%s" % (name, k)]) for k in ("X", "W", "B", "c0"))
+    H, C, cT = sru(X.to(device), Parameter(W.to(device)), Parameter(B.to(device)), c0.to(device), bool(g[name + ".use_tanh"]))
+    assert H.shape == X.shape
+    # bf16 operands in the projection: compare against the oracle fed with bf16-rounded X and W, and loosely with the golden
+    Hr, Cr, cTr = onn.sru_fwd(_bf(X).double().numpy(), _bf(W).double().numpy(), B.double().numpy(), c0.double().numpy(),
+                              bool(g[name + ".use_tanh"]))
+    assert _rel(C.cpu(), Cr) < 2e-5 and _rel(cT.cpu(), cTr) < 2e-5
+    assert _rel(H.float().cpu(), Hr) < 5e-3
+    assert _rel(H.float().cpu(), g[name + ".H"]) < 2e-2
+
+
+@pytest.mark.parametrize("use_tanh,masked", [(True, False), (False, False), (True, True)])
+def test_sru_forward_backward(device, use_tanh, masked):
+    from asr.nn.sru import sru
+    from asr.link import Parameter
+    torch.manual_seed(0)
+    Bn, D, T = 3, 64, 17
+    X = _bf(torch.randn(Bn, D, T))
+    W = _bf(torch.randn(3 * D, D) * 0.2)
+    Bias = torch.randn(2 * D) * 0.3
+    c0 = torch.randn(Bn, D)
+    mask = (torch.rand(Bn, D) > 0.3).float() if masked else None
+    gH = _bf(torch.randn(Bn, D, T))
+    gcT = torch.randn(Bn, D)
+    Xd = X.to(device).requires_grad_(True)
+    Wp, Bp = Parameter(W.to(device)), Parameter(Bias.to(device))
+    c0d = c0.to(device).requires_grad_(True)
+    H, C, cT = sru(Xd, Wp, Bp, c0d, use_tanh, None if mask is None else mask.to(device))
+    ((H.float() * gH.to(device)).sum() + (cT * gcT.to(device)).sum()).backward()
+    Xm = X if mask is None else X * mask[..., None]        # GPU semantics: the projection sees the masked input (sru.py:336-341)
+    Hr, Cr, cTr = onn.sru_fwd(Xm.double().numpy(), W.double().numpy(), Bias.double().numpy(), c0.double().numpy(), use_tanh)
+    assert _rel(H.float().cpu(), Hr) < 5e-3 and _rel(cT.cpu(), cTr) < 1e-4
+    gX, gW, gb, gc = onn.sru_bwd(Xm.double().numpy(), W.double().numpy(), Bias.double().numpy(), c0.double().numpy(),
+                                 gH.double().numpy(), gcT.double().numpy(), use_tanh)
+    if mask is not None:
+        gX = gX * mask[..., None].numpy()
+    assert _rel(Xd.grad.float().cpu(), gX) < 1e-2
+    assert _rel(Wp.grad.cpu(), gW) < 1e-2
+    assert _rel(Bp.grad.cpu(), gb) < 1e-2
+    assert _rel(c0d.grad.cpu(), gc) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ layers
+def _img(B, C, H, T, seed=0):
+    return _bf(torch.randn(B, C, H, T, generator=torch.Generator().manual_seed(seed)))
+
+
+@pytest.mark.parametrize("kind", ["relu", "clipped_relu", "leaky_relu", "elu", "sigmoid", "tanh", "hard_sigmoid", "softplus"])
+def test_activations(device, kind):
+    import asr.nn as nn
+    x = _img(2, 6, 5, 7) * 3
+    layer = {"relu": nn.ReLU(), "clipped_relu": nn.ClippedReLU(2.0), "leaky_relu": nn.LeakyReLU(0.1), "elu": nn.ELU(0.7),
+             "sigmoid": nn.Sigmoid(), "tanh": nn.Tanh(), "hard_sigmoid": nn.HardSigmoid(), "softplus": nn.Softplus(1.5)}[kind]
+    F = torch.nn.functional
+    ref = {"relu": F.relu, "clipped_relu": lambda t: t.clamp(0, 2.0), "leaky_relu": lambda t: F.leaky_relu(t, 0.1),
+           "elu": lambda t: F.elu(t, 0.7), "sigmoid": torch.sigmoid, "tanh": torch.tanh,
+           "hard_sigmoid": lambda t: (0.2 * t + 0.5).clamp(0, 1), "softplus": lambda t: F.softplus(t, 1.5)}[kind]
+    xd = x.to(device).requires_grad_(True)
+    y = layer(xd)
+    gy = _img(2, 6, 5, 7, 1)
+    y.float().backward(gy.to(device))
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gy)
+    assert y.shape == x.shape
+    assert _rel(y.float().cpu(), yr.detach()) < 6e-3
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-2
+
+
+def test_glu_dropout_residual_linear(device):
+    import asr.nn as nn
+    from asr import functions as F
+    x = _img(2, 8, 5, 9)
+    xd = x.to(device).requires_grad_(True)
+    y = F.glu(xd)
+    a, b = x[:, :4], x[:, 4:]
+    assert y.shape == (2, 4, 5, 9) and _rel(y.float().cpu(), a * torch.sigmoid(b)) < 6e-3
+    y.float().sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (xr[:, :4] * torch.sigmoid(xr[:, 4:])).sum().backward()
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-2
+    # dropout: scaled Bernoulli mask, identical mask in backward, identity at ratio 0 and in eval mode
+    d = nn.Dropout(0.4)
+    xd2 = (torch.ones(4, 8, 6, 50) * 2).to(device).requires_grad_(True)
+    yd = d(xd2)
+    kept = (yd != 0).float().mean().item()
+    assert abs(kept - 0.6) < 0.03 and torch.allclose(yd[yd != 0].float(), torch.tensor(2 / 0.6, device=device), rtol=1e-2)
+    yd.float().sum().backward()
+    assert torch.equal(xd2.grad != 0, yd != 0)
+    assert nn.Dropout(0)(xd2) is xd2
+    F.train_mode[0] = False
+    assert d(xd2) is xd2
+    F.train_mode[0] = True
+    # residual: y = layer(x) + x  (asr/nn/nn.py:322-328)
+    s = nn.Stream(nn.Residual(nn.ReLU()))
+    ys = s(x.to(device))
+    assert _rel(ys.float().cpu(), torch.relu(x) + x) < 6e-3
+    # linear
+    torch.manual_seed(1)
+    lin = nn.Linear(16, 24).to_gpu()
+    v = _bf(torch.randn(10, 16))
+    out = lin(v.to(device))
+    assert _rel(out.float().cpu(), v @ _bf(lin.W.detach().cpu()).T + lin.b.detach().cpu()) < 6e-3
+
+
+def test_layernorm_3d_joint_statistics(device):
+    """(B, V, T) input: the reference normalises over V and T jointly (axes 1, 2) -- asr/nn/layernorm.py:42-45."""
+    import asr.nn as nn
+    rs = np.random.RandomState(5)
+    x = rs.uniform(-3, 3, (3, 10, 7)).astype(np.float32)
+    ln = nn.LayerNormalization(10).to_gpu()
+    ln.output_float32 = True
+    with torch.no_grad():
+        ln.gamma.copy_(torch.tensor(rs.uniform(0.5, 1.5, 10).astype(np.float32)))
+        ln.beta.copy_(torch.tensor(rs.uniform(-1, 1, 10).astype(np.float32)))
+    y = ln(torch.tensor(x).to(device))
+    yr, _ = onn.layer_normalization(_bf(torch.tensor(x)).double().numpy(), ln.gamma.detach().cpu().double().numpy(),
+                                    ln.beta.detach().cpu().double().numpy())
+    assert y.shape == (3, 10, 7)
+    np.testing.assert_allclose(y.cpu().numpy(), yr, rtol=1e-3, atol=1e-3)
+
+
+def test_weightnorm_convolution(device):
+    """first call = data-dependent init returning the normalised output; later calls use W = g V / ||V||
+    (asr/nn/convolution_2d.py:152-187), gradients w.r.t. V, g, b against torch autograd of the same formula."""
+    import asr.nn as nn
+    torch.manual_seed(0)
+    conv = nn.Convolution2D(4, 6, (3, 5), pad=(1, 4), weightnorm=True).to_gpu()
+    x = _img(3, 4, 7, 20, 2)
+    y0 = conv(x.to(device))[..., :-4]
+    V = conv.V.detach().cpu()
+    Vn = V / (V.pow(2).sum(dim=(1, 2, 3), keepdim=True).sqrt() + 1e-9)
+    t = onn.conv2d_causal(x, _bf(Vn), None, 1)
+    tfull = torch.nn.functional.conv2d(x, _bf(Vn), None, padding=(1, 4))          # statistics are taken over the padded output
+    mean, std = tfull.mean(dim=(0, 2, 3)), tfull.var(dim=(0, 2, 3), unbiased=False).sqrt()
+    assert _rel(conv.g.detach().cpu().reshape(-1), 1 / std) < 5e-3
+    assert _rel(conv.b.detach().cpu(), -mean / std) < 2e-2
+    assert _rel(y0.float().cpu(), (t - mean[None, :, None, None]) / std[None, :, None, None]) < 1e-2
+    y1 = conv(x.to(device))[..., :-4]
+    assert _rel(y1.float().cpu(), y0.float().cpu()) < 1e-2          # second call reproduces the initialised output
+    gy = _img(3, 6, 7, 20, 3)
+    y1.float().backward(gy.to(device))
+    Vr = V.clone().requires_grad_(True)
+    gr = conv.g.detach().cpu().clone().requires_grad_(True)
+    br = conv.b.detach().cpu().clone().requires_grad_(True)
+    Wr = gr * Vr / (Vr.pow(2).sum(dim=(1, 2, 3), keepdim=True).sqrt() + 1e-9)
+    onn.conv2d_causal(x, Wr, br, 1).backward(gy)
+    assert _rel(conv.V.grad.cpu(), Vr.grad) < 3e-2
+    assert _rel(conv.g.grad.cpu(), gr.grad) < 3e-2
+    assert _rel(conv.b.grad.cpu(), br.grad) < 1e-2
+
+
+def test_generic_layout_entry(device):
+    """ops accept tensors in the reference's plain (B, C, H, T) float32 layout and convert once"""
+    import asr.nn as nn
+    x = _img(2, 8, 6, 11)
+    y = nn.Maxout(2)(x.to(device))
+    assert _rel(y.float().cpu(), onn.maxout2(x)) == 0
+    y = nn.MaxPooling2D(ksize=(2, 1))(x.to(device))
+    assert _rel(y.float().cpu(), onn.maxpool_h(x, 2)) == 0
