@@ -17,6 +17,7 @@ class SRUFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, Bias, c0, mask, w16, w16t, use_tanh):
+        ctx.set_materialize_grads(False)
         T, Bn, D = x.shape
         xm = x if mask is None else _ops.sru_combine(x, None, mask)
         U = _ops.gemm_nt(xm.reshape(T * Bn, D), w16, None, F32)                  # asr/nn/sru.py:340-341
@@ -49,8 +50,6 @@ def sru(x, W, B, initial_ct, use_tanh=True, mask_x=None, link=None):
     """x (B, D, T) -> (H (B, D, T), C (B, D, T), c_T (B, D))   (asr/nn/sru.py:435-439)."""
     link = link if link is not None else _DEFAULT_LINK
     p = functions.phys3(x)
-    if W.shape[1] % 8:
-        raise ValueError("SRU width must be a multiple of 8")
     w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w))
     w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w, transpose=True))
     H, C, cT = SRUFunction.apply(p, W, B, initial_ct, mask_x, w16, w16t, bool(use_tanh))

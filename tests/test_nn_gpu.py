@@ -195,7 +195,7 @@ def test_layernorm_3d_joint_statistics(device):
     yr, _ = onn.layer_normalization(_bf(torch.tensor(x)).double().numpy(), ln.gamma.detach().cpu().double().numpy(),
                                     ln.beta.detach().cpu().double().numpy())
     assert y.shape == (3, 10, 7)
-    np.testing.assert_allclose(y.cpu().numpy(), yr, rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr, rtol=1e-3, atol=1e-3)
 
 
 def test_weightnorm_convolution(device):
