@@ -1,0 +1,138 @@
+"""Host-side logic of the drop-in API that needs no GPU: structure, naming, configuration, optimiser bookkeeping."""
+import json
+import os
+
+import pytest
+import torch
+
+
+def test_stream_and_module_register_links_with_reference_names():
+    """parameter names follow asr/nn/nn.py:304-320 (layer_%d, layer_%d_%d) and :341-392 (_sequential_%d...)."""
+    import asr.nn as nn
+    s = nn.Stream()
+    s.layer(nn.Convolution2D(3, 8, (3, 5), pad=(0, 4)), lambda x: x[..., :-4], nn.Maxout(2))
+    s.layer(nn.Residual(nn.Convolution2D(4, 8, (3, 5), pad=(1, 4)), nn.Maxout(2)))
+    s.layer(nn.GLU(4, 4), nn.LayerNormalization(4))
+    names = [n for n, _ in s.namedparams()]
+    assert "/layer_0/W" in names and "/layer_0/b" in names
+    assert "/layer_3_0/W" in names                       # Residual at index 3, conv is its element 0
+    assert "/layer_4/W" in names                          # GLU registers its conv
+    assert "/layer_5/gamma" in names and "/layer_5/beta" in names
+    assert len(s.layers) == 6
+    m = nn.Module()
+    m.add(nn.Convolution1D(8, 16), nn.Maxout(2))
+    m.add(nn.SRU(8), nn.Dropout(0))
+    assert [n for n, _ in m.namedparams()] == ["/_sequential_0/W", "/_sequential_0/b", "/_sequential_2/W", "/_sequential_2/B"]
+    assert len(m.blocks) == 2 and len(m.blocks[1]) == 2
+    outer = nn.Module()
+    outer.inner = m
+    assert m._locked and any(n.startswith("/inner/") for n, _ in outer.namedparams())
+    with pytest.raises(AssertionError):
+        m.extra = nn.Convolution1D(4, 4)                 # owned module refuses new links (asr/nn/nn.py:363)
+
+
+def test_parameter_shapes_and_lazy_initialisation():
+    import asr.nn as nn
+    c = nn.Convolution2D(3, 16, (3, 5), pad=(0, 4))
+    assert tuple(c.W.shape) == (16, 3, 3, 5) and tuple(c.b.shape) == (16,)
+    assert float(c.b.abs().sum()) == 0.0
+    assert nn.Convolution1D(None, 32).W.numel() == 0      # sized at first call (asr/nn/convolution_1d.py:33-35)
+    assert nn.LayerNormalization(None).gamma.numel() == 0
+    ln = nn.LayerNormalization(7)
+    assert torch.equal(ln.gamma.data, torch.ones(7)) and torch.equal(ln.beta.data, torch.zeros(7))
+    sru = nn.SRU(12)
+    assert tuple(sru.W.shape) == (36, 12) and tuple(sru.B.shape) == (24,)      # asr/nn/sru.py:455-458
+    gru = nn.BiGRU(20, 32)
+    assert tuple(gru.w_ih.shape) == (2, 96, 20) and tuple(gru.w_hh.shape) == (2, 96, 32)
+    wn = nn.Convolution2D(3, 8, (3, 5), pad=(0, 4), weightnorm=True)
+    assert tuple(wn.V.shape) == (8, 3, 3, 5) and wn.g.numel() == 0             # g, b come from the first batch
+
+
+def test_initialisers_follow_the_reference_recipes():
+    import math
+    from asr.link import HeNormal, LeCunNormal, Normal
+    torch.manual_seed(0)
+    w = Normal(math.sqrt(1.0 / 128 / 3 / 5))((256, 128, 3, 5))          # run/ctc/cnn/model.py:162
+    assert abs(w.std().item() - math.sqrt(1.0 / 1920)) < 2e-4
+    w = LeCunNormal()((64, 100))
+    assert abs(w.std().item() - 0.1) < 5e-3
+    w = HeNormal(1.0)((64, 200))
+    assert abs(w.std().item() - 0.1) < 5e-3
+
+
+def test_configuration_roundtrip(tmp_path):
+    from asr.model import cnn, sru, ds2
+    c = cnn.configure()
+    assert (c.ndim_h, c.ndim_dense, c.num_conv_layers, c.architecture, c.num_mel_filters) == (128, 256, 5, "zhang", 40)
+    with pytest.raises(AssertionError):
+        c.save(str(tmp_path / "c.json"))                    # vocab_size must be set (asr/model/cnn.py:22-24)
+    c.vocab_size = 119
+    c.kernel_size = (3, 5)
+    c.save(str(tmp_path / "c.json"))
+    d = json.load(open(tmp_path / "c.json"))
+    assert d["vocab_size"] == 119 and d["frame_width"] == 0.032 and d["bucket_split_sec"] == 0.5
+    c2 = cnn.configure()
+    assert c2.load(str(tmp_path / "c.json")) is True and c2.vocab_size == 119 and tuple(c2.kernel_size) == (3, 5)
+    assert c2.load(str(tmp_path / "missing.json")) is None
+    assert sru.configure().num_rnn_layers == 2 and ds2.configure().ndim_rnn == 512
+
+
+def test_optimizer_factory_and_learning_rate_helpers():
+    """asr/optimizers.py:3-75"""
+    from asr import optimizers as O
+    adam = O.get_optimizer("adam", 1e-3, 0.9)
+    assert isinstance(adam, O.Adam) and adam.alpha == 1e-3 and adam.beta1 == 0.9 and adam.beta2 == 0.999 and adam.eps == 1e-8
+    assert isinstance(O.get_optimizer("sgd", 0.1, 0.9), O.SGD)
+    assert O.get_optimizer("msgd", 0.1, 0.8).momentum == 0.8 and isinstance(O.get_optimizer("nesterov", 0.1, 0.9), O.NesterovAG)
+    with pytest.raises(NotImplementedError):
+        O.get_optimizer("rmsprop", 0.1, 0.9)
+    assert O.get_learning_rate(adam) == 1e-3
+    O.decay_learning_rate(adam, 0.5, 1e-6)
+    assert adam.alpha == 5e-4
+    O.set_learning_rate(adam, 1e-6)
+    assert O.decay_learning_rate(adam, 0.5, 1e-6) == 1e-6 and adam.alpha == 1e-6       # floor (asr/optimizers.py:70-72)
+    O.set_momentum(adam, 0.5)
+    assert adam.beta1 == 0.5
+    adam.add_hook(O.GradientClipping(1))
+    adam.add_hook(O.WeightDecay(1e-5))
+    assert [h.name for h in adam._hooks] == ["GradientClipping", "WeightDecay"]
+
+
+def test_views_cost_nothing_and_keep_reference_semantics():
+    from asr import functions as F
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    assert F.swapaxes(x, 1, 3).shape == (2, 5, 4, 3) and F.swapaxes(x, 1, 3).data_ptr() == x.data_ptr()
+    parts = F.split_axis(x.reshape(2, 60), 5, axis=1)
+    assert len(parts) == 5 and parts[0].shape == (2, 12)
+    assert F.squeeze(x[:, :, :1], axis=2).shape == (2, 3, 5)
+    assert F.expand_dims(x, 1).shape == (2, 1, 3, 4, 5)
+    assert F.reshape(x, (2, -1, 5)).shape == (2, 12, 5)
+    phys = torch.zeros(5, 2, 4, 3, dtype=torch.bfloat16)            # (T, B, H, C)
+    logical = phys.permute(1, 3, 2, 0)                                # (B, C, H, T) view
+    merged = F.reshape(logical, (2, -1, 5))
+    assert merged.shape == (2, 12, 5) and merged.data_ptr() == phys.data_ptr()       # no copy
+
+
+def test_ctc_argument_checks_match_reference():
+    """asr/loss/gram_ctc.py:224-227,301-308"""
+    from asr.loss import connectionist_temporal_classification, gram_ctc
+    x = torch.zeros(4, 2, 5)
+    t = torch.ones(2, 2, dtype=torch.int32)
+    with pytest.raises(TypeError):
+        gram_ctc(5, t, t, 0)
+    with pytest.raises(TypeError):
+        gram_ctc(x, t, t, 0.0)
+    with pytest.raises(ValueError):
+        connectionist_temporal_classification(x, t, 0, reduce="sum")
+    with pytest.raises(AssertionError):
+        connectionist_temporal_classification(x, t, 7)
+    with pytest.raises(AssertionError):
+        gram_ctc(x, t, torch.ones(2, 3, dtype=torch.int32), 0)
+
+
+def test_feature_host_constants():
+    from asr import fft
+    assert fft.num_frames(160672, 512, 160) == 1002
+    assert fft.num_frames(400, 512, 160) == 1 and fft.num_frames(513, 512, 160) == 2
+    fb = fft.get_filterbanks(40, 512, 16000)
+    assert fb.shape == (40, 257) and fb.sum() == pytest.approx(247.0)
