@@ -247,20 +247,24 @@ def main():
         breakdown = {k: {"ms": round(ms, 3), "calls": n} for k, (ms, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])}
         out["kernel_ms_per_step"] = breakdown
         H, nl = cfg.ndim_rnn, cfg.num_rnn_layers
-        # dominant kernel class: the GRU step kernels.  One launch = one time step of one layer, both directions.
+        # dominant kernel class: the persistent GRU kernels.  One launch = one layer, both directions, all T steps.
         gru_ms = tot["gru_fwd"][0] + tot["gru_bwd"][0]
-        launches = 2 * nl * T
+        launches = tot["gru_fwd"][1] + tot["gru_bwd"][1]
         per_launch_s = gru_ms * 1e-3 / launches
-        # algorithmic bytes of a forward step launch: W_hh bf16 (2 x 3H x H), gi f32 (B x 6H), h in bf16 + out f32/bf16,
-        # saved gates f32 (B x 2 x 4H); backward: W_hh^T, dgh in, gates in, dgi/dgh out
-        fwd_bytes = 2 * 3 * H * H * 2 + B * 6 * H * 4 + B * 2 * H * (2 + 4 + 2) + B * 2 * 4 * H * 4
-        bwd_bytes = 2 * 3 * H * H * 2 + B * 6 * H * 2 + B * 2 * 4 * H * 4 + B * H * 2 + 2 * B * 6 * H * 2 + B * 2 * H * 4 * 3
+        # algorithmic HBM bytes of a launch, per (t, b) row and both directions:
+        #   forward : gi f32 in (6H*4), h bf16 out + in again by the next step (2H*2*2), f32 state out (2H*4), gates out (8H*4)
+        #   backward: dy bf16 in (H*2), gates in (8H*4), f32 state in (2H*4), dgi out (6H*2), dgh out + in again (6H*2*2)
+        # plus the W_hh slice once per launch (2*3H*H*2)
+        fwd_bytes = T * B * (6 * H * 4 + 2 * H * 2 * 2 + 2 * H * 4 + 8 * H * 4) + 2 * 3 * H * H * 2
+        bwd_bytes = T * B * (H * 2 + 8 * H * 4 + 2 * H * 4 + 6 * H * 2 + 6 * H * 2 * 2) + 2 * 3 * H * H * 2
         alg = 0.5 * (fwd_bytes + bwd_bytes)
-        out["roofline"] = {"bound": "hbm", "kernel": "gru fwd_step_kernel / bwd_step_kernel (one launch per time step)",
+        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_kernel / bwd_persistent_kernel (one launch per layer)",
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
-                           "us_per_launch": per_launch_s * 1e6, "launches_per_step": launches,
-                           "note": "latency-bound recurrence: operands are L2-resident, neither roofline binds (DESIGN.md)"}
+                           "ms_per_launch": per_launch_s * 1e3, "launches_per_step": launches,
+                           "us_per_time_step": per_launch_s * 1e6 / T, "algorithmic_bytes_per_launch": alg,
+                           "note": "latency-bound recurrence (8000 dependent steps per train step): neither roofline binds, "
+                                   "see DESIGN.md section 5; HBM-bound CTC sweep and MFMA-bound GEMMs reported beside it"}
         ctc_bytes = 2.0 * T * B * V * 4
         ctc_ms = ctc["ctc_forward"] + ctc["ctc_grad"]
         out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,

@@ -56,7 +56,7 @@ SIGNATURES = {
     "asr_channel_affine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),
     "asr_weightnorm_init": (c_int, [c_void_p] * 5 + [c_int]),
     "asr_gru_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
-    "asr_gru_bwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p, c_int]),
+    "asr_gru_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_int]),
     "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4),
     "asr_sru_bwd": (c_int, [c_void_p] * 13 + [c_int] * 4),
     "asr_sru_combine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),

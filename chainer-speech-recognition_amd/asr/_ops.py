@@ -229,7 +229,7 @@ GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only
 
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
-    sync = torch.zeros(4, dtype=torch.int32, device=dev)
+    sync = torch.zeros(1024, dtype=torch.int32, device=dev)
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
@@ -247,18 +247,19 @@ LAST_SYNC = [None]
 def gru_check_sync():
     """(debug / tests) synchronise and raise if the last persistent GRU launch abandoned an in-launch wait"""
     s = LAST_SYNC[0]
-    if s is not None and int(s.cpu()[2]) != 0:
+    if s is not None and int(s.cpu()[1023]) != 0:
         raise _lib.AsrHipError("persistent GRU kernel timed out waiting for another workgroup")
 
 
-def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir):
+def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
+    """db_ih / db_hh: (ndir * 3H) f32 buffers the bias gradients are accumulated into (optional)."""
     dev = dy.device
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
-    sync = torch.zeros(4, dtype=torch.int32, device=dev)
+    sync = torch.zeros(1024, dtype=torch.int32, device=dev)
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
-                                ptr(carry), T, B, H, ndir, ptr(sync), GRU_MODE[0])
+                                ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_bwd")
     LAST_SYNC[0] = sync
     return dgi, dgh

@@ -449,10 +449,9 @@ class _GRU(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh = ctx.params
         T, B, H, ndir, need_dx = ctx.meta
         gy = gy.contiguous()
-        dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir)
+        dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir, grad_buffer(b_ih).reshape(-1),
+                                grad_buffer(b_hh).reshape(-1))
         _ops.gemm_tn_acc(dgi, x2, grad_buffer(w_ih).reshape(ndir * 3 * H, -1))
-        _ops.colsum_acc(dgi, grad_buffer(b_ih).reshape(-1))
-        _ops.colsum_acc(dgh, grad_buffer(b_hh).reshape(-1))
         gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
         if T > 1:
             for d in range(ndir):

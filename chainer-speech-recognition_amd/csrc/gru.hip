@@ -265,6 +265,7 @@ __device__ __forceinline__ bool wait_counter(unsigned* counter, unsigned target,
     unsigned spins = 0;
     for (;;) {
         if (__hip_atomic_load(counter, ASR_RLX_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
         ++spins;
         if ((spins & 63u) == 0u) {          // the abort word is looked at once per 64 polls: the poll itself stays one load
             if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nks = H >> 5;
     const size_t hs = (size_t)ndir * H;
-    unsigned* counter = sync + d;
-    unsigned* abort_word = sync + 2;
+    unsigned* counter = sync + d * 64;
+    unsigned* abort_word = sync + 1023;
     const __amdgpu_buffer_rsrc_t h16rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
 
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nks = (3 * H) >> 5;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + d;
-    unsigned* abort_word = sync + 2;
+    unsigned* counter = sync + d * 64;
+    unsigned* abort_word = sync + 1023;
     const __amdgpu_buffer_rsrc_t dghrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
 
@@ -540,6 +541,283 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
     }
 }
 
+// ================================================================================================ grouped persistent form
+// The recurrence is independent across utterances, so the batch is cut into groups of RG = 8 rows and a group's
+// workgroups only ever talk to each other: 8 workgroups (64 hidden units each, 512 threads) hold the whole W_hh of one
+// direction in registers for those 8 rows.  Per step a workgroup now waits for 8 arrivals instead of 32 and pulls
+// 8 KB (forward, h) / 24 KB (backward, dgh) instead of 32 / 96 KB -- the two terms of the step's latency chain that
+// scaled with the batch.  Waves: 4 over the workgroup's units (16 each = one MFMA tile per gate) x 2 over K; the K = 1
+// half parks its partial tile in LDS, the K = 0 half adds it and does the gate math in the accumulator layout
+// (lane = unit, register = batch row), so no transposition is needed.  Bias gradients are summed over time in registers.
+constexpr int RG = 8;
+
+__device__ __forceinline__ float lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
+
+template <int KSF>      // K steps (of 32) per wave = H / 64
+__global__ __launch_bounds__(512) void fwd_group_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+                                                        const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                        uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
+                                                        int T, int B, int H, int ndir) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                       // [4 unit tiles][3 gates][64 lanes]
+    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * 3 * 64);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 3, wk = w >> 2;
+    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y, nwg = gridDim.x;
+    const int u0 = blockIdx.x * 64 + wn * 16, r0 = g * RG;
+    const size_t hs = (size_t)ndir * H;
+    unsigned* counter = sync + (d * G + g) * 64;
+    unsigned* abort_word = sync + 1023;
+    const __amdgpu_buffer_rsrc_t h16rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
+
+    Frag bb[KSF][3];
+#pragma unroll
+    for (int i = 0; i < KSF; ++i) {
+        const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            bb[i][q].u = *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + q) * H + u0 + (lane & 15)) * H + k);
+    }
+    // gate role: K = 0 half, lanes 0..31: unit u0 + (lane & 15), batch rows r0 + 4 * (lane >> 4) + e
+    const bool role = wk == 0 && lane < 32;
+    const int unit = u0 + (lane & 15), rb = r0 + 4 * ((lane >> 4) & 1);
+    float bh[3] = {0.f, 0.f, 0.f};
+    if (role)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bh[q] = bhh[(d * 3 + q) * H + unit];
+    float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        float egi[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = role && rb + e < B;
+            const float* gir = gi + ((size_t)t * B + (ok ? rb + e : 0)) * (3 * hs) + (size_t)d * 3 * H + unit;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) egi[q][e] = ok ? gir[q * H] : 0.f;
+        }
+        f32x4 acc[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
+            __syncthreads();
+            if (*s_abort) break;
+            Frag a[KSF];
+#pragma unroll
+            for (int i = 0; i < KSF; ++i) {
+                const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
+                const int row = r0 + (lane & 15);
+                const bool ok = (lane & 15) < RG && row < B;
+                const unsigned off = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * hs + d * H + k) * 2);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                a[i].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < KSF; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][q].v, acc[q], 0, 0, 0);
+            if (wk == 1)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) part[(wn * 3 + q) * 64 + lane] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+            __syncthreads();
+            if (wk == 0)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float4 v = part[(wn * 3 + q) * 64 + lane];
+                    acc[q][0] += v.x; acc[q][1] += v.y; acc[q][2] += v.z; acc[q][3] += v.w;
+                }
+        }
+        float r[4], z[4], n[4], h[4], qn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qn[e] = acc[2][e] + bh[2];
+            r[e] = sigmoidf_(egi[0][e] + acc[0][e] + bh[0]);
+            z[e] = sigmoidf_(egi[1][e] + acc[1][e] + bh[1]);
+            n[e] = tanhf_(egi[2][e] + r[e] * qn[e]);
+            h[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
+            hprev[e] = h[e];
+        }
+        // publish h_t as bf16 pairs: even lanes store rows e = 0, 1 of units (unit, unit + 1), odd lanes rows e = 2, 3
+        {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = lane_xor1(h[e]);       // all lanes execute the shuffle
+            if (role) {
+                const int odd = lane & 1;
+#pragma unroll
+                for (int x = 0; x < 2; ++x) {
+                    const int e = 2 * odd + x;
+                    const float lo = odd ? o[e] : h[e], hi = odd ? h[e] : o[e];
+                    if (rb + e < B) {
+                        const size_t idx = ((size_t)t * B + rb + e) * hs + d * H + (unit - odd);
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + idx),
+                                           (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16), ASR_RLX_AGENT);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+        if (role)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (rb + e < B) {
+                    const size_t rowi = (size_t)t * B + rb + e;
+                    hseq[rowi * hs + d * H + unit] = h[e];
+                    float* gs = gates + (rowi * ndir + d) * 4 * H + unit;
+                    gs[0] = r[e]; gs[H] = z[e]; gs[2 * H] = n[e]; gs[3 * H] = qn[e];
+                }
+    }
+}
+
+template <int KSF>      // K steps per wave = 3H / 128; workgroup = 32 units: waves 2 (unit tiles) x 4 (K quarters)
+__global__ __launch_bounds__(512) void bwd_group_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
+                                                        const float* __restrict__ hseq,
+                                                        const uint16_t* __restrict__ whhT, uint16_t* __restrict__ dgi,
+                                                        uint16_t* dgh, float* __restrict__ db_ih,
+                                                        float* __restrict__ db_hh, unsigned* sync, int T, int B, int H,
+                                                        int ndir) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                       // [3 K quarters][2 unit tiles][64 lanes]
+    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 3 * 2 * 64);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 1, wk = w >> 1;
+    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y, nwg = gridDim.x;
+    const int u0 = blockIdx.x * 32 + wn * 16, r0 = g * RG;
+    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
+    unsigned* counter = sync + (d * G + g) * 64;
+    unsigned* abort_word = sync + 1023;
+    const __amdgpu_buffer_rsrc_t dghrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
+
+    Frag bb[KSF];
+#pragma unroll
+    for (int i = 0; i < KSF; ++i) {
+        const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
+        bb[i].u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + u0 + (lane & 15)) * (3 * H) + k);
+    }
+    const bool role = wk == 0 && lane < 32;
+    const int unit = u0 + (lane & 15), rb = r0 + 4 * ((lane >> 4) & 1);
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float sb[4] = {0.f, 0.f, 0.f, 0.f};          // running bias-gradient sums: r, z, n (input side), q (hidden side)
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? t + 1 : t - 1;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        const bool has_prev = d == 0 ? t > 0 : t < T - 1;
+        float edy[4], eg[4][4], ehp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool ok = role && rb + e < B;
+            const size_t rowi = (size_t)t * B + (ok ? rb + e : 0);
+            edy[e] = ok ? bf16_to_f32(dy[rowi * H + unit]) : 0.f;
+            const float* gs = gates + (rowi * ndir + d) * 4 * H + unit;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) eg[q][e] = ok ? gs[q * H] : 0.f;
+            ehp[e] = (ok && has_prev) ? hseq[((size_t)tp * B + rb + e) * hs + d * H + unit] : 0.f;
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
+            __syncthreads();
+            if (*s_abort) break;
+            Frag a[KSF];
+#pragma unroll
+            for (int i = 0; i < KSF; ++i) {
+                const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
+                const int row = r0 + (lane & 15);
+                const bool ok = (lane & 15) < RG && row < B;
+                const unsigned off = (unsigned)((((size_t)tn * B + (ok ? row : 0)) * gs3 + (size_t)d * 3 * H + k) * 2);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                a[i].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < KSF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
+            if (wk > 0) part[((wk - 1) * 2 + wn) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            __syncthreads();
+            if (wk == 0)
+#pragma unroll
+                for (int qk = 0; qk < 3; ++qk) {
+                    const float4 v = part[(qk * 2 + wn) * 64 + lane];
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                }
+        }
+        float dar[4], daz[4], dan[4], dq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dh = edy[e] + carry[e] + acc[e];
+            const float r = eg[0][e], z = eg[1][e], n = eg[2][e], qq = eg[3][e];
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (ehp[e] - n);
+            dan[e] = dn * (1.0f - n * n);
+            daz[e] = dz * z * (1.0f - z);
+            dq[e] = dan[e] * r;
+            dar[e] = dan[e] * qq * r * (1.0f - r);
+            carry[e] = dh * z;
+            // the bias gradients see the bf16-rounded values the weight-gradient GEMMs see
+            sb[0] += bf16_to_f32(f32_to_bf16(dar[e])); sb[1] += bf16_to_f32(f32_to_bf16(daz[e]));
+            sb[2] += bf16_to_f32(f32_to_bf16(dan[e])); sb[3] += bf16_to_f32(f32_to_bf16(dq[e]));
+        }
+        float o_r[4], o_z[4], o_n[4], o_q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o_r[e] = lane_xor1(dar[e]); o_z[e] = lane_xor1(daz[e]); o_n[e] = lane_xor1(dan[e]); o_q[e] = lane_xor1(dq[e]); }
+        unsigned pk[2][4];      // [row slot][r, z, n, q] packed (unit - odd, unit - odd + 1)
+        const int odd = lane & 1;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int e = 2 * odd + x;
+            auto pack = [&](float own, float oth) -> unsigned {
+                const float lo = odd ? oth : own, hi = odd ? own : oth;
+                return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+            };
+            pk[x][0] = pack(dar[e], o_r[e]); pk[x][1] = pack(daz[e], o_z[e]);
+            pk[x][2] = pack(dan[e], o_n[e]); pk[x][3] = pack(dq[e], o_q[e]);
+        }
+        if (role)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int e = 2 * odd + x;
+                if (rb + e < B) {
+                    const size_t o = ((size_t)t * B + rb + e) * gs3 + (size_t)d * 3 * H + (unit - odd);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pk[x][0], ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pk[x][1], ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pk[x][3], ASR_RLX_AGENT);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+        if (role)
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const int e = 2 * odd + x;
+                if (rb + e < B) {
+                    const size_t o = ((size_t)t * B + rb + e) * gs3 + (size_t)d * 3 * H + (unit - odd);
+                    *reinterpret_cast<unsigned*>(dgi + o) = pk[x][0];
+                    *reinterpret_cast<unsigned*>(dgi + o + H) = pk[x][1];
+                    *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pk[x][2];
+                }
+            }
+    }
+    // bias gradients: rows 0..3 sit in lanes 0..15, rows 4..7 in lanes 16..31 of the same unit
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sb[q] += __shfl_xor(sb[q], 16, 64);
+    if (role && lane < 16 && db_ih && db_hh) {
+        float* bi = db_ih + (size_t)d * 3 * H + unit;
+        float* bh2 = db_hh + (size_t)d * 3 * H + unit;
+        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
+        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
+    }
+}
+
 // y = hf + hb (or a copy for one direction): f32 state -> bf16 layer output
 __global__ void merge_dirs_kernel(const float* __restrict__ hseq, uint16_t* __restrict__ y, long long rows, int H,
                                   int ndir) {
@@ -567,6 +845,9 @@ static int check_dims(int T, int B, int H, int ndir) {
 
 // persistent form applies when one pass covers the batch (B <= 32), the grid is surely co-resident (<= 128 workgroups)
 // and the offsets fit the 32-bit buffer descriptors
+// grouped form: 8 workgroups x 64 units, groups of 8 utterances; at most 4 groups x 2 directions x 8 = 64 workgroups
+static bool can_group(int B, int H) { return H % 128 == 0 && H <= 512 && B <= 4 * RG; }
+
 static bool can_persist(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
     if (mode == 1 || !sync_ws) return false;
     if (B > 16 * MT || (H / 16) * ndir > 128 || H > 1024) return false;
@@ -586,8 +867,26 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     if (ksw > 8) return ASR_ERR_UNSUPPORTED;      // H <= 1024
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
-    if (persist) {
-        if (hipMemsetAsync(sync_ws, 0, 16, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    const bool grouped = persist && can_group(B, H);
+    if (grouped) {
+        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const dim3 ggrid(H / 64, (B + RG - 1) / RG, ndir), gblock(512);
+#define ASR_FWDG(K)                                                                                                       \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL(fwd_group_kernel<K>, ggrid, gblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,   \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir);                                \
+    } while (0)
+        switch (H / 64) {
+            case 2: ASR_FWDG(2); break;
+            case 4: ASR_FWDG(4); break;
+            case 6: ASR_FWDG(6); break;
+            case 8: ASR_FWDG(8); break;
+            default: return ASR_ERR_UNSUPPORTED;
+        }
+#undef ASR_FWDG
+    } else if (persist) {
+        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
 #define ASR_FWDP(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)fwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
@@ -616,8 +915,8 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
 }
 
 extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq,
-                           const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, int T, int B, int H,
-                           int ndir, void* sync_ws, int mode) {
+                           const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih,
+                           float* db_hh, int T, int B, int H, int ndir, void* sync_ws, int mode) {
     if (!dy_bf16 || !gates || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
@@ -626,8 +925,29 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
     const int ksw = (3 * H / 32 + 3) / 4;
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12;
     if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
+    const bool grouped = persist && can_group(B, H) && db_ih && db_hh;
+    if (grouped) {
+        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const dim3 ggrid(H / 32, (B + RG - 1) / RG, ndir), gblock(512);
+#define ASR_BWDG(K)                                                                                                       \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)bwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL(bwd_group_kernel<K>, ggrid, gblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq,       \
+                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,              \
+                           (unsigned*)sync_ws, T, B, H, ndir);                                                             \
+    } while (0)
+        switch (3 * H / 128) {
+            case 3: ASR_BWDG(3); break;
+            case 6: ASR_BWDG(6); break;
+            case 9: ASR_BWDG(9); break;
+            case 12: ASR_BWDG(12); break;
+            default: return ASR_ERR_UNSUPPORTED;
+        }
+#undef ASR_BWDG
+        return ASR_OK;
+    }
     if (persist) {
-        if (hipMemsetAsync(sync_ws, 0, 16, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
 #define ASR_BWDP(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)bwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
@@ -644,5 +964,14 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
 #undef ASR_BWD
     }
     ASR_LAUNCH_CHECK();
+    // bias gradients (the grouped kernel sums them in registers; here a column sum over all (t, b) rows)
+    if (db_ih) {
+        const int rc2 = asr_colsum_acc(stream, dgi_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_ih);
+        if (rc2 != ASR_OK) return rc2;
+    }
+    if (db_hh) {
+        const int rc2 = asr_colsum_acc(stream, dgh_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_hh);
+        if (rc2 != ASR_OK) return rc2;
+    }
     return ASR_OK;
 }
