@@ -229,7 +229,8 @@ GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only
 
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
-    sync = torch.zeros(1024, dtype=torch.int32, device=dev)
+    sync = torch.empty(_lib.lib().asr_gru_sync_bytes(B, H, ndir) // 4, dtype=torch.int32, device=dev)
+    sync[1023:1024].zero_()
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
@@ -257,7 +258,8 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
-    sync = torch.zeros(1024, dtype=torch.int32, device=dev)
+    sync = torch.empty(_lib.lib().asr_gru_sync_bytes(B, H, ndir) // 4, dtype=torch.int32, device=dev)
+    sync[1023:1024].zero_()
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
                                 ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_bwd")

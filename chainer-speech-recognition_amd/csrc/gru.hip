@@ -27,10 +27,12 @@ union Frag {
     uint4 u;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// one v_exp_f32 + one v_rcp_f32 each (an IEEE division costs ~10 dependent VALU instructions, and the gate math runs on
+// one wave per SIMD in the latency chain of a step)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-    const float e = __expf(-2.0f * fabsf(x));
-    const float t = (1.0f - e) / (1.0f + e);
+    const float e = __expf(-2.0f * fabsf(x));                 // in (0, 1]
+    const float t = 1.0f - 2.0f * e * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, x);
 }
 
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __rest
     }
     float hprev[2] = {0.f, 0.f};
     if (tid == 0) *s_abort = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
     const bool act = b < B;
     float carry[2] = {0.f, 0.f};
     if (tid == 0) *s_abort = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -553,147 +557,250 @@ constexpr int RG = 8;
 
 __device__ __forceinline__ float lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
 
-template <int KSF>      // K steps (of 32) per wave = H / 64
-__global__ __launch_bounds__(512) void fwd_group_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+// Hand-off inside a group: DATA-TAGGED GRANULES (MI355X_MICROARCH.md, R2 "the data IS the flag").  A granule is one
+// naturally aligned 8-byte word {tag = step + 1, two bf16 values}, written by ONE sc1 store and read with 16-byte sc1
+// loads; a wave re-reads its K slice until every tag carries the step it waits for.  No drain, no counter, no poll of a
+// separate word: the chain per step is store -> visible -> load.  The exchange buffer is double-buffered by step
+// parity (a workgroup can only start step s+1 after every workgroup of its group has published step s, i.e. after they
+// all finished reading step s-1) and zeroed by the launch function, so stale tags never match.
+typedef unsigned long long u64;
+
+// returns false on time-out (abort word raised); lanes with !need are ignored
+template <int N>
+__device__ __forceinline__ bool load_granules(const __amdgpu_buffer_rsrc_t& rsrc, const unsigned (&off)[N], bool need,
+                                              unsigned tag, Frag (&out)[N], unsigned* abort_word) {
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 16 /* sc1 */);
+            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + 16, 0, 16 /* sc1 */);
+            ok = ok && lo[1] == tag && lo[3] == tag && hi[1] == tag && hi[3] == tag;
+            out[i].u = make_uint4(lo[0], lo[2], hi[0], hi[2]);
+        }
+        if (__all(ok || !need)) return true;
+        if ((spins & 63u) == 63u) {
+            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+// Forward group kernel: 8 compute waves + 2 I/O waves, 32 hidden units per workgroup.  Memory operations of a wave
+// retire in issue order, so an HBM load or store issued by a compute wave would sit in front of its hand-off loads and put
+// the HBM latency (3-4 us with the strided gi rows) on the step-to-step chain.  The compute waves therefore touch only
+// the exchange buffer and LDS:
+//   waves 0..7  2 unit tiles x 4 K quarters; K quarter 0, lanes 0..31 also do the gate math (lane = unit, register = row)
+//   wave 8 (loader)  streams gi[t] for steps s+1 .. s+GD into an LDS ring, two steps of loads in flight in registers
+//   wave 9 (storer)  writes what the backward pass / the next layer read later (f32 state, gates, bf16 copy) from an
+//                    LDS double buffer, one step behind
+// All ten waves meet at ONE barrier per step.
+constexpr int GD = 4;                          // depth of the gi ring (steps)
+constexpr int UW = 32;                         // hidden units per workgroup
+
+template <int KSF>      // K steps (of 32) per compute wave = H / 128
+__global__ __launch_bounds__(640) void fwd_group_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
                                                         const float* __restrict__ bhh, float* __restrict__ hseq,
-                                                        uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
-                                                        int T, int B, int H, int ndir) {
+                                                        uint16_t* __restrict__ hseq16, float* __restrict__ gates,
+                                                        unsigned* sync, u64* xbuf, int T, int B, int H, int ndir) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                       // [4 unit tiles][3 gates][64 lanes]
-    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * 3 * 64);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 3, wk = w >> 2;
-    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y, nwg = gridDim.x;
-    const int u0 = blockIdx.x * 64 + wn * 16, r0 = g * RG;
+    float4* part0 = reinterpret_cast<float4*>(smem);                      // [step parity][3 K quarters][2 tiles][3 gates][64 lanes]
+    constexpr int kPartStep = 3 * 2 * 3 * 64;
+    float* giring = reinterpret_cast<float*>(smem + sizeof(float4) * 2 * kPartStep);       // [GD][3 gates][RG][UW]
+    float* oring = giring + GD * 3 * RG * UW;                                               // [2][5][RG][UW]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * RG * UW);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 1, wk = ((w >> 1) + 3) & 3;   // K quarter 0 = waves 2, 3:
+    // waves are dealt to the four SIMDs cyclically, so the gate-math waves do not share a SIMD with the I/O waves 8, 9
+    const bool is_loader = w == 8, is_storer = w == 9, is_compute = w < 8;
+    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y;
+    const int ublk = blockIdx.x * UW, u0 = ublk + wn * 16, r0 = g * RG;
     const size_t hs = (size_t)ndir * H;
-    unsigned* counter = sync + (d * G + g) * 64;
     unsigned* abort_word = sync + 1023;
-    const __amdgpu_buffer_rsrc_t h16rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
+    const int HG = H >> 1;                                                // granules per row
+    u64* xg = xbuf + (size_t)(d * G + g) * 2 * RG * HG;                    // [parity][RG rows][HG]
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * RG * HG * 8, 0x00020000);
+
+    // ---- I/O lanes work in 16-byte pieces: piece p = (row-array ra = p >> 3, units 4 * (p & 7) .. + 3)
+    const int c4 = (lane & 7) * 4, rsel = lane >> 3;                      // 8 lanes per 128-byte row
+    const long long tstep = d == 0 ? 1 : -1;
+    const int tfirst = d == 0 ? 0 : T - 1;
+    // loader: 3 gates x RG rows = 24 row-arrays, 3 per lane: ra = rsel + 8 * i  ->  gate q = ra / RG, row rr = ra % RG
+    auto gi_load = [&](int s_, float4 (&v)[3]) {
+        const long long t_ = tfirst + tstep * s_;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ra = rsel + 8 * i, q = ra / RG, rr = ra % RG;
+            const bool ok = s_ < T && r0 + rr < B;
+            v[i] = ok ? *reinterpret_cast<const float4*>(gi + ((size_t)t_ * B + r0 + rr) * (3 * hs) + (size_t)d * 3 * H + q * H + ublk + c4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto gi_put = [&](int s_, const float4 (&v)[3]) {
+        float* dst = giring + (size_t)(s_ % GD) * 3 * RG * UW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(dst + (rsel + 8 * i) * UW + c4) = v[i];
+    };
+    // storer: 5 arrays x RG rows = 40 row-arrays, 5 per lane (ra = rsel + 8 * i -> array k = i, row rr = rsel)
+    auto store_step = [&](int sp) {
+        const long long tq = tfirst + tstep * sp;
+        const float* src = oring + (size_t)(sp & 1) * 5 * RG * UW;
+        const int rr = rsel;
+        if (r0 + rr < B) {
+            const size_t rowi = (size_t)tq * B + r0 + rr;
+            const float4 hv = *reinterpret_cast<const float4*>(src + (0 * RG + rr) * UW + c4);
+            *reinterpret_cast<float4*>(hseq + rowi * hs + d * H + ublk + c4) = hv;
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(hv.x) | ((unsigned)f32_to_bf16(hv.y) << 16);
+            pk.y = (unsigned)f32_to_bf16(hv.z) | ((unsigned)f32_to_bf16(hv.w) << 16);
+            *reinterpret_cast<uint2*>(hseq16 + rowi * hs + d * H + ublk + c4) = pk;
+            float* gs = gates + (rowi * ndir + d) * 4 * H + ublk + c4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(gs + q * H) = *reinterpret_cast<const float4*>(src + ((1 + q) * RG + rr) * UW + c4);
+        }
+    };
+    float4 la[3], lb[3];
+    if (is_loader) {
+        for (int s0 = 0; s0 < GD - 1; ++s0) {          // steps 0 .. GD-2 are in the ring before the first step runs
+            gi_load(s0, la);
+            gi_put(s0, la);
+        }
+        gi_load(GD - 1, la);                           // in flight: steps GD-1 (la) and GD (lb)
+        gi_load(GD, lb);
+    }
 
     Frag bb[KSF][3];
-#pragma unroll
-    for (int i = 0; i < KSF; ++i) {
-        const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            bb[i][q].u = *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + q) * H + u0 + (lane & 15)) * H + k);
-    }
-    // gate role: K = 0 half, lanes 0..31: unit u0 + (lane & 15), batch rows r0 + 4 * (lane >> 4) + e
-    const bool role = wk == 0 && lane < 32;
-    const int unit = u0 + (lane & 15), rb = r0 + 4 * ((lane >> 4) & 1);
     float bh[3] = {0.f, 0.f, 0.f};
-    if (role)
+    const bool role = is_compute && wk == 0 && lane < 32;
+    const int ul = wn * 16 + (lane & 15);                                 // unit inside the workgroup
+    const int unit = ublk + ul, rloc = 4 * ((lane >> 4) & 1), rb = r0 + rloc;
+    if (is_compute) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) bh[q] = bhh[(d * 3 + q) * H + unit];
+        for (int i = 0; i < KSF; ++i) {
+            const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                bb[i][q].u = *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + q) * H + u0 + (lane & 15)) * H + k);
+        }
+        if (role)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bh[q] = bhh[(d * 3 + q) * H + unit];
+    }
+    if (__builtin_amdgcn_readfirstlane(wk) == 0 && __builtin_amdgcn_readfirstlane(w) < 8) __builtin_amdgcn_s_setprio(3);
     float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+    const int arow = lane & 15;
+    const bool aneed = arow < RG && r0 + arow < B;
     if (tid == 0) *s_abort = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? s : T - 1 - s;
-        const int tp = d == 0 ? t - 1 : t + 1;
-        float egi[3][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool ok = role && rb + e < B;
-            const float* gir = gi + ((size_t)t * B + (ok ? rb + e : 0)) * (3 * hs) + (size_t)d * 3 * H + unit;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) egi[q][e] = ok ? gir[q * H] : 0.f;
-        }
         f32x4 acc[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
-            __syncthreads();
-            if (*s_abort) break;
+        float4* part = part0 + (s & 1) * kPartStep;        // parity: other K quarters may run one step ahead of quarter 0
+        if (is_compute && s > 0) {
             Frag a[KSF];
+            unsigned off[KSF];
 #pragma unroll
             for (int i = 0; i < KSF; ++i) {
                 const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-                const int row = r0 + (lane & 15);
-                const bool ok = (lane & 15) < RG && row < B;
-                const unsigned off = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * hs + d * H + k) * 2);
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
-                a[i].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+                off[i] = (unsigned)(((((s - 1) & 1) * RG + (aneed ? arow : 0)) * HG + (k >> 1)) * 8);
             }
+            if (!load_granules<KSF>(xrsrc, off, aneed, (unsigned)s, a, abort_word)) *s_abort = 1;
+            if (!aneed)
+#pragma unroll
+                for (int i = 0; i < KSF; ++i) a[i].u = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < KSF; ++i)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][q].v, acc[q], 0, 0, 0);
-            if (wk == 1)
+            if (wk > 0)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) part[(wn * 3 + q) * 64 + lane] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-            __syncthreads();
-            if (wk == 0)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float4 v = part[(wn * 3 + q) * 64 + lane];
-                    acc[q][0] += v.x; acc[q][1] += v.y; acc[q][2] += v.z; acc[q][3] += v.w;
-                }
+                for (int q = 0; q < 3; ++q)
+                    part[(((wk - 1) * 2 + wn) * 3 + q) * 64 + lane] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
         }
-        float r[4], z[4], n[4], h[4], qn[4];
+        __syncthreads();                                   // the one barrier of the step (all ten waves)
+        if (*s_abort) break;
+        if (is_loader) {
+            // the slot of step s-1 is free now: step s+GD-1 goes there; two steps of loads stay in flight (la / lb alternate)
+            if (s & 1) { gi_put(s + GD - 1, lb); gi_load(s + GD + 1, lb); }
+            else       { gi_put(s + GD - 1, la); gi_load(s + GD + 1, la); }
+        } else if (is_storer) {
+            if (s > 0) store_step(s - 1);
+        } else if (wk == 0) {
+            if (s > 0)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qn[e] = acc[2][e] + bh[2];
-            r[e] = sigmoidf_(egi[0][e] + acc[0][e] + bh[0]);
-            z[e] = sigmoidf_(egi[1][e] + acc[1][e] + bh[1]);
-            n[e] = tanhf_(egi[2][e] + r[e] * qn[e]);
-            h[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
-            hprev[e] = h[e];
-        }
-        // publish h_t as bf16 pairs: even lanes store rows e = 0, 1 of units (unit, unit + 1), odd lanes rows e = 2, 3
-        {
-            float o[4];
+                for (int qk = 0; qk < 3; ++qk)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = lane_xor1(h[e]);       // all lanes execute the shuffle
-            if (role) {
-                const int odd = lane & 1;
-#pragma unroll
-                for (int x = 0; x < 2; ++x) {
-                    const int e = 2 * odd + x;
-                    const float lo = odd ? o[e] : h[e], hi = odd ? h[e] : o[e];
-                    if (rb + e < B) {
-                        const size_t idx = ((size_t)t * B + rb + e) * hs + d * H + (unit - odd);
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + idx),
-                                           (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16), ASR_RLX_AGENT);
+                    for (int q = 0; q < 3; ++q) {
+                        const float4 v = part[((qk * 2 + wn) * 3 + q) * 64 + lane];
+                        acc[q][0] += v.x; acc[q][1] += v.y; acc[q][2] += v.z; acc[q][3] += v.w;
                     }
+            const float* gsrc = giring + (size_t)(s % GD) * 3 * RG * UW;
+            float* odst = oring + (size_t)(s & 1) * 5 * RG * UW;
+            float h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = (rloc + e) & (RG - 1);
+                const float g0 = gsrc[(0 * RG + rr) * UW + ul], g1 = gsrc[(1 * RG + rr) * UW + ul], g2 = gsrc[(2 * RG + rr) * UW + ul];
+                const float qn = acc[2][e] + bh[2];
+                const float r = sigmoidf_(g0 + acc[0][e] + bh[0]);
+                const float z = sigmoidf_(g1 + acc[1][e] + bh[1]);
+                const float n = tanhf_(g2 + r * qn);
+                h[e] = (1.0f - z) * n + z * hprev[e];
+                hprev[e] = h[e];
+                if (lane < 32) {
+                    odst[(0 * RG + rr) * UW + ul] = h[e];
+                    odst[(1 * RG + rr) * UW + ul] = r;
+                    odst[(2 * RG + rr) * UW + ul] = z;
+                    odst[(3 * RG + rr) * UW + ul] = n;
+                    odst[(4 * RG + rr) * UW + ul] = qn;
                 }
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
-        if (role)
+            // publish h_t: even lanes carry rows e = 0, 1 of units (unit, unit + 1), odd lanes rows e = 2, 3
+            float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (rb + e < B) {
-                    const size_t rowi = (size_t)t * B + rb + e;
-                    hseq[rowi * hs + d * H + unit] = h[e];
-                    float* gs = gates + (rowi * ndir + d) * 4 * H + unit;
-                    gs[0] = r[e]; gs[H] = z[e]; gs[2 * H] = n[e]; gs[3 * H] = qn[e];
-                }
+            for (int e = 0; e < 4; ++e) o[e] = lane_xor1(h[e]);
+            const int odd = lane & 1;
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {      // both packings are formed from fixed registers and the lane picks one
+                const unsigned even_pk = (unsigned)f32_to_bf16(h[x]) | ((unsigned)f32_to_bf16(o[x]) << 16);
+                const unsigned odd_pk = (unsigned)f32_to_bf16(o[2 + x]) | ((unsigned)f32_to_bf16(h[2 + x]) << 16);
+                const unsigned pk = odd ? odd_pk : even_pk;
+                const int e = 2 * odd + x;
+                if (role && rb + e < B)
+                    __hip_atomic_store(xg + ((size_t)(s & 1) * RG + rloc + e) * HG + ((unit - odd) >> 1),
+                                       ((u64)(unsigned)(s + 1) << 32) | pk, ASR_RLX_AGENT);
+            }
+        }
     }
+    // drain: the storer still owes the last step
+    __syncthreads();
+    if (is_storer && !*s_abort) store_step(T - 1);
 }
 
 template <int KSF>      // K steps per wave = 3H / 128; workgroup = 32 units: waves 2 (unit tiles) x 4 (K quarters)
 __global__ __launch_bounds__(512) void bwd_group_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ hseq,
                                                         const uint16_t* __restrict__ whhT, uint16_t* __restrict__ dgi,
-                                                        uint16_t* dgh, float* __restrict__ db_ih,
-                                                        float* __restrict__ db_hh, unsigned* sync, int T, int B, int H,
-                                                        int ndir) {
+                                                        uint16_t* __restrict__ dgh, float* __restrict__ db_ih,
+                                                        float* __restrict__ db_hh, unsigned* sync, u64* xbuf, int T,
+                                                        int B, int H, int ndir) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                       // [3 K quarters][2 unit tiles][64 lanes]
-    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 3 * 2 * 64);
+    float4* part0 = reinterpret_cast<float4*>(smem);                      // [step parity][3 K quarters][2 unit tiles][64 lanes]
+    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 2 * 3 * 2 * 64);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 1, wk = w >> 1;
-    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y, nwg = gridDim.x;
+    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y;
     const int u0 = blockIdx.x * 32 + wn * 16, r0 = g * RG;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + (d * G + g) * 64;
     unsigned* abort_word = sync + 1023;
-    const __amdgpu_buffer_rsrc_t dghrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
+    const int KG = (3 * H) >> 1;                                          // granules per row of dgh
+    u64* xg = xbuf + (size_t)(d * G + g) * 2 * RG * KG;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * RG * KG * 8, 0x00020000);
 
     Frag bb[KSF];
 #pragma unroll
@@ -702,47 +809,56 @@ __global__ __launch_bounds__(512) void bwd_group_kernel(const uint16_t* __restri
         bb[i].u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + u0 + (lane & 15)) * (3 * H) + k);
     }
     const bool role = wk == 0 && lane < 32;
-    const int unit = u0 + (lane & 15), rb = r0 + 4 * ((lane >> 4) & 1);
+    const int unit = u0 + (lane & 15), rloc = 4 * ((lane >> 4) & 1), rb = r0 + rloc;
+    const int arow = lane & 15;
+    const bool aneed = arow < RG && r0 + arow < B;
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
     float sb[4] = {0.f, 0.f, 0.f, 0.f};          // running bias-gradient sums: r, z, n (input side), q (hidden side)
     if (tid == 0) *s_abort = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
     __syncthreads();
 
-    for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? T - 1 - s : s;
-        const int tn = d == 0 ? t + 1 : t - 1;
-        const int tp = d == 0 ? t - 1 : t + 1;
-        const bool has_prev = d == 0 ? t > 0 : t < T - 1;
-        float edy[4], eg[4][4], ehp[4];
+    // operands of step s+1 (dy, saved gates, h_prev: HBM streams) are fetched while step s runs
+    float edy[4], eg[4][4], ehp[4], ndy[4], ng[4][4], nhp[4];
+    auto fetch_ops = [&](int s_, float (&dy_)[4], float (&g_)[4][4], float (&hp_)[4]) {
+        const int t_ = d == 0 ? T - 1 - s_ : s_;
+        const int tp_ = d == 0 ? t_ - 1 : t_ + 1;
+        const bool hasp = d == 0 ? t_ > 0 : t_ < T - 1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool ok = role && rb + e < B;
-            const size_t rowi = (size_t)t * B + (ok ? rb + e : 0);
-            edy[e] = ok ? bf16_to_f32(dy[rowi * H + unit]) : 0.f;
+            const bool ok = role && rb + e < B && s_ < T;
+            const size_t rowi = (size_t)(ok ? t_ : 0) * B + (ok ? rb + e : 0);
+            dy_[e] = ok ? bf16_to_f32(dy[rowi * H + unit]) : 0.f;
             const float* gs = gates + (rowi * ndir + d) * 4 * H + unit;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) eg[q][e] = ok ? gs[q * H] : 0.f;
-            ehp[e] = (ok && has_prev) ? hseq[((size_t)tp * B + rb + e) * hs + d * H + unit] : 0.f;
+            for (int q = 0; q < 4; ++q) g_[q][e] = ok ? gs[q * H] : 0.f;
+            hp_[e] = (ok && hasp) ? hseq[((size_t)tp_ * B + rb + e) * hs + d * H + unit] : 0.f;
         }
+    };
+    fetch_ops(0, edy, eg, ehp);
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        if (s == 0) fetch_ops(1, ndy, ng, nhp);
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
-            __syncthreads();
-            if (*s_abort) break;
+            float4* part = part0 + (s & 1) * (3 * 2 * 64);
             Frag a[KSF];
+            unsigned off[KSF];
 #pragma unroll
             for (int i = 0; i < KSF; ++i) {
                 const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-                const int row = r0 + (lane & 15);
-                const bool ok = (lane & 15) < RG && row < B;
-                const unsigned off = (unsigned)((((size_t)tn * B + (ok ? row : 0)) * gs3 + (size_t)d * 3 * H + k) * 2);
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
-                a[i].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+                off[i] = (unsigned)(((((s - 1) & 1) * RG + (aneed ? arow : 0)) * KG + (k >> 1)) * 8);
             }
+            if (!load_granules<KSF>(xrsrc, off, aneed, (unsigned)s, a, abort_word)) *s_abort = 1;
+            fetch_ops(s + 1, ndy, ng, nhp);        // behind the hand-off loads (in-order return)
+            if (!aneed)
+#pragma unroll
+                for (int i = 0; i < KSF; ++i) a[i].u = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < KSF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
             if (wk > 0) part[((wk - 1) * 2 + wn) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             __syncthreads();
+            if (*s_abort) break;
             if (wk == 0)
 #pragma unroll
                 for (int qk = 0; qk < 3; ++qk) {
@@ -772,40 +888,47 @@ __global__ __launch_bounds__(512) void bwd_group_kernel(const uint16_t* __restri
         unsigned pk[2][4];      // [row slot][r, z, n, q] packed (unit - odd, unit - odd + 1)
         const int odd = lane & 1;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int e = 2 * odd + x;
-            auto pack = [&](float own, float oth) -> unsigned {
-                const float lo = odd ? oth : own, hi = odd ? own : oth;
-                return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+        for (int x = 0; x < 2; ++x) {      // static register indices only
+            auto pack = [&](float own0, float own1, float oth0, float oth1) -> unsigned {
+                const unsigned even_pk = (unsigned)f32_to_bf16(own0) | ((unsigned)f32_to_bf16(oth0) << 16);
+                const unsigned odd_pk = (unsigned)f32_to_bf16(oth1) | ((unsigned)f32_to_bf16(own1) << 16);
+                return odd ? odd_pk : even_pk;
             };
-            pk[x][0] = pack(dar[e], o_r[e]); pk[x][1] = pack(daz[e], o_z[e]);
-            pk[x][2] = pack(dan[e], o_n[e]); pk[x][3] = pack(dq[e], o_q[e]);
+            pk[x][0] = pack(dar[x], dar[2 + x], o_r[x], o_r[2 + x]); pk[x][1] = pack(daz[x], daz[2 + x], o_z[x], o_z[2 + x]);
+            pk[x][2] = pack(dan[x], dan[2 + x], o_n[x], o_n[2 + x]); pk[x][3] = pack(dq[x], dq[2 + x], o_q[x], o_q[2 + x]);
         }
         if (role)
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const int e = 2 * odd + x;
                 if (rb + e < B) {
-                    const size_t o = ((size_t)t * B + rb + e) * gs3 + (size_t)d * 3 * H + (unit - odd);
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pk[x][0], ASR_RLX_AGENT);
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pk[x][1], ASR_RLX_AGENT);
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pk[x][3], ASR_RLX_AGENT);
+                    u64* gp = xg + ((size_t)(s & 1) * RG + rloc + e) * KG + ((unit - odd) >> 1);
+                    const u64 tag = (u64)(unsigned)(s + 1) << 32;
+                    __hip_atomic_store(gp, tag | pk[x][0], ASR_RLX_AGENT);                 // k = unit       (r gate)
+                    __hip_atomic_store(gp + (H >> 1), tag | pk[x][1], ASR_RLX_AGENT);      // k = H + unit   (z gate)
+                    __hip_atomic_store(gp + H, tag | pk[x][3], ASR_RLX_AGENT);             // k = 2H + unit  (q)
                 }
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
         if (role)
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const int e = 2 * odd + x;
                 if (rb + e < B) {
                     const size_t o = ((size_t)t * B + rb + e) * gs3 + (size_t)d * 3 * H + (unit - odd);
+                    *reinterpret_cast<unsigned*>(dgh + o) = pk[x][0];
+                    *reinterpret_cast<unsigned*>(dgh + o + H) = pk[x][1];
+                    *reinterpret_cast<unsigned*>(dgh + o + 2 * H) = pk[x][3];
                     *reinterpret_cast<unsigned*>(dgi + o) = pk[x][0];
                     *reinterpret_cast<unsigned*>(dgi + o + H) = pk[x][1];
                     *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pk[x][2];
                 }
             }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            edy[e] = ndy[e]; ehp[e] = nhp[e];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) eg[q][e] = ng[q][e];
+        }
     }
     // bias gradients: rows 0..3 sit in lanes 0..15, rows 4..7 in lanes 16..31 of the same unit
 #pragma unroll
@@ -836,6 +959,11 @@ __global__ void merge_dirs_kernel(const float* __restrict__ hseq, uint16_t* __re
 
 using namespace asr;
 using namespace asr::gru;
+
+extern "C" size_t asr_gru_sync_bytes(int B, int H, int ndir) {
+    const size_t G = (size_t)(B + RG - 1) / RG;
+    return 4096 + (size_t)ndir * G * 2 * RG * (3 * (size_t)H / 2) * 8;
+}
 
 static int check_dims(int T, int B, int H, int ndir) {
     if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASR_ERR_BAD_ARG;
@@ -869,19 +997,20 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
     if (grouped) {
-        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
-        const dim3 ggrid(H / 64, (B + RG - 1) / RG, ndir), gblock(512);
+        const int G = (B + RG - 1) / RG;
+        if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const dim3 ggrid(H / UW, G, ndir), gblock(640);
 #define ASR_FWDG(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)fwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
         hipLaunchKernelGGL(fwd_group_kernel<K>, ggrid, gblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,   \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir);                                \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, (u64*)((char*)sync_ws + 4096), T, B, H, ndir);  \
     } while (0)
-        switch (H / 64) {
+        switch (H / 128) {
+            case 1: ASR_FWDG(1); break;
             case 2: ASR_FWDG(2); break;
+            case 3: ASR_FWDG(3); break;
             case 4: ASR_FWDG(4); break;
-            case 6: ASR_FWDG(6); break;
-            case 8: ASR_FWDG(8); break;
             default: return ASR_ERR_UNSUPPORTED;
         }
 #undef ASR_FWDG
@@ -927,14 +1056,15 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
     if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H) && db_ih && db_hh;
     if (grouped) {
-        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
-        const dim3 ggrid(H / 32, (B + RG - 1) / RG, ndir), gblock(512);
+        const int G = (B + RG - 1) / RG;
+        if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (3 * H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const dim3 ggrid(H / 32, G, ndir), gblock(512);
 #define ASR_BWDG(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)bwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
         hipLaunchKernelGGL(bwd_group_kernel<K>, ggrid, gblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq,       \
                            (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,              \
-                           (unsigned*)sync_ws, T, B, H, ndir);                                                             \
+                           (unsigned*)sync_ws, (u64*)((char*)sync_ws + 4096), T, B, H, ndir);                              \
     } while (0)
         switch (3 * H / 128) {
             case 3: ASR_BWDG(3); break;

@@ -142,10 +142,12 @@ int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, floa
  * nn.GRU / nn.NStepBiGRU reach the reference API through `from chainer.links import *` (asr/nn/nn.py:3); gate
  * convention = cuDNN / torch.nn.GRU (r, z, n).  Layouts in csrc/gru.hip.  gi comes from asr_gemm_nt.
  * db_ih / db_hh (ndir, 3H) f32 or NULL: bias gradients, ACCUMULATED (sum over all rows of dgi / dgh).
- * sync_ws: 4096 bytes of device memory (step counters + abort word, zeroed by the call) enabling the persistent
+ * sync_ws: asr_gru_sync_bytes(B, H, ndir) bytes of device memory (control words + the in-launch exchange
+ * buffer, zeroed by the call) enabling the persistent
  * one-launch-per-layer form; mode 0 = automatic, 1 = one launch per time step, 2 = persistent or error.
  * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).
  */
+size_t asr_gru_sync_bytes(int B, int H, int ndir);
 int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
                 float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode);
 int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
