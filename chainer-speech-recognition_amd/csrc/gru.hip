@@ -1054,7 +1054,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
     const int ksw = (3 * H / 32 + 3) / 4;
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12;
     if (mode == 2 && !persist) return ASR_ERR_UNSUPPORTED;
-    const bool grouped = persist && can_group(B, H) && db_ih && db_hh;
+    const bool grouped = persist && can_group(B, H) && db_ih && db_hh && mode == 3;   // grouped backward: opt-in until it fits the register file
     if (grouped) {
         const int G = (B + RG - 1) / RG;
         if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (3 * H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;

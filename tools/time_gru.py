@@ -14,13 +14,14 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
     whhT16 = whh.transpose(1, 2).contiguous().to(torch.bfloat16)
     bhh = torch.zeros(ndir * 3 * H, device=dev)
     dy = torch.randn(T * B, H, generator=g).to(dev).to(torch.bfloat16)
+    dbi = torch.zeros(ndir * 3 * H, device=dev); dbh = torch.zeros(ndir * 3 * H, device=dev)
     for mode in (1, 2):
         _ops.GRU_MODE[0] = mode
         res = {}
         for name in ("fwd", "bwd"):
             y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir)
             fn = (lambda: _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir)) if name == "fwd" else \
-                 (lambda: _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir))
+                 (lambda: _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh))
             fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
