@@ -136,3 +136,36 @@ def test_feature_host_constants():
     assert fft.num_frames(400, 512, 160) == 1 and fft.num_frames(513, 512, 160) == 2
     fb = fft.get_filterbanks(40, 512, 16000)
     assert fb.shape == (40, 257) and fb.sum() == pytest.approx(247.0)
+
+
+@pytest.mark.parametrize("arch", ["zhang", "zhang+fc_relu", "zhang+residual", "zhang+layernorm", "glu", "relu+layernorm",
+                                  "relu+layernorm+residual"])
+def test_build_model_architectures(arch):
+    """layer counts, channel plan and parameter names of run/ctc/cnn/model.py:11-332"""
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    import asr.nn as nn
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers, cfg.architecture = 119, 3, 128, 320, 4, arch
+    m = build_model(cfg)
+    names = [n for n, _ in m.namedparams()]
+    assert "/layer_0/W" in names
+    assert tuple(m.layer_0.W.shape) == ((256 if arch.startswith("zhang") or arch == "glu" else 128), 3, 3, 5)
+    assert isinstance(m.layers[-1], nn.LayerNormalization)            # every recipe ends Conv 1x1 -> LayerNormalization
+    if arch == "zhang+residual":
+        # 3 residual blocks + 1 plain conv block (run/ctc/cnn/model.py:160-176), then 3 dense blocks
+        assert sum(isinstance(l, nn.Residual) for l in m.layers) == 3
+        macs = 256 * 38 * 3 * 15 + 4 * 256 * 13 * 128 * 15 + 640 * 128 * 13 + 640 * 320 + 119 * 320
+        assert abs(macs / 1e6 - 27.3) < 0.05                           # SURVEY.md section 8(d): 27.3 MMAC / frame
+        assert "/layer_5_0/W" in names and tuple(m.layer_5_0.W.shape) == (256, 128, 3, 5)
+    if arch == "relu+layernorm+residual":
+        assert sum(isinstance(l, nn.Residual) for l in m.layers) == 4
+        assert isinstance(m.layers[6].layers[0], nn.LayerNormalization)       # pre-activation block (:315-323)
+    cfg.num_conv_layers = 6
+    if arch == "zhang+residual":
+        wide = build_model(cfg)                                         # "VGG-deep" branch: 4th layer 128->512, +4 layers 256->512
+        shapes = [tuple(p.shape) for n, p in wide.namedparams() if n.endswith("/W") and p.dim() == 4 and p.shape[2:] == (3, 5)]
+        assert shapes.count((512, 256, 3, 5)) == 4 and (512, 128, 3, 5) in shapes
+    cfg.architecture = "unknown"
+    with pytest.raises(NotImplementedError):
+        build_model(cfg)

@@ -129,3 +129,30 @@ def test_reference_style_stream_model(device):
     got = y2.detach().cpu().numpy()                      # (B, T, V)
     want = yr[:, :, 0, :].transpose(0, 2, 1)
     assert _cos(torch.tensor(got), torch.tensor(want)) > 0.999
+
+
+@pytest.mark.parametrize("arch", ["zhang", "zhang+fc_relu", "zhang+residual", "zhang+layernorm", "glu", "relu+layernorm",
+                                  "relu+layernorm+residual"])
+def test_cnn_recipes_train_step(device, arch):
+    """every recipe of run/ctc/cnn/model.py runs forward + CTC + backward + one optimiser step and lowers its loss"""
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import get_optimizer, GradientClipping, WeightDecay
+    torch.manual_seed(0)
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers, cfg.architecture = 19, 3, 16, 24, 3, arch
+    model = build_model(cfg).to_gpu()
+    x, labels, x_len, l_len = omodel.synthetic_batch(3, 40, 19, Lmin=2, Lmax=6, seed=5)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+    opt = get_optimizer("adam", 2e-3, 0.9)
+    ys = model(xd)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    opt.add_hook(WeightDecay(1e-5))
+    losses = []
+    for _ in range(4):
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
