@@ -317,6 +317,161 @@ __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch
     }
 }
 
+
+// 16-byte variants for the internal (T, B, H, C) bf16 layout with C % 8 == 0: one thread moves 8 channels
+__global__ void im2col_vec8_kernel(const uint16_t* __restrict__ x, int T, int B, int Hin, int Cin, int KH, int KW, int ph,
+                                   int pt, int Tout, int Hout, int Kp, uint16_t* __restrict__ col) {
+    const int c8n = Cin >> 3;
+    const int per_row = KH * KW * c8n;
+    const long long n = (long long)Tout * B * Hout * per_row;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        long long r = i / c8n;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH); r /= KH;
+        const int ho = (int)(r % Hout); r /= Hout;
+        const int b = (int)(r % B);
+        const int t = (int)(r / B);
+        const int ti = t + kw - pt, hi = ho + kh - ph;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ti >= 0 && ti < T && hi >= 0 && hi < Hin)
+            v = *reinterpret_cast<const uint4*>(x + ((((long long)ti * B + b) * Hin + hi) * Cin + c8 * 8));
+        *reinterpret_cast<uint4*>(col + (((long long)t * B + b) * Hout + ho) * Kp + (kh * KW + kw) * Cin + c8 * 8) = v;
+    }
+}
+__global__ void col2im_vec8_kernel(const uint16_t* __restrict__ dcol, int T, int B, int Hin, int Cin, int KH, int KW,
+                                   int ph, int pt, int Tout, int Hout, int Kp, uint16_t* __restrict__ dx) {
+    const int c8n = Cin >> 3;
+    const long long n = (long long)T * B * Hin * c8n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        long long r = i / c8n;
+        const int h = (int)(r % Hin); r /= Hin;
+        const int b = (int)(r % B);
+        const int t = (int)(r / B);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < KH; ++kh) {
+            const int ho = h - kh + ph;
+            if (ho < 0 || ho >= Hout) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int to = t - kw + pt;
+                if (to < 0 || to >= Tout) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(dcol + (((long long)to * B + b) * Hout + ho) * Kp + (kh * KW + kw) * Cin + c8 * 8);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xffff));
+                    acc[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
+                }
+            }
+        }
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+        o.z = (uint32_t)f32_to_bf16(acc[4]) | ((uint32_t)f32_to_bf16(acc[5]) << 16);
+        o.w = (uint32_t)f32_to_bf16(acc[6]) | ((uint32_t)f32_to_bf16(acc[7]) << 16);
+        *reinterpret_cast<uint4*>(dx + i * 8) = o;
+    }
+}
+
+// maxout / max-pool, 8 outputs per thread
+__device__ __forceinline__ uint32_t max_bf16x2(uint32_t a, uint32_t b) {      // element-wise max, first wins ties
+    const float a0 = bf16_to_f32((uint16_t)(a & 0xffff)), a1 = bf16_to_f32((uint16_t)(a >> 16));
+    const float b0 = bf16_to_f32((uint16_t)(b & 0xffff)), b1 = bf16_to_f32((uint16_t)(b >> 16));
+    return (b0 > a0 ? (b & 0xffffu) : (a & 0xffffu)) | (b1 > a1 ? (b & 0xffff0000u) : (a & 0xffff0000u));
+}
+__global__ void maxout2_fwd_vec_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long n8) {
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    uint4* y4 = reinterpret_cast<uint4*>(y);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 a = x4[2 * i], b = x4[2 * i + 1];
+        const uint32_t in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t p = in[2 * e + h];
+                const float lo = bf16_to_f32((uint16_t)(p & 0xffff)), hi = bf16_to_f32((uint16_t)(p >> 16));
+                r |= (hi > lo ? (p >> 16) : (p & 0xffffu)) << (16 * h);
+            }
+            out[e] = r;
+        }
+        y4[i] = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+__global__ void maxout2_bwd_vec_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                       uint16_t* __restrict__ dx, long long n8) {
+    const uint4* x4 = reinterpret_cast<const uint4*>(x);
+    const uint4* g4 = reinterpret_cast<const uint4*>(dy);
+    uint4* d4 = reinterpret_cast<uint4*>(dx);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const uint4 a = x4[2 * i], b = x4[2 * i + 1], g = g4[i];
+        const uint32_t in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const uint32_t gg[4] = {g.x, g.y, g.z, g.w};
+        uint32_t out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t p = in[e];
+            const float lo = bf16_to_f32((uint16_t)(p & 0xffff)), hi = bf16_to_f32((uint16_t)(p >> 16));
+            const uint32_t gv = (gg[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            out[e] = hi > lo ? (gv << 16) : gv;
+        }
+        d4[2 * i] = make_uint4(out[0], out[1], out[2], out[3]);
+        d4[2 * i + 1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+__global__ void maxpool_h_fwd_vec_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, long long R, int Hin,
+                                         int Hout, int C, int k) {
+    const int c8n = C >> 3;
+    const long long n = R * Hout * c8n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % c8n);
+        const int ho = (int)((i / c8n) % Hout);
+        const long long r = i / ((long long)c8n * Hout);
+        const uint16_t* src = x + (r * Hin) * C + c8 * 8;
+        uint4 m = *reinterpret_cast<const uint4*>(src + (long long)(ho * k) * C);
+        for (int j = 1; j < k; ++j) {
+            const int h = ho * k + j;
+            if (h >= Hin) break;
+            const uint4 v = *reinterpret_cast<const uint4*>(src + (long long)h * C);
+            m.x = max_bf16x2(m.x, v.x); m.y = max_bf16x2(m.y, v.y); m.z = max_bf16x2(m.z, v.z); m.w = max_bf16x2(m.w, v.w);
+        }
+        *reinterpret_cast<uint4*>(y + ((r * Hout + ho) * C + c8 * 8)) = m;
+    }
+}
+
+// column sums with 16-byte loads: a workgroup walks a chunk of rows; thread = (row lane, 8 columns)
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const uint16_t* __restrict__ x, long long rows, int cols, int ld,
+                                                         float* __restrict__ out) {
+    extern __shared__ float red[];                   // [row lanes][cols]
+    const int tpr = cols >> 3;                       // threads per row
+    const int rl = threadIdx.x / tpr, c8 = threadIdx.x - rl * tpr, nrl = blockDim.x / tpr;
+    const long long chunk = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < nrl)
+        for (long long r = r0 + rl; r < r1; r += nrl) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + r * ld + c8 * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xffff));
+                acc[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
+            }
+        }
+    if (rl < nrl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl * cols + c8 * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s2 = 0.f;
+        for (int q = 0; q < nrl; ++q) s2 += red[q * cols + c];
+        atomicAdd(out + c, s2);
+    }
+}
+
 }  // namespace ew
 }  // namespace asr
 
@@ -371,6 +526,14 @@ extern "C" int asr_im2col(void* stream, const void* x, int x_bf16, long long sT,
     if (Hout <= 0 || Kp < KH * KW * Cin || Tout <= 0 || Tout > T + 2 * pad_t - KW + 1) return ASR_ERR_BAD_ARG;
     const long long n = (long long)Tout * B * Hout * Kp;
     hipStream_t s = (hipStream_t)stream;
+    if (x_bf16 && (Cin & 7) == 0 && (Kp & 7) == 0 && sC == 1 && sH == Cin && sB == (long long)Hin * Cin &&
+        sT == (long long)B * Hin * Cin && ((((uintptr_t)x) | ((uintptr_t)col)) & 15) == 0 && Kp == KH * KW * Cin) {
+        const long long nv = (long long)Tout * B * Hout * KH * KW * (Cin >> 3);
+        hipLaunchKernelGGL(im2col_vec8_kernel, dim3(grid_for(nv)), dim3(kThreads), 0, s, (const uint16_t*)x, T, B, Hin, Cin, KH,
+                           KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)col);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     if (x_bf16)
         hipLaunchKernelGGL(im2col_kernel<uint16_t>, dim3(grid_for(n)), dim3(kThreads), 0, s, (const uint16_t*)x, sT, sB, sH,
                            sC, T, B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)col);
@@ -387,6 +550,12 @@ extern "C" int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin,
     const int Hout = Hin + 2 * pad_h - KH + 1;
     if (Hout <= 0 || Kp < KH * KW * Cin || Tout <= 0 || Tout > T + 2 * pad_t - KW + 1) return ASR_ERR_BAD_ARG;
     const long long n = (long long)T * B * Hin * Cin;
+    if ((Cin & 7) == 0 && (Kp & 7) == 0 && ((((uintptr_t)dcol) | ((uintptr_t)dx)) & 15) == 0) {
+        hipLaunchKernelGGL(col2im_vec8_kernel, dim3(grid_for(n >> 3)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const uint16_t*)dcol, T, B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)dx);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)dcol, T,
                        B, Hin, Cin, KH, KW, pad_h, pad_t, Tout, Hout, Kp, (uint16_t*)dx);
     ASR_LAUNCH_CHECK();
@@ -395,6 +564,12 @@ extern "C" int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin,
 
 extern "C" int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out) {
     if (!x || !y || n_out <= 0) return ASR_ERR_BAD_ARG;
+    if ((n_out & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        hipLaunchKernelGGL(maxout2_fwd_vec_kernel, dim3(grid_for(n_out >> 3)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (uint16_t*)y, n_out >> 3);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(maxout2_fwd_kernel, dim3(grid_for(n_out)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (uint16_t*)y, n_out);
     ASR_LAUNCH_CHECK();
@@ -402,6 +577,12 @@ extern "C" int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n
 }
 extern "C" int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out) {
     if (!x || !dy || !dx || n_out <= 0) return ASR_ERR_BAD_ARG;
+    if ((n_out & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+        hipLaunchKernelGGL(maxout2_bwd_vec_kernel, dim3(grid_for(n_out >> 3)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, n_out >> 3);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(maxout2_bwd_kernel, dim3(grid_for(n_out)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, n_out);
     ASR_LAUNCH_CHECK();
@@ -412,6 +593,12 @@ extern "C" int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long
     if (!x || !y || R <= 0 || Hin <= 0 || C <= 0 || k <= 0) return ASR_ERR_BAD_ARG;
     const int Hout = Hin <= k ? 1 : cdiv(Hin - k, k) + 1;     // cover_all = True, stride = k
     const long long n = R * Hout * C;
+    if ((C & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        hipLaunchKernelGGL(maxpool_h_fwd_vec_kernel, dim3(grid_for(n >> 3)), dim3(kThreads), 0, (hipStream_t)stream,
+                           (const uint16_t*)x, (uint16_t*)y, R, Hin, Hout, C, k);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(maxpool_h_fwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (uint16_t*)y, R, Hin, Hout, C, k);
     ASR_LAUNCH_CHECK();
@@ -438,6 +625,19 @@ extern "C" int asr_add_bf16(void* stream, const void* a, const void* b, void* y,
 
 extern "C" int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long rows, int cols, int ld, float* out) {
     if (!x || !out || rows <= 0 || cols <= 0 || ld < cols) return ASR_ERR_BAD_ARG;
+    if (x_bf16 && (cols & 7) == 0 && cols <= 2048 && (ld & 7) == 0 && (((uintptr_t)x) & 15) == 0) {
+        const int tpr = cols >> 3;
+        const int nrl = 256 / tpr;
+        if (nrl >= 1) {
+            int blocks = (int)((rows + 511) / 512);
+            if (blocks > 1024) blocks = 1024;
+            if (blocks < 1) blocks = 1;
+            hipLaunchKernelGGL(colsum_vec_kernel, dim3(blocks), dim3(256), sizeof(float) * nrl * cols, (hipStream_t)stream,
+                               (const uint16_t*)x, rows, cols, ld, out);
+            ASR_LAUNCH_CHECK();
+            return ASR_OK;
+        }
+    }
     int chunks = (int)((rows + 255) / 256);
     if (chunks > 128) chunks = 128;
     const dim3 g(cdiv(cols, 64), chunks);

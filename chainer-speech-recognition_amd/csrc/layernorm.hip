@@ -101,6 +101,65 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const XT* __restrict__ 
     }
 }
 
+
+// float4 variants for f32 rows with D % 4 == 0 and C % 4 == 0 (the logits path: D = C = V)
+__global__ __launch_bounds__(256) void fwd_f32x4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out, int D,
+                                                        int C) {
+    __shared__ float scratch[32];
+    const long long row = blockIdx.x;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    float4* yr = reinterpret_cast<float4*>(y + row * D);
+    const int n4 = D >> 2;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) { const float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+    const float mean = block_sum(s, scratch) / (float)D;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = xr[i];
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(q, scratch) / (float)D);
+    if (threadIdx.x == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = xr[i];
+        const int c = (i * 4) % C;
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+        yr[i] = make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y, (v.z - mean) * rstd * g.z + b.z,
+                            (v.w - mean) * rstd * g.w + b.w);
+    }
+}
+__global__ __launch_bounds__(256) void bwd_f32x4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                        const float* __restrict__ rstd_in, float* __restrict__ dx, int D,
+                                                        int C) {
+    __shared__ float scratch[32];
+    const long long row = blockIdx.x;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    const float4* gr = reinterpret_cast<const float4*>(dy + row * D);
+    float4* dr = reinterpret_cast<float4*>(dx + row * D);
+    const int n4 = D >> 2;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = xr[i], gy = gr[i];
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + (i * 4) % C);
+        const float g0 = gy.x * gm.x, g1 = gy.y * gm.y, g2 = gy.z * gm.z, g3 = gy.w * gm.w;
+        s1 += (g0 + g1) + (g2 + g3);
+        s2 += (g0 * (v.x - mean) + g1 * (v.y - mean) + g2 * (v.z - mean) + g3 * (v.w - mean)) * rstd;
+    }
+    const float m1 = block_sum(s1, scratch) / (float)D;
+    const float m2 = block_sum(s2, scratch) / (float)D;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = xr[i], gy = gr[i];
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + (i * 4) % C);
+        dr[i] = make_float4((gy.x * gm.x - m1 - (v.x - mean) * rstd * m2) * rstd, (gy.y * gm.y - m1 - (v.y - mean) * rstd * m2) * rstd,
+                            (gy.z * gm.z - m1 - (v.z - mean) * rstd * m2) * rstd, (gy.w * gm.w - m1 - (v.w - mean) * rstd * m2) * rstd);
+    }
+}
+
 }  // namespace ln
 }  // namespace asr
 
@@ -112,6 +171,11 @@ extern "C" int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* 
     if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || D <= 0 || C <= 0 || D % C) return ASR_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const dim3 g((unsigned)rows), b(256);
+    if (!x_bf16 && !y_bf16 && (D & 3) == 0 && (C & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        hipLaunchKernelGGL(fwd_f32x4_kernel, g, b, 0, s, (const float*)x, (float*)y, gamma, beta, mean, rstd, D, C);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     if (x_bf16 && y_bf16)
         hipLaunchKernelGGL((fwd_kernel<uint16_t, uint16_t>), g, b, 0, s, (const uint16_t*)x, (uint16_t*)y, gamma, beta, mean, rstd, D, C);
     else if (x_bf16)
@@ -129,7 +193,11 @@ static int launch_bwd(hipStream_t s, const void* x, const void* dy, const float*
                       const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta, long long rows, int D,
                       int C) {
     const dim3 g((unsigned)rows), b(256);
-    if (dx) {
+    if (dx && sizeof(XT) == 4 && sizeof(GT) == 4 && !dx_bf16 && (D & 3) == 0 && (C & 3) == 0 &&
+        ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0) {
+        hipLaunchKernelGGL(bwd_f32x4_kernel, g, b, 0, s, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, D, C);
+        ASR_LAUNCH_CHECK();
+    } else if (dx) {
         if (dx_bf16)
             hipLaunchKernelGGL((bwd_kernel<XT, GT, uint16_t>), g, b, 0, s, (const XT*)x, (const GT*)dy, gamma, mean, rstd, (uint16_t*)dx, D, C);
         else
