@@ -175,7 +175,7 @@ def main():
     _lib.lib()      # fail loudly if the HIP library is missing
 
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("ASR_BENCH_FORCE_COMM") == "1":      # the latter: exercise the RCCL path on one GPU
         from asr.parallel import Communicator
         comm = Communicator("nccl")
 
