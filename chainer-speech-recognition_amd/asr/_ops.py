@@ -224,7 +224,7 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
     return dx
 
 
-GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only
+GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only, 3 persistent + grouped backward
 
 
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
