@@ -165,8 +165,8 @@ __device__ __forceinline__ double lse_masked(const double* v, int mask) {
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < NK; ++j)
-        if (mask & (1 << j)) acc += expf((float)(v[j] - m));
-    return m + (double)logf(acc);
+        if (mask & (1 << j)) acc += __expf((float)(v[j] - m));     // arguments <= 0: absolute error ~1e-7
+    return m + (double)__logf(acc);                                  // acc in [1, NK]
 }
 
 template <int NK>
@@ -204,7 +204,76 @@ __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__
         return;
     }
 
-    if (!backward) {
+    const bool one_node = (int)blockDim.x >= Sp;          // one node per thread: lp is prefetched PF steps ahead in registers
+    constexpr int PF = 4;
+    if (!backward && one_node) {
+        if (threadIdx.x == 0) prev[0] = 0.0;
+        __syncthreads();
+        const int sidx = threadIdx.x;
+        const int mk = mask_s[sidx];
+        float lq[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) lq[j] = j < xl ? lpb[(size_t)j * Sp + sidx] : 0.f;
+        for (int t0 = 0; t0 < xl; t0 += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int t = t0 + j;
+                if (t < xl) {                      // uniform over the workgroup
+                    double v[NK];
+#pragma unroll
+                    for (int q = 0; q < NK; ++q) v[q] = prev[sidx - koff<NK>(q)];
+                    const double a = lse_masked<NK>(v, mk) + (double)lq[j];
+                    cur[sidx] = a;
+                    outb[(size_t)t * Sp + sidx] = a;
+                    lq[j] = t + PF < xl ? lpb[(size_t)(t + PF) * Sp + sidx] : 0.f;
+                    __syncthreads();
+                    double* tmp = prev; prev = cur; cur = tmp;
+                }
+            }
+        }
+        if (threadIdx.x == 0) {
+            double v[3] = {-INFINITY, -INFINITY, -INFINITY};
+            v[0] = prev[S - 1];
+            if (S >= 2) v[1] = prev[S - 2];
+            if (NK != 3 && S >= 3) v[2] = prev[S - 3];
+            const double tot = lse_masked<3>(v, 7);
+            total[b] = tot;
+            loss[b] = tot == -INFINITY ? 1e10f : (float)(-tot);
+        }
+    } else if (backward && one_node) {
+        const int sidx = threadIdx.x;
+        bool fin;
+        if (NK == 3) fin = (sidx == S - 1) || (sidx == S - 2 && S >= 2);
+        else fin = (sidx == S - 1) || (S >= 3 && (sidx == S - 2 || sidx == S - 3));
+        fin = fin && pl[sidx] >= 0;
+        const double bt0 = fin ? 0.0 : -INFINITY;
+        outb[(size_t)(xl - 1) * Sp + sidx] = bt0;
+        prev[sidx] = bt0 + (double)lpb[(size_t)(xl - 1) * Sp + sidx];
+        int mkd = 0;                                 // edge s -> s + k belongs to the destination's mask
+#pragma unroll
+        for (int q = 0; q < NK; ++q) mkd |= ((mask_s[sidx + koff<NK>(q)] >> q) & 1) << q;
+        __syncthreads();
+        float lq[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) lq[j] = xl - 2 - j >= 0 ? lpb[(size_t)(xl - 2 - j) * Sp + sidx] : 0.f;
+        for (int t0 = xl - 2; t0 >= 0; t0 -= PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int t = t0 - j;
+                if (t >= 0) {
+                    double v[NK];
+#pragma unroll
+                    for (int q = 0; q < NK; ++q) v[q] = prev[sidx + koff<NK>(q)];
+                    const double bt = lse_masked<NK>(v, mkd);
+                    outb[(size_t)t * Sp + sidx] = bt;
+                    cur[sidx] = bt + (double)lq[j];
+                    lq[j] = t - PF >= 0 ? lpb[(size_t)(t - PF) * Sp + sidx] : 0.f;
+                    __syncthreads();
+                    double* tmp = prev; prev = cur; cur = tmp;
+                }
+            }
+        }
+    } else if (!backward) {
         if (threadIdx.x == 0) prev[0] = 0.0;    // virtual alpha_{-1} = e_0  (asr/loss/gram_ctc.py:144)
         __syncthreads();
         for (int t = 0; t < xl; ++t) {
