@@ -21,6 +21,50 @@ from .link import grad_buffer
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+# ---------------------------------------------------------------------------------------------- side stream
+# Weight-gradient GEMMs do not feed the activation-gradient chain: they run on a second HIP stream, beside the next
+# (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
+_SIDE = {"stream": None, "enabled": True}
+
+
+def side_stream():
+    if not _SIDE["enabled"]:
+        return None
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    return _SIDE["stream"]
+
+
+def join_side_stream():
+    """called by the optimiser before it reads the gradients"""
+    if _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+
+
+class _OnSide(object):
+    """with _OnSide(tensors...): kernels launched inside go to the side stream, after everything queued so far"""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.side = side_stream()
+
+    def __enter__(self):
+        if self.side is None:
+            return self
+        self.side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 # ---------------------------------------------------------------------------------------------- layout helpers
 class _ToPhys(torch.autograd.Function):
     """any strided f32/bf16 tensor (logical order given by `perm`) -> contiguous bf16 in physical order."""
@@ -206,10 +250,13 @@ class _Dense(torch.autograd.Function):
         gy = gy.contiguous()
         if gy.dtype != BF16:
             gy = _ops.permute4(gy, (1, 1, gy.shape[0], gy.shape[1]), (0, 0, gy.shape[1], 1), BF16).reshape(gy.shape)
-        _ops.gemm_tn_acc(gy, x2, grad_buffer(W).reshape(W.shape[0], -1))
-        if b is not None:
-            _ops.colsum_acc(gy, grad_buffer(b))
         gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
+        gW = grad_buffer(W).reshape(W.shape[0], -1)
+        gb = grad_buffer(b) if b is not None else None
+        with _OnSide(gy, x2):
+            _ops.gemm_tn_acc(gy, x2, gW)
+            if gb is not None:
+                _ops.colsum_acc(gy, gb)
         return gx, None, None, None, None, None
 
 
@@ -451,17 +498,19 @@ class _GRU(torch.autograd.Function):
         gy = gy.contiguous()
         dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir, grad_buffer(b_ih).reshape(-1),
                                 grad_buffer(b_hh).reshape(-1))
-        _ops.gemm_tn_acc(dgi, x2, grad_buffer(w_ih).reshape(ndir * 3 * H, -1))
+        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None        # the only product on the critical path
+        gwih = grad_buffer(w_ih).reshape(ndir * 3 * H, -1)
         gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
-        if T > 1:
-            for d in range(ndir):
-                a = dgh[:, d * 3 * H:(d + 1) * 3 * H]
-                h = hseq16[:, d * H:(d + 1) * H]
-                if d == 0:
-                    _ops.gemm_tn_acc(a[B:], h[:-B], gwhh[d])
-                else:
-                    _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
-        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None
+        with _OnSide(dgi, dgh, x2, hseq16):
+            _ops.gemm_tn_acc(dgi, x2, gwih)
+            if T > 1:
+                for d in range(ndir):
+                    a = dgh[:, d * 3 * H:(d + 1) * 3 * H]
+                    h = hseq16[:, d * H:(d + 1) * H]
+                    if d == 0:
+                        _ops.gemm_tn_acc(a[B:], h[:-B], gwhh[d])
+                    else:
+                        _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
         return gx, None, None, None, None, None, None, None, None, None
 
 

@@ -63,6 +63,8 @@ class Optimizer(object):
                 self.communicator.begin_backward(self)
             loss.backward()
         self._ensure_flat()
+        from .functions import join_side_stream
+        join_side_stream()                  # weight-gradient GEMMs issued on the side stream
         scale = 1.0
         if self.communicator is not None:
             self.communicator.finish_backward(self)

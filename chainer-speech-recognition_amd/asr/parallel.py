@@ -79,6 +79,9 @@ class Communicator(object):
         g = self._opt._flat["G"][begin:end]
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
+            from .functions import _SIDE
+            if _SIDE["stream"] is not None:         # weight-gradient GEMMs run on the side stream
+                self._stream.wait_stream(_SIDE["stream"])
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
