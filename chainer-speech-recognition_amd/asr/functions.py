@@ -171,23 +171,8 @@ class _Conv2D(torch.autograd.Function):
         Kreal = KH * KW * Ci
         Kp = col.shape[1]
         w_is_param = isinstance(W, torch.nn.Parameter)
-        if w_is_param:
-            gW = grad_buffer(W)
-        else:       # a derived weight (weight normalisation): hand its gradient back to the tape
-            gW = torch.empty(W.shape, dtype=F32, device=gy.device)
-            _ops.fill_(gW, 0.0)
-        if Kp == Kreal and KH == 1 and KW == 1:
-            _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
-        else:
-            # weights are stored (Co, Ci, kh, kw); the GEMM produces (Co, (kh, kw, ci)): accumulate through a scratch
-            scratch = torch.empty((Co, Kp), dtype=F32, device=gy.device)
-            _ops.fill_(scratch, 0.0)
-            _ops.gemm_tn_acc(g2, col, scratch)
-            _ops.conv_weight_grad_unpack(scratch, gW)
-        if b is not None:
-            _ops.colsum_acc(g2, grad_buffer(b))
         gx = None
-        if need_dx:
+        if need_dx:         # activation gradient first: it is what the rest of the backward pass waits for
             dcol = _ops.gemm_nt(g2, w16t, None, BF16)
             if pointwise:
                 gp = dcol.reshape(T, B, Hin, Ci)
@@ -196,6 +181,29 @@ class _Conv2D(torch.autograd.Function):
             gx = gp.permute(1, 3, 2, 0)
             if xdtype == F32:
                 gx = _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
+        if w_is_param:
+            gW = grad_buffer(W)
+        else:       # a derived weight (weight normalisation): hand its gradient back to the tape
+            gW = torch.empty(W.shape, dtype=F32, device=gy.device)
+            _ops.fill_(gW, 0.0)
+        gb = grad_buffer(b) if b is not None else None
+
+        def weight_grads():
+            if Kp == Kreal and KH == 1 and KW == 1:
+                _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
+            else:
+                # weights are stored (Co, Ci, kh, kw); the GEMM produces (Co, (kh, kw, ci)): accumulate through a scratch
+                scratch = torch.empty((Co, Kp), dtype=F32, device=gy.device)
+                _ops.fill_(scratch, 0.0)
+                _ops.gemm_tn_acc(g2, col, scratch)
+                _ops.conv_weight_grad_unpack(scratch, gW)
+            if gb is not None:
+                _ops.colsum_acc(g2, gb)
+        if w_is_param:
+            with _OnSide(g2, col):
+                weight_grads()
+        else:
+            weight_grads()
         return gx, (None if w_is_param else gW), None, None, None, None, None, None, None
 
 
