@@ -551,8 +551,27 @@ __global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __r
 // operations of a wave retire in issue order, so in the plain kernel every step's hand-off loads queued behind that
 // step's HBM loads.  Bias gradients are summed over time in registers (no column-sum pass over dgi / dgh afterwards).
 constexpr int BIO_GD = 4;
+#define ASR_RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
-template <int KSW, int MTT>
+// XCD-local hand-off: counter polled with an atomic executed in the XCD's L2 (a plain load could sit in the CU's L1)
+__device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned target, unsigned* abort_word) {
+    unsigned spins = 0;
+    for (;;) {
+        unsigned seen;      // returning atomic without a scope bit: executed in L2, never served from the L1
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(counter), "v"(0u) : "memory");
+        if (seen >= target) return true;
+        ++spins;
+        if ((spins & 63u) == 0u) {
+            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
+template <int KSW, int MTT, bool LOCAL, int EPT>
 __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* __restrict__ dy,
                                                                 const float* __restrict__ gates,
                                                                 const float* __restrict__ hseq,
@@ -565,13 +584,19 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     float* opring = reinterpret_cast<float*>(part + 4 * MTT * 64);         // [BIO_GD][6: dy r z n q hp][32 rows][16 units]
     unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * 6 * 32 * 16);   // [2][3: ar az an][32 rows][8 pairs]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 32 * 8);
-    const int d = blockIdx.z, g = blockIdx.y, j0 = blockIdx.x * 16, nwg = gridDim.x;
+    // LOCAL: a 1-D grid of 8 x H/16 workgroups; the hardware deals workgroup ids round-robin over the 8 XCDs, so
+    // recurrence (d, g) = id % 8 has all its workgroups on one XCD and hands off through that XCD's L2
+    const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
+    const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    if (LOCAL && rec >= G_ * ndir) return;
+    const int d = rec / G_, g = rec % G_;
+    const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
     const int b0 = g * rows, Bl = min(rows, B - b0);      // this workgroup's batch rows (an independent recurrence)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = (3 * H) >> 5;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + (d * gridDim.y + g) * 64;
+    unsigned* counter = sync + rec * 64;
     unsigned* abort_word = sync + 1023;
     const __amdgpu_buffer_rsrc_t dghrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
@@ -580,24 +605,41 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
 
     // ---- loader: 10 f32 pieces (16 B) + 1 bf16 piece per lane and step
     // f32 piece p = lane + 64 i: array 1 + p / 128 (r, z, n, q, hp), row (p % 128) / 4, units 4 * (p % 4) .. + 3
+    // loader addresses advance by a constant stride per step (no 64-bit multiplies in the loop)
+    const float* lp[10];
+    const uint16_t* lpy;
+    long long lstride[2];       // floats per step for the gate arrays / for h
+    {
+        lstride[0] = tstep * (long long)B * ndir * 4 * H;
+        lstride[1] = tstep * (long long)B * (long long)hs;
+        const long long tp0 = d == 0 ? (long long)tfirst - 1 : (long long)tfirst + 1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2, c4 = (pp & 3) * 4;
+            const int rr = b0 + (row < Bl ? row : 0);
+            lp[i] = arr < 4 ? gates + (((size_t)tfirst * B + rr) * ndir + d) * 4 * H + arr * H + j0 + c4
+                            : hseq + (tp0 * B + rr) * (long long)hs + d * H + j0 + c4;     // not dereferenced when tp0 is outside [0, T)
+        }
+        const int row = lane >> 1, c8 = (lane & 1) * 8;
+        lpy = dy + ((size_t)tfirst * B + b0 + (row < Bl ? row : 0)) * H + j0 + c8;
+    }
+    const long long ystride = tstep * (long long)B * H;
 #define ASR_BIO_LOAD(S_, F, Y)                                                                                            \
     {                                                                                                                     \
         const int s__ = (S_);                                                                                             \
-        const long long t_ = tfirst + tstep * s__;                                                                        \
-        const long long tp_ = d == 0 ? t_ - 1 : t_ + 1;                                                                   \
-        const bool hasp = d == 0 ? t_ > 0 : t_ < T - 1;                                                                   \
+        const bool hasp = s__ < T - 1;                                                                                    \
         _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                                  \
-            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2, c4 = (pp & 3) * 4;                         \
-            const bool ok = s__ < T && row < Bl && (arr < 4 || hasp);                                                      \
-            const size_t rowi = (size_t)(ok ? t_ : 0) * B + (ok ? b0 + row : 0);                                               \
-            const float* src = arr < 4 ? gates + (rowi * ndir + d) * 4 * H + arr * H + j0 + c4                            \
-                                       : hseq + ((size_t)(ok ? tp_ : 0) * B + (ok ? b0 + row : 0)) * hs + d * H + j0 + c4;     \
-            F[i] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);                          \
+            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2;                                            \
+            const bool ok = s__ < T && row < Bl && (arr < 4 || hasp);                                                     \
+            F[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                       \
+            if (ok) F[i] = *reinterpret_cast<const float4*>(lp[i]);                                                       \
+            lp[i] += lstride[arr < 4 ? 0 : 1];                                                                            \
         }                                                                                                                 \
         {                                                                                                                 \
-            const int row = lane >> 1, c8 = (lane & 1) * 8;                                                               \
-            const bool ok = s__ < T && row < Bl;                                                                          \
-            Y = ok ? *reinterpret_cast<const uint4*>(dy + ((size_t)t_ * B + b0 + row) * H + j0 + c8) : make_uint4(0, 0, 0, 0); \
+            const int row = lane >> 1;                                                                                    \
+            Y = make_uint4(0, 0, 0, 0);                                                                                   \
+            if (s__ < T && row < Bl) Y = *reinterpret_cast<const uint4*>(lpy);                                            \
+            lpy += ystride;                                                                                               \
         }                                                                                                                 \
     }
 #define ASR_BIO_PUT(S_, F, Y)                                                                                             \
@@ -645,21 +687,47 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                                : make_uint4(0, 0, 0, 0);
         }
     }
-    const int b = (tid >> 3) & 31, jp = tid & 7, j = j0 + 2 * jp;
-    const bool act = is_compute && b < Bl;
-    float carry[2] = {0.f, 0.f};
-    float sb[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if (tid == 0) *s_abort = 0;
+    // gate phase: EPT = 2: thread (row tid / 8, unit pair tid % 8); EPT = 1 (at most 8 rows): thread (row tid / 16, unit tid % 16)
+    // (waves 2 and 3: they do not share a SIMD with the I/O waves 4 and 5)
+    const int b = EPT == 2 ? (tid >> 3) & 31 : ((tid - 128) >> 4) & 15;
+    const int u0 = EPT == 2 ? 2 * (tid & 7) : (tid & 15);      // first unit of this thread
+    const int j = j0 + (u0 & ~1);                              // the even unit of the stored pair
+    const bool act = is_compute && b < Bl && (EPT == 2 || tid >= 128);
+    constexpr int kPoller = 128;                               // first lane of wave 2
+    if (is_compute) __builtin_amdgcn_s_setprio(3);
+    float carry[EPT], sb[4][EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { carry[e] = 0.f; sb[0][e] = sb[1][e] = sb[2][e] = sb[3][e] = 0.f; }
+    if (tid == 0) {
+        *s_abort = 0;
+        if (LOCAL) {        // all workgroups of a recurrence must report the same XCD, or the launch is abandoned
+            const unsigned xcc = (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) + 1u;      // HW_REG_XCC_ID[3:0]
+            unsigned expect = 0u;
+            if (!__hip_atomic_compare_exchange_strong(sync + 960 + rec, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+                expect != xcc)
+                __hip_atomic_store(abort_word, 2u, ASR_RLX_AGENT);
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
+#ifdef ASR_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memrealtime();
+#define ASR_ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += n_ - st_last; st_last = n_; }
+#else
+#define ASR_ST(i)
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? t + 1 : t - 1;
-        float rec[2] = {0.f, 0.f};
+        float rcr[2] = {0.f, 0.f};      // [1] unused when EPT == 1
         if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
+            if (tid == kPoller && !(LOCAL ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
+                                    : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
+                *s_abort = 1;
+            ASR_ST(0)
             __syncthreads();
+            ASR_ST(1)
             if (*s_abort) break;
             if (is_compute) {
                 f32x4 acc[MTT];
@@ -674,9 +742,14 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                     for (int m = 0; m < MTT; ++m) {
                         const int row = m * 16 + (lane & 15);
                         const bool ok = ks < nks && row < Bl;
-                        const unsigned off = (unsigned)((((size_t)tn * B + b0 + (ok ? row : 0)) * gs3 + (size_t)d * 3 * H + (ok ? k : 0)) * 2);
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
-                        a[i][m].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
+                        // lanes of rows beyond the group are masked off: no request leaves the CU for them
+                        // (an out-of-range descriptor offset also returns zeros, but measured 2.3 us slower per step)
+                        a[i][m].u = make_uint4(0, 0, 0, 0);
+                        if (ok) {
+                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, LOCAL ? 0 : 16 /* sc1 */);
+                            a[i][m].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
                     }
                 }
 #pragma unroll
@@ -687,16 +760,18 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                 for (int m = 0; m < MTT; ++m)
                     part[(w * MTT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
             }
+            ASR_ST(2)
             __syncthreads();
+            ASR_ST(3)
             if (act) {
                 const int m = b >> 4, row = b & 15, pr = row & 3;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int pl = (row >> 2) * 16 + 2 * jp + e;
+                for (int e = 0; e < EPT; ++e) {
+                    const int pl = (row >> 2) * 16 + u0 + e;
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) {
                         const float4 v = part[(ww * MTT + m) * 64 + pl];
-                        rec[e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
+                        rcr[e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
                     }
                 }
             }
@@ -707,17 +782,22 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else {
-            const float* osrc = opring + (size_t)(s % BIO_GD) * 6 * 32 * 16 + b * 16 + 2 * jp;
-            const float2 dyv = *reinterpret_cast<const float2*>(osrc);
-            const float2 rv = *reinterpret_cast<const float2*>(osrc + 1 * 512), zv = *reinterpret_cast<const float2*>(osrc + 2 * 512);
-            const float2 nv = *reinterpret_cast<const float2*>(osrc + 3 * 512), qv = *reinterpret_cast<const float2*>(osrc + 4 * 512);
-            const float2 hpv = *reinterpret_cast<const float2*>(osrc + 5 * 512);
-            const float dyy[2] = {dyv.x, dyv.y}, r[2] = {rv.x, rv.y}, z[2] = {zv.x, zv.y}, n[2] = {nv.x, nv.y}, qq[2] = {qv.x, qv.y},
-                        hp[2] = {hpv.x, hpv.y};
-            uint16_t ar[2], az[2], an[2], aq[2];
+            const float* osrc = opring + (size_t)(s % BIO_GD) * 6 * 32 * 16 + b * 16 + u0;
+            float dyy[EPT], r[EPT], z[EPT], n[EPT], qq[EPT], hp[EPT];
+            if (EPT == 2) {
+                const float2 dyv = *reinterpret_cast<const float2*>(osrc);
+                const float2 rv = *reinterpret_cast<const float2*>(osrc + 1 * 512), zv = *reinterpret_cast<const float2*>(osrc + 2 * 512);
+                const float2 nv = *reinterpret_cast<const float2*>(osrc + 3 * 512), qv = *reinterpret_cast<const float2*>(osrc + 4 * 512);
+                const float2 hpv = *reinterpret_cast<const float2*>(osrc + 5 * 512);
+                dyy[0] = dyv.x; r[0] = rv.x; z[0] = zv.x; n[0] = nv.x; qq[0] = qv.x; hp[0] = hpv.x;
+                dyy[EPT - 1] = dyv.y; r[EPT - 1] = rv.y; z[EPT - 1] = zv.y; n[EPT - 1] = nv.y; qq[EPT - 1] = qv.y; hp[EPT - 1] = hpv.y;
+            } else {
+                dyy[0] = osrc[0]; r[0] = osrc[512]; z[0] = osrc[2 * 512]; n[0] = osrc[3 * 512]; qq[0] = osrc[4 * 512]; hp[0] = osrc[5 * 512];
+            }
+            uint16_t ar[EPT], az[EPT], an[EPT], aq[EPT];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float dh = dyy[e] + carry[e] + rec[e];
+            for (int e = 0; e < EPT; ++e) {
+                const float dh = dyy[e] + carry[e] + rcr[e];
                 const float dn = dh * (1.0f - z[e]);
                 const float dz = dh * (hp[e] - n[e]);
                 const float dan = dn * (1.0f - n[e] * n[e]);
@@ -731,28 +811,56 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                     sb[2][e] += bf16_to_f32(an[e]); sb[3][e] += bf16_to_f32(aq[e]);
                 }
             }
-            const unsigned pr_ = (unsigned)ar[0] | ((unsigned)ar[1] << 16), pz_ = (unsigned)az[0] | ((unsigned)az[1] << 16);
-            const unsigned pn_ = (unsigned)an[0] | ((unsigned)an[1] << 16), pq_ = (unsigned)aq[0] | ((unsigned)aq[1] << 16);
-            if (act) {
-                const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
-                __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);           // sc1 payload
-                __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
-                __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
-                unsigned* od = oring + (size_t)(s & 1) * 3 * 32 * 8 + b * 8 + jp;
-                od[0] = pr_; od[32 * 8] = pz_; od[2 * 32 * 8] = pn_;
+            unsigned pr_, pz_, pn_, pq_;
+            bool st_rz = act, st_qn = act;       // who stores which packed pair
+            if (EPT == 2) {
+                pr_ = (unsigned)ar[0] | ((unsigned)ar[EPT - 1] << 16); pz_ = (unsigned)az[0] | ((unsigned)az[EPT - 1] << 16);
+                pn_ = (unsigned)an[0] | ((unsigned)an[EPT - 1] << 16); pq_ = (unsigned)aq[0] | ((unsigned)aq[EPT - 1] << 16);
+            } else {            // neighbouring lanes hold the two units of a pair: the even lane stores r and z, the odd lane q and n
+                const unsigned m1 = (unsigned)ar[0] | ((unsigned)az[0] << 16), m2 = (unsigned)an[0] | ((unsigned)aq[0] << 16);
+                const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
+                const bool odd = u0 & 1;
+                const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;   // e: even unit, d: odd unit
+                pr_ = (e1 & 0xffffu) | (d1 << 16); pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
+                pn_ = (e2 & 0xffffu) | (d2 << 16); pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
+                st_rz = act && !odd; st_qn = act && odd;
             }
+            const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
+            unsigned* od = oring + (size_t)(s & 1) * 3 * 32 * 8 + b * 8 + (u0 >> 1);
+            if (st_rz) {
+                if (LOCAL) {        // plain stores: the line stays in this XCD's L2, where the consumers read it
+                    __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
+                } else {            // sc1 write-through payload
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
+                }
+                od[0] = pr_;
+            }
+            if (st_qn) {
+                if (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
+                else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
+                od[32 * 8] = pz_; od[2 * 32 * 8] = pn_;
+            }
+            ASR_ST(4)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ASR_ST(5)
         }
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
+        ASR_ST(6)
+        if (tid == kPoller) { if (LOCAL) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
     }
+#ifdef ASR_STAMP
+    if (blockIdx.x < 8 && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[((blockIdx.x * 6) + w) * 8 + i] = st_acc[i];
+#endif
     __syncthreads();
     if (is_storer && !*s_abort) store_step(T - 1);
     if (act && db_ih && db_hh) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float* bi = db_ih + (size_t)d * 3 * H + j + e;
-            float* bh2 = db_hh + (size_t)d * 3 * H + j + e;
+        for (int e = 0; e < EPT; ++e) {
+            float* bi = db_ih + (size_t)d * 3 * H + j0 + u0 + e;
+            float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0 + e;
             atomicAdd(bi, sb[0][e]); atomicAdd(bi + H, sb[1][e]); atomicAdd(bi + 2 * H, sb[2][e]);
             atomicAdd(bh2, sb[0][e]); atomicAdd(bh2 + H, sb[1][e]); atomicAdd(bh2 + 2 * H, sb[3][e]);
         }
@@ -1362,16 +1470,25 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         const int G = (B + rows - 1) / rows;
         if (rows <= 32 && (size_t)ndir * G * 64 <= 1023 - 64) {
             if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
-            const dim3 igrid(H / 16, G, ndir), iblock(384);
-#define ASR_BWDIO(K, M)                                                                                                   \
+            const bool local = mode == 4 && ndir * G <= 8;
+            const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
+#define ASR_BWDIO(K, M, E)                                                                                                 \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, M>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL((bwd_persistent_io_kernel<K, M>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
-                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                    \
-                           (unsigned*)sync_ws, T, B, H, ndir, rows);                                                              \
+        if (local) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, M, true, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, M, true, E>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
+                               (unsigned*)sync_ws, T, B, H, ndir, rows);                                                          \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, M, false, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, M, false, E>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
+                               (unsigned*)sync_ws, T, B, H, ndir, rows);                                                          \
+        }                                                                                                                 \
     } while (0)
-            if (rows <= 16) { if (ksw <= 2) ASR_BWDIO(2, 1); else if (ksw <= 6) ASR_BWDIO(6, 1); else ASR_BWDIO(12, 1); }
-            else            { if (ksw <= 2) ASR_BWDIO(2, 2); else if (ksw <= 6) ASR_BWDIO(6, 2); else ASR_BWDIO(12, 2); }
+            if (rows <= 8)       { if (ksw <= 2) ASR_BWDIO(2, 1, 1); else if (ksw <= 6) ASR_BWDIO(6, 1, 1); else ASR_BWDIO(12, 1, 1); }
+            else if (rows <= 16) { if (ksw <= 2) ASR_BWDIO(2, 1, 2); else if (ksw <= 6) ASR_BWDIO(6, 1, 2); else ASR_BWDIO(12, 1, 2); }
+            else                 { if (ksw <= 2) ASR_BWDIO(2, 2, 2); else if (ksw <= 6) ASR_BWDIO(6, 2, 2); else ASR_BWDIO(12, 2, 2); }
 #undef ASR_BWDIO
             ASR_LAUNCH_CHECK();
             return ASR_OK;

@@ -178,7 +178,8 @@ def test_layernorm(device, B, C, H, T):
     np.testing.assert_allclose(dbeta.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])   # 1: one launch per time step, 2: persistent (in-launch hand-off), 3: + grouped backward
+# 1: one launch per time step, 2: persistent (in-launch hand-off), 3: + grouped backward, 4: + XCD-local backward hand-off
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("T,B,I,H,ndir", [(12, 4, 64, 64, 2), (9, 5, 96, 128, 1), (20, 32, 64, 512, 2), (7, 40, 32, 64, 2),
                                           (150, 32, 32, 256, 2), (40, 19, 48, 128, 2), (30, 7, 32, 384, 1)])
 def test_gru_step_kernels(device, T, B, I, H, ndir, mode):

@@ -15,7 +15,8 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
     bhh = torch.zeros(ndir * 3 * H, device=dev)
     dy = torch.randn(T * B, H, generator=g).to(dev).to(torch.bfloat16)
     dbi = torch.zeros(ndir * 3 * H, device=dev); dbh = torch.zeros(ndir * 3 * H, device=dev)
-    for mode in (1, 2):
+    ref = None
+    for mode in (1, 2, 4):
         _ops.GRU_MODE[0] = mode
         res = {}
         for name in ("fwd", "bwd"):
@@ -29,6 +30,10 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
             e1.record(); torch.cuda.synchronize()
             res[name + "_us_per_step"] = e0.elapsed_time(e1) / iters / T * 1e3
         _ops.gru_check_sync()
+        out = _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh); torch.cuda.synchronize()
+        _ops.gru_check_sync()
+        if ref is None: ref = [o.float().clone() for o in out[:2]]
+        else: res['maxdiff_vs_step'] = max(float((o.float() - r).abs().max()) for o, r in zip(out[:2], ref))
         print(json.dumps(dict(mode=mode, T=T, B=B, H=H, **res)))
     _ops.GRU_MODE[0] = 0
 
