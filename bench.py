@@ -236,10 +236,13 @@ def main():
     log("%.2f ms/step, %.1f utt/s" % (ms_per_step, value))
     if not args.no_census:
         log("kernel census")
+        from asr import functions as asr_functions
         census = Census()
         census.wrap(_ops)
+        asr_functions._SIDE["enabled"] = False        # one stream for this extra step: per-op times without overlap
         step()
         tot = census.totals()
+        asr_functions._SIDE["enabled"] = True
         census.unwrap()
         ctc = time_ctc(_lib, _ops, T, B, V, labels.shape[1], x_len, l_len, labels, dev)
         tot["ctc_forward"] = (ctc["ctc_forward"], 1)
@@ -258,9 +261,19 @@ def main():
         fwd_bytes = T * B * (6 * H * 4 + 2 * H * 2 * 2 + 2 * H * 4 + 8 * H * 4) + 2 * 3 * H * H * 2
         bwd_bytes = T * B * (H * 2 + 8 * H * 4 + 2 * H * 4 + 6 * H * 2 + 6 * H * 2 * 2) + 2 * 3 * H * H * 2
         alg = 0.5 * (fwd_bytes + bwd_bytes)
-        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_kernel / bwd_persistent_kernel (one launch per layer)",
+        # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
+        # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            ks = json.load(open(pmc_path))["kernels"]
+            sel = [v for k, v in ks.items() if "gru::fwd_group_kernel" in k or "gru::bwd_persistent_io_kernel" in k]
+            if sel:
+                traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
+                traffic_src = "profiles/r01_pmc_traffic.json"
+        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_group_kernel / bwd_persistent_io_kernel (one launch per layer)",
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                           "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "ms_per_launch": per_launch_s * 1e3, "launches_per_step": launches,
                            "us_per_time_step": per_launch_s * 1e6 / T, "algorithmic_bytes_per_launch": alg,
                            "note": "latency-bound recurrence (8000 dependent steps per train step): neither roofline binds, "
