@@ -571,6 +571,24 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
     }
 }
 
+// XCD-local hand-off is a speed-up, not an assumption: the workgroups of a recurrence agree at kernel start whether they
+// all sit on one XCD (HIP promises no placement).  Each registers its HW_REG_XCC_ID; after all have arrived every one
+// reads the same verdict: local (plain payload stores that stay in the XCD's L2 + a counter kept by L2 atomics) or the
+// placement-free protocol (sc1 write-through stores + agent-scope counter).  Payload loads are sc1 either way (they
+// bypass the L1 and are served by the L2).  Control words: sync[960 + r] XCC id, [976 + r] mismatch, [992 + r] arrivals.
+__device__ __forceinline__ int decide_local(unsigned* sync, int rec, int nwg, unsigned* abort_word, int forge) {
+    unsigned xcc = (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) + 1u;      // HW_REG_XCC_ID[3:0]
+    if (forge) xcc = 1u + (blockIdx.x >> 3 & 1u);                              // test hook: pretend a split placement
+    unsigned expect = 0u;
+    if (!__hip_atomic_compare_exchange_strong(sync + 960 + rec, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+        expect != xcc)
+        __hip_atomic_store(sync + 976 + rec, 1u, ASR_RLX_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(sync + 992 + rec, 1u, ASR_RLX_AGENT);
+    if (!wait_counter(sync + 992 + rec, (unsigned)nwg, abort_word)) return -1;
+    return __hip_atomic_load(sync + 976 + rec, ASR_RLX_AGENT) == 0u ? 1 : 0;
+}
+
 template <int KSW, int MTT, bool LOCAL, int EPT>
 __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* __restrict__ dy,
                                                                 const float* __restrict__ gates,
@@ -578,7 +596,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                                                                 const uint16_t* __restrict__ whhT,
                                                                 uint16_t* __restrict__ dgi, uint16_t* dgh,
                                                                 float* __restrict__ db_ih, float* __restrict__ db_hh,
-                                                                unsigned* sync, int T, int B, int H, int ndir, int rows) {
+                                                                unsigned* sync, int T, int B, int H, int ndir, int rows, int forge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MTT][64]
     float* opring = reinterpret_cast<float*>(part + 4 * MTT * 64);         // [BIO_GD][6: dy r z n q hp][32 rows][16 units]
@@ -700,16 +718,15 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     for (int e = 0; e < EPT; ++e) { carry[e] = 0.f; sb[0][e] = sb[1][e] = sb[2][e] = sb[3][e] = 0.f; }
     if (tid == 0) {
         *s_abort = 0;
-        if (LOCAL) {        // all workgroups of a recurrence must report the same XCD, or the launch is abandoned
-            const unsigned xcc = (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) + 1u;      // HW_REG_XCC_ID[3:0]
-            unsigned expect = 0u;
-            if (!__hip_atomic_compare_exchange_strong(sync + 960 + rec, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
-                expect != xcc)
-                __hip_atomic_store(abort_word, 2u, ASR_RLX_AGENT);
+        s_abort[1] = 0;
+        if (LOCAL) {
+            const int v = decide_local(sync, rec, nwg, abort_word, forge);
+            if (v < 0) *s_abort = 1; else s_abort[1] = v;
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    const bool local = LOCAL && s_abort[1] != 0;
 
 #ifdef ASR_STAMP
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memrealtime();
@@ -722,7 +739,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         const int tn = d == 0 ? t + 1 : t - 1;
         float rcr[2] = {0.f, 0.f};      // [1] unused when EPT == 1
         if (s > 0) {
-            if (tid == kPoller && !(LOCAL ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
+            if (tid == kPoller && !(local ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
                                     : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
                 *s_abort = 1;
             ASR_ST(0)
@@ -747,7 +764,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                         a[i][m].u = make_uint4(0, 0, 0, 0);
                         if (ok) {
                             const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, LOCAL ? 0 : 16 /* sc1 */);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1: bypasses the L1, served by the L2 */);
                             a[i][m].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
@@ -828,7 +845,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
             const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
             unsigned* od = oring + (size_t)(s & 1) * 3 * 32 * 8 + b * 8 + (u0 >> 1);
             if (st_rz) {
-                if (LOCAL) {        // plain stores: the line stays in this XCD's L2, where the consumers read it
+                if (local) {        // plain stores: the line stays in this XCD's L2, where the consumers read it
                     __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
                 } else {            // sc1 write-through payload
@@ -838,7 +855,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                 od[0] = pr_;
             }
             if (st_qn) {
-                if (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
+                if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
                 else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
                 od[32 * 8] = pz_; od[2 * 32 * 8] = pn_;
             }
@@ -848,7 +865,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         }
         __syncthreads();
         ASR_ST(6)
-        if (tid == kPoller) { if (LOCAL) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
+        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
     }
 #ifdef ASR_STAMP
     if (blockIdx.x < 8 && lane == 0)
@@ -867,6 +884,202 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     }
 #undef ASR_BIO_LOAD
 #undef ASR_BIO_PUT
+}
+
+// Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
+// most 8 rows, 4 compute waves (K = H split in 4) + loader (gi ring) + storer (f32 state and the four saved gate arrays,
+// one step behind).  The exchanged payload is the bf16 h row (hseq16), written sc1 by the gate threads themselves.
+template <int KSW, bool LOCAL>
+__global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+                                                                const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                                uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
+                                                                int T, int B, int H, int ndir, int rows, int forge) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [4 waves][3 gates][64]
+    float* opring = reinterpret_cast<float*>(part + 4 * 3 * 64);                      // [BIO_GD][3 gates][8 rows][16 units]
+    float* oring = opring + BIO_GD * 3 * 8 * 16;                                      // [2][5: h r z n q][8 rows][16 units]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 8 * 16);
+    const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
+    const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    if (LOCAL && rec >= G_ * ndir) return;
+    const int d = rec / G_, g = rec % G_;
+    const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
+    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
+    const int nks = H >> 5;
+    const size_t hs = (size_t)ndir * H;
+    unsigned* counter = sync + rec * 64;
+    unsigned* abort_word = sync + 1023;
+    const __amdgpu_buffer_rsrc_t h16rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
+    const long long tstep = d == 0 ? 1 : -1;
+    const int tfirst = d == 0 ? 0 : T - 1;
+
+    // loader: 3 gates x 8 rows x 64 B = 96 pieces of 16 B: piece p = lane + 64 i (i < 2, p < 96): gate p / 32, row (p % 32) / 4
+    const float* lp[2];
+    const long long lstride = tstep * (long long)B * 3 * (long long)hs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pp = lane + 64 * i, gg = pp >> 5, row = (pp & 31) >> 2, c4 = (pp & 3) * 4;
+        lp[i] = gi + ((size_t)tfirst * B + b0 + (row < Bl ? row : 0)) * (3 * hs) + (size_t)d * 3 * H + (gg < 3 ? gg : 0) * H + j0 + c4;
+    }
+    float4 fa[2];
+#define ASR_FIO_LOAD(S_)                                                                                                  \
+    {                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
+            const int pp = lane + 64 * i, row = (pp & 31) >> 2;                                                            \
+            fa[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                      \
+            if ((S_) < T && pp < 96 && row < Bl) fa[i] = *reinterpret_cast<const float4*>(lp[i]);                          \
+            lp[i] += lstride;                                                                                             \
+        }                                                                                                                 \
+    }
+#define ASR_FIO_PUT(S_)                                                                                                   \
+    {                                                                                                                     \
+        float* dst = opring + (size_t)((S_) % BIO_GD) * 3 * 8 * 16;                                                       \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
+            const int pp = lane + 64 * i;                                                                                 \
+            if (pp < 96) *reinterpret_cast<float4*>(dst + pp * 4) = fa[i];                                                \
+        }                                                                                                                 \
+    }
+    // storer: 5 arrays x 8 rows x 64 B = 160 pieces: piece p = lane + 64 i (i < 3, p < 160): array p / 32, row (p % 32) / 4
+    auto store_step = [&](int sp) {
+        const long long tq = tfirst + tstep * sp;
+        const float* src = oring + (size_t)(sp & 1) * 5 * 8 * 16;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pp = lane + 64 * i, arr = pp >> 5, row = (pp & 31) >> 2, c4 = (pp & 3) * 4;
+            if (pp < 160 && row < Bl) {
+                const size_t rowi = (size_t)tq * B + b0 + row;
+                float* dst = arr == 0 ? hseq + rowi * hs + (size_t)d * H + j0 + c4
+                                      : gates + (rowi * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c4;
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src + pp * 4);
+            }
+        }
+    };
+    if (is_loader) {
+        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) {
+            ASR_FIO_LOAD(s0)
+            ASR_FIO_PUT(s0)
+        }
+        ASR_FIO_LOAD(BIO_GD - 1)
+    }
+    Frag bb[KSW][3];
+    if (is_compute) {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+            const int ks = i * 4 + w;
+            const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg)
+                bb[i][gg].u = ks < nks ? *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + gg) * H + j0 + (lane & 15)) * H + k)
+                                       : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // gate phase on waves 2 and 3 (no I/O wave on their SIMDs): thread (row (tid - 128) / 16, unit tid % 16)
+    const int b = ((tid - 128) >> 4) & 7, u = tid & 15;
+    const bool act = tid >= 128 && tid < 256 && b < Bl;
+    constexpr int kPoller = 128;
+    float bh[3] = {0.f, 0.f, 0.f};
+    if (tid >= 128 && tid < 256) {
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg) bh[gg] = bhh[(d * 3 + gg) * H + j0 + u];
+    }
+    float hprev = 0.f;
+    if (tid == 0) {
+        *s_abort = 0;
+        s_abort[1] = 0;
+        if (LOCAL) {
+            const int v = decide_local(sync, rec, nwg, abort_word, forge);
+            if (v < 0) *s_abort = 1; else s_abort[1] = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    const bool local = LOCAL && s_abort[1] != 0;
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        float gh[3] = {bh[0], bh[1], bh[2]};
+        if (s > 0) {
+            if (tid == kPoller && !(local ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
+                                          : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
+                *s_abort = 1;
+            __syncthreads();
+            if (*s_abort) break;
+            if (is_compute) {
+                f32x4 acc[3];
+#pragma unroll
+                for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                Frag a[KSW];
+#pragma unroll
+                for (int i = 0; i < KSW; ++i) {
+                    const int ks = i * 4 + w;
+                    const int k = ks * 32 + 8 * (lane >> 4);
+                    const int row = lane & 15;
+                    a[i].u = make_uint4(0, 0, 0, 0);
+                    if (ks < nks && row < Bl) {       // lanes of the empty MFMA rows are masked off
+                        const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + k) * 2);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1: bypasses the L1, served by the L2 */);
+                        a[i].u = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KSW; ++i)
+#pragma unroll
+                    for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][gg].v, acc[gg], 0, 0, 0);
+#pragma unroll
+                for (int gg = 0; gg < 3; ++gg)
+                    part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
+            }
+            __syncthreads();
+            if (act) {
+                const int pr = b & 3, pl = (b >> 2) * 16 + u;
+#pragma unroll
+                for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const float4 v = part[(ww * 3 + gg) * 64 + pl];
+                        gh[gg] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
+                    }
+            }
+        }
+        if (is_loader) {
+            ASR_FIO_PUT(s + BIO_GD - 1)
+            ASR_FIO_LOAD(s + BIO_GD)
+        } else if (is_storer) {
+            if (s > 0) store_step(s - 1);
+        } else if (tid >= 128) {
+            const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 8 * 16 + b * 16 + u;
+            const float gr = osrc[0], gz = osrc[128], gn = osrc[256];
+            const float r = sigmoidf_(gr + gh[0]);
+            const float z = sigmoidf_(gz + gh[1]);
+            const float n = tanhf_(gn + r * gh[2]);
+            const float h = (1.0f - z) * n + z * hprev;
+            hprev = h;
+            const unsigned mine = (unsigned)f32_to_bf16(h);
+            const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+            if (act) {
+                if (!(u & 1)) {
+                    const unsigned packed = mine | (other << 16);
+                    const size_t o = ((size_t)t * B + b0 + b) * hs + (size_t)d * H + j0 + u;
+                    if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
+                    else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
+                }
+                float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
+                od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
+    }
+    __syncthreads();
+    if (is_storer && !*s_abort) store_step(T - 1);
+#undef ASR_FIO_LOAD
+#undef ASR_FIO_PUT
 }
 
 // ================================================================================================ grouped persistent form
@@ -1380,7 +1593,27 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
-    if (grouped) {
+    const int Gio = (B + 7) / 8;
+    if (persist && mode != 3 && H % 16 == 0 && (size_t)ndir * Gio * 64 <= 960) {
+        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
+        const int forge = mode == 7;
+        const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
+#define ASR_FWDIO(K)                                                                                                      \
+    do {                                                                                                                  \
+        if (local) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true>), igrid, iblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, 8, forge);                     \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, false>), igrid, iblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, 8, 0);                         \
+        }                                                                                                                 \
+    } while (0)
+        if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
+#undef ASR_FWDIO
+    } else if (grouped) {
         const int G = (B + RG - 1) / RG;
         if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 ggrid(H / UW, G, ndir), gblock(640);
@@ -1463,32 +1696,31 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
 #undef ASR_BWDG
         return ASR_OK;
     }
-    if (persist && db_ih && db_hh && H % 16 == 0) {
-        // batch rows split into independent recurrences of `rows` rows each (one 16-row MFMA tile when rows <= 16)
+    if (persist && mode != 3 && db_ih && db_hh && H % 16 == 0) {
+        // batch rows split into independent recurrences of 8 rows (half of one 16-row MFMA tile)
         // measured at T=1000, H=512, B=32: 32 rows 6.3 us/step, 16 rows 4.6, 8 rows 4.2
-        const int rows = B <= 32 ? 8 : 16;
+        const int rows = 8;
         const int G = (B + rows - 1) / rows;
-        if (rows <= 32 && (size_t)ndir * G * 64 <= 1023 - 64) {
+        if ((size_t)ndir * G * 64 <= 960) {
             if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
-            const bool local = mode == 4 && ndir * G <= 8;
+            const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
+            const int forge = mode == 7;
             const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
-#define ASR_BWDIO(K, M, E)                                                                                                 \
+#define ASR_BWDIO(K)                                                                                                      \
     do {                                                                                                                  \
         if (local) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, M, true, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, M, true, E>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, 1, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, 1, true, 1>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
-                               (unsigned*)sync_ws, T, B, H, ndir, rows);                                                          \
+                               (unsigned*)sync_ws, T, B, H, ndir, rows, forge);                                                   \
         } else {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, M, false, E>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, M, false, E>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, 1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, 1, false, 1>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
-                               (unsigned*)sync_ws, T, B, H, ndir, rows);                                                          \
+                               (unsigned*)sync_ws, T, B, H, ndir, rows, 0);                                                       \
         }                                                                                                                 \
     } while (0)
-            if (rows <= 8)       { if (ksw <= 2) ASR_BWDIO(2, 1, 1); else if (ksw <= 6) ASR_BWDIO(6, 1, 1); else ASR_BWDIO(12, 1, 1); }
-            else if (rows <= 16) { if (ksw <= 2) ASR_BWDIO(2, 1, 2); else if (ksw <= 6) ASR_BWDIO(6, 1, 2); else ASR_BWDIO(12, 1, 2); }
-            else                 { if (ksw <= 2) ASR_BWDIO(2, 2, 2); else if (ksw <= 6) ASR_BWDIO(6, 2, 2); else ASR_BWDIO(12, 2, 2); }
+            if (ksw <= 2) ASR_BWDIO(2); else if (ksw <= 6) ASR_BWDIO(6); else ASR_BWDIO(12);
 #undef ASR_BWDIO
             ASR_LAUNCH_CHECK();
             return ASR_OK;

@@ -144,10 +144,12 @@ int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, floa
  * db_ih / db_hh (ndir, 3H) f32 or NULL: bias gradients, ACCUMULATED (sum over all rows of dgi / dgh).
  * sync_ws: asr_gru_sync_bytes(B, H, ndir) bytes of device memory (control words + the in-launch exchange
  * buffer, zeroed by the call) enabling the persistent
- * one-launch-per-layer form; mode 0 = automatic, 1 = one launch per time step, 2 = persistent or error,
- * 3 = persistent with the 32-unit grouped backward kernel, 4 = persistent with the backward hand-off kept inside
- * one XCD's L2 (workgroup ids are dealt round-robin over the 8 XCDs; every workgroup verifies its XCC id and the
- * launch is abandoned with ((int*)sync_ws)[1023] == 2 when the placement does not hold).
+ * one-launch-per-layer form.  mode: 0 = automatic (persistent when B <= 32, else one launch per step),
+ * 1 = one launch per time step, 2 = persistent with the placement-free hand-off only (sc1 write-through + agent-scope
+ * counter), 3 = the 32-unit grouped kernels, 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
+ * find themselves on one XCD (what mode 0 selects; decided inside the launch, falls back to the mode-2 protocol
+ * otherwise), 7 = mode 4 with a forged split placement (test hook for that fall-back).  Modes >= 2 return
+ * ASR_ERR_UNSUPPORTED instead of falling back to mode 1.
  * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).
  */
 size_t asr_gru_sync_bytes(int B, int H, int ndir);

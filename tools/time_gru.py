@@ -16,7 +16,8 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
     dy = torch.randn(T * B, H, generator=g).to(dev).to(torch.bfloat16)
     dbi = torch.zeros(ndir * 3 * H, device=dev); dbh = torch.zeros(ndir * 3 * H, device=dev)
     ref = None
-    for mode in (1, 2, 4):
+    fref = None
+    for mode in (1, 2, 3, 4, 7):
         _ops.GRU_MODE[0] = mode
         res = {}
         for name in ("fwd", "bwd"):
@@ -32,6 +33,9 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
         _ops.gru_check_sync()
         out = _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh); torch.cuda.synchronize()
         _ops.gru_check_sync()
+        fo = _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir); torch.cuda.synchronize(); _ops.gru_check_sync()
+        if fref is None: fref = [o.float().clone() for o in fo]
+        else: res['fwd_maxdiff'] = max(float((o.float() - r).abs().max()) for o, r in zip(fo, fref))
         if ref is None: ref = [o.float().clone() for o in out[:2]]
         else: res['maxdiff_vs_step'] = max(float((o.float() - r).abs().max()) for o, r in zip(out[:2], ref))
         print(json.dumps(dict(mode=mode, T=T, B=B, H=H, **res)))
