@@ -781,15 +781,12 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
             __syncthreads();
             ASR_ST(3)
             if (act) {
-                const int m = b >> 4, row = b & 15, pr = row & 3;
+                const int m = b >> 4, row = b & 15;
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) {
-                    const int pl = (row >> 2) * 16 + u0 + e;
+                for (int e = 0; e < EPT; ++e) {      // scalar reads (see fwd_persistent_io_kernel)
+                    const float* pf = reinterpret_cast<const float*>(part) + ((row >> 2) * 16 + u0 + e) * 4 + (row & 3);
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        const float4 v = part[(ww * MTT + m) * 64 + pl];
-                        rcr[e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
-                    }
+                    for (int ww = 0; ww < 4; ++ww) rcr[e] += pf[(ww * MTT + m) * 256];
                 }
             }
         }
@@ -884,6 +881,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     }
 #undef ASR_BIO_LOAD
 #undef ASR_BIO_PUT
+#undef ASR_ST
 }
 
 // Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
@@ -998,6 +996,12 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     const bool local = LOCAL && s_abort[1] != 0;
+#ifdef ASR_STAMP
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#define ASR_ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_last; st_last = n_; }
+#else
+#define ASR_ST(i)
+#endif
 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
@@ -1007,7 +1011,9 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
             if (tid == kPoller && !(local ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
                                           : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
                 *s_abort = 1;
+            ASR_ST(0)
             __syncthreads();
+            ASR_ST(1)
             if (*s_abort) break;
             if (is_compute) {
                 f32x4 acc[3];
@@ -1026,6 +1032,10 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                         a[i].u = make_uint4(v[0], v[1], v[2], v[3]);
                     }
                 }
+#ifdef ASR_STAMP
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                ASR_ST(2)
 #pragma unroll
                 for (int i = 0; i < KSW; ++i)
 #pragma unroll
@@ -1034,17 +1044,19 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                 for (int gg = 0; gg < 3; ++gg)
                     part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
             }
+            ASR_ST(3)
             __syncthreads();
+            ASR_ST(4)
             if (act) {
-                const int pr = b & 3, pl = (b >> 2) * 16 + u;
+                // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
+                // nest of divergent branches around narrow reads (measured 0.95 us per step)
+                const float* pf = reinterpret_cast<const float*>(part) + ((b >> 2) * 16 + u) * 4 + (b & 3);
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        const float4 v = part[(ww * 3 + gg) * 64 + pl];
-                        gh[gg] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
-                    }
+                    for (int ww = 0; ww < 4; ++ww) gh[gg] += pf[(ww * 3 + gg) * 256];
             }
+            ASR_ST(9)
         }
         if (is_loader) {
             ASR_FIO_PUT(s + BIO_GD - 1)
@@ -1054,11 +1066,16 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         } else if (tid >= 128) {
             const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 8 * 16 + b * 16 + u;
             const float gr = osrc[0], gz = osrc[128], gn = osrc[256];
+#ifdef ASR_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            ASR_ST(10)
             const float r = sigmoidf_(gr + gh[0]);
             const float z = sigmoidf_(gz + gh[1]);
             const float n = tanhf_(gn + r * gh[2]);
             const float h = (1.0f - z) * n + z * hprev;
             hprev = h;
+            ASR_ST(5)
             const unsigned mine = (unsigned)f32_to_bf16(h);
             const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
             if (act) {
@@ -1071,11 +1088,18 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                 float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
                 od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
             }
+            ASR_ST(6)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ASR_ST(7)
         }
         __syncthreads();
+        ASR_ST(8)
         if (tid == kPoller) { if (local) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
     }
+#ifdef ASR_STAMP
+    if (blockIdx.x < 8 && lane == 0)
+        for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[((blockIdx.x * 6) + w) * 12 + i] = st_acc[i];
+#endif
     __syncthreads();
     if (is_storer && !*s_abort) store_step(T - 1);
 #undef ASR_FIO_LOAD

@@ -26,3 +26,6 @@ for wg in (0, 1):
     for w in range(6):
         print("wg", wg, "wave", w, " ".join("%s=%.2f" % (n, st[wg, w, i].item() / 100.0 / T) for i, n in enumerate(names[:7])),
               "sum=%.2f" % (st[wg, w].sum().item() / 100.0 / T))
+
+w32 = _ops.LAST_SYNC[0].cpu().view(torch.uint8)[:4096].view(torch.int32)
+print("placement words: xcc", w32[960:968].tolist(), "mismatch", w32[976:984].tolist(), "arrivals", w32[992:1000].tolist())
