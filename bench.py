@@ -239,7 +239,10 @@ def main():
         from asr import functions as asr_functions
         census = Census()
         census.wrap(_ops)
-        asr_functions._SIDE["enabled"] = False        # one stream for this extra step: per-op times without overlap
+        asr_functions._SIDE["enabled"] = False        # one stream for these extra steps: per-op times without overlap
+        step()                                        # settles the caching allocator in the single-stream pattern
+        torch.cuda.synchronize()
+        census.events = []
         step()
         tot = census.totals()
         asr_functions._SIDE["enabled"] = True
