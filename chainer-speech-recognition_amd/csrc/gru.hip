@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kSpinLimit = 1u << 19;
 constexpr int kPersistLds = 96 * 1024;
+constexpr size_t kShardBytes = 16 * 8 * 128;      // 16 recurrences x 8 shards x one 128-B line
 
 #define ASR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -571,6 +572,44 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
     }
 }
 
+// The step counter of a recurrence is kept in NSH shards on lines of their own (workgroup i adds to shard i % NSH): atomics on
+// one address serialise in the L2, 32 of them per step were ~0.3 us of the chain.  The poller reads all four (sc1 loads:
+// they bypass the L1 and are served by the L2, so they also see the L2-scope adds of the XCD-local form).
+constexpr int NSH = 4;          // shards per recurrence (8 measured no better)
+__device__ __forceinline__ unsigned* shard_base(unsigned* sync, int rec) {
+    return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sync) + 4096) + rec * NSH * 32;
+}
+template <bool L2ATOMIC>
+__device__ __forceinline__ bool wait_shards(unsigned* base, int nwg, unsigned s, unsigned* abort_word) {
+    unsigned spins = 0;
+    for (;;) {
+        unsigned c[NSH];
+#pragma unroll
+        for (int i = 0; i < NSH; ++i) {
+            if (L2ATOMIC)       // XCD-local form: returning atomics without a scope bit, executed in the L2 that holds the counters
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=&v"(c[i]) : "v"(base + i * 32), "v"(0u) : "memory");
+            else
+                c[i] = __hip_atomic_load(base + i * 32, ASR_RLX_AGENT);
+        }
+        if (L2ATOMIC) {
+#pragma unroll
+            for (int i = 0; i < NSH; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(c[i]) :: "memory");
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NSH; ++i) ok = ok && c[i] >= (unsigned)((nwg + NSH - 1 - i) / NSH) * s;
+        if (ok) return true;
+        ++spins;
+        if ((spins & 63u) == 0u) {
+            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+                return false;
+            }
+        }
+    }
+}
+
 // XCD-local hand-off is a speed-up, not an assumption: the workgroups of a recurrence agree at kernel start whether they
 // all sit on one XCD (HIP promises no placement).  Each registers its HW_REG_XCC_ID; after all have arrived every one
 // reads the same verdict: local (plain payload stores that stay in the XCD's L2 + a counter kept by L2 atomics) or the
@@ -614,7 +653,8 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = (3 * H) >> 5;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + rec * 64;
+    unsigned* shards = shard_base(sync, rec);
+    unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
     unsigned* abort_word = sync + 1023;
     const __amdgpu_buffer_rsrc_t dghrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
@@ -739,8 +779,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         const int tn = d == 0 ? t + 1 : t - 1;
         float rcr[2] = {0.f, 0.f};      // [1] unused when EPT == 1
         if (s > 0) {
-            if (tid == kPoller && !(local ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
-                                    : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
+            if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
             ASR_ST(0)
             __syncthreads();
@@ -862,7 +901,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         }
         __syncthreads();
         ASR_ST(6)
-        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
+        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT); }
     }
 #ifdef ASR_STAMP
     if (blockIdx.x < 8 && lane == 0)
@@ -907,7 +946,8 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = H >> 5;
     const size_t hs = (size_t)ndir * H;
-    unsigned* counter = sync + rec * 64;
+    unsigned* shards = shard_base(sync, rec);
+    unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
     unsigned* abort_word = sync + 1023;
     const __amdgpu_buffer_rsrc_t h16rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
@@ -1008,8 +1048,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         const int tp = d == 0 ? t - 1 : t + 1;
         float gh[3] = {bh[0], bh[1], bh[2]};
         if (s > 0) {
-            if (tid == kPoller && !(local ? wait_counter_l2(counter, (unsigned)nwg * (unsigned)s, abort_word)
-                                          : wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)))
+            if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
             ASR_ST(0)
             __syncthreads();
@@ -1094,7 +1133,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         }
         __syncthreads();
         ASR_ST(8)
-        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT); }
+        if (tid == kPoller) { if (local) __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT); }
     }
 #ifdef ASR_STAMP
     if (blockIdx.x < 8 && lane == 0)
@@ -1583,7 +1622,8 @@ using namespace asr::gru;
 
 extern "C" size_t asr_gru_sync_bytes(int B, int H, int ndir) {
     const size_t G = (size_t)(B + RG - 1) / RG;
-    return 4096 + (size_t)ndir * G * 2 * RG * (3 * (size_t)H / 2) * 8;
+    const size_t exch = (size_t)ndir * G * 2 * RG * (3 * (size_t)H / 2) * 8;       // granule exchange area of the grouped kernels
+    return 4096 + (exch > kShardBytes ? exch : kShardBytes);                      // or the sharded step counters
 }
 
 static int check_dims(int T, int B, int H, int ndir) {
@@ -1618,8 +1658,8 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
     const int Gio = (B + 7) / 8;
-    if (persist && mode != 3 && H % 16 == 0 && (size_t)ndir * Gio * 64 <= 960) {
-        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
+        if (hipMemsetAsync(sync_ws, 0, 4096 + kShardBytes, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
         const int forge = mode == 7;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
@@ -1725,8 +1765,8 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         // measured at T=1000, H=512, B=32: 32 rows 6.3 us/step, 16 rows 4.6, 8 rows 4.2
         const int rows = 8;
         const int G = (B + rows - 1) / rows;
-        if ((size_t)ndir * G * 64 <= 960) {
-            if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (ndir * G <= 16) {
+            if (hipMemsetAsync(sync_ws, 0, 4096 + kShardBytes, st) != hipSuccess) return ASR_ERR_LAUNCH;
             const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
             const int forge = mode == 7;
             const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
