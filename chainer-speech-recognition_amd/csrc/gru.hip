@@ -572,6 +572,16 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
     }
 }
 
+// rows r and r + 8 of every 16-lane row swap places (DPP row_ror:8), for all four dwords of a fragment
+__device__ __forceinline__ uint4 swap_half_rows(uint4 v) {
+    uint4 r;
+    r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x128, 0xF, 0xF, false);
+    r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x128, 0xF, 0xF, false);
+    r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x128, 0xF, 0xF, false);
+    r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x128, 0xF, 0xF, false);
+    return r;
+}
+
 // The step counter of a recurrence is kept in NSH shards on lines of their own (workgroup i adds to shard i % NSH): atomics on
 // one address serialise in the L2, 32 of them per step were ~0.3 us of the chain.  The poller reads all four (sc1 loads:
 // they bypass the L1 and are served by the L2, so they also see the L2-scope adds of the XCD-local form).
@@ -652,6 +662,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = (3 * H) >> 5;
+    constexpr bool PAIRED = EPT == 1 && MTT == 1 && (KSW % 2 == 0);
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
     unsigned* shards = shard_base(sync, rec);
     unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
@@ -739,7 +750,9 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     if (is_compute) {
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
-            const int ks = i * 4 + w;
+            // PAIRED: this wave's slices come in adjacent pairs (2p, 2p + 1), p = (i / 2) * 4 + w, so that one load
+            // instruction can fetch both (a whole 128-B line per row) -- see the step loop
+            const int ks = PAIRED ? (((i >> 1) * 4 + w) * 2 + (i & 1)) : i * 4 + w;
             const int k = ks * 32 + 8 * (lane >> 4);
             bb[i].u = ks < nks ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k)
                                : make_uint4(0, 0, 0, 0);
@@ -789,6 +802,32 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                 f32x4 acc[MTT];
 #pragma unroll
                 for (int m = 0; m < MTT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (PAIRED) {
+                    // the MFMA tile has 16 rows and the recurrence 8: lanes of tile rows 8..15 fetch the NEXT K slice of
+                    // rows 0..7 instead of idling, so each load instruction brings two slices (half as many instructions
+                    // and whole 128-B lines); a DPP row rotate moves them to rows 0..7 for the second MFMA.  Tile rows
+                    // 8..15 then hold real but unrelated data: their output rows are never read.
+                    Frag a[KSW / 2];
+#pragma unroll
+                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                        const int r16 = lane & 15, row = r16 & 7;
+                        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+                        const int k = ks * 32 + 8 * (lane >> 4);
+                        a[i2].u = make_uint4(0, 0, 0, 0);
+                        if (ks < nks && row < Bl) {
+                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                            a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                        Frag a1;
+                        a1.u = swap_half_rows(a[i2].u);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i2].v, bb[2 * i2].v, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1].v, acc[0], 0, 0, 0);
+                    }
+                } else {
                 Frag a[KSW][MTT];
 #pragma unroll
                 for (int i = 0; i < KSW; ++i) {
@@ -812,6 +851,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                 for (int i = 0; i < KSW; ++i)
 #pragma unroll
                     for (int m = 0; m < MTT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i].v, acc[m], 0, 0, 0);
+                }
 #pragma unroll
                 for (int m = 0; m < MTT; ++m)
                     part[(w * MTT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
