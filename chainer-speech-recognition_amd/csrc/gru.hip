@@ -791,6 +791,21 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         const int t = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? t + 1 : t - 1;
         float rcr[2] = {0.f, 0.f};      // [1] unused when EPT == 1
+        // this step's operands (in the ring since at least three steps ago) are read before the wait, off the chain
+        float dyy[EPT], r[EPT], z[EPT], n[EPT], qq[EPT], hp[EPT];
+        {
+            const float* osrc = opring + (size_t)(s % BIO_GD) * 6 * 32 * 16 + b * 16 + u0;
+            if (EPT == 2) {
+                const float2 dyv = *reinterpret_cast<const float2*>(osrc);
+                const float2 rv = *reinterpret_cast<const float2*>(osrc + 1 * 512), zv = *reinterpret_cast<const float2*>(osrc + 2 * 512);
+                const float2 nv = *reinterpret_cast<const float2*>(osrc + 3 * 512), qv = *reinterpret_cast<const float2*>(osrc + 4 * 512);
+                const float2 hpv = *reinterpret_cast<const float2*>(osrc + 5 * 512);
+                dyy[0] = dyv.x; r[0] = rv.x; z[0] = zv.x; n[0] = nv.x; qq[0] = qv.x; hp[0] = hpv.x;
+                dyy[EPT - 1] = dyv.y; r[EPT - 1] = rv.y; z[EPT - 1] = zv.y; n[EPT - 1] = nv.y; qq[EPT - 1] = qv.y; hp[EPT - 1] = hpv.y;
+            } else {
+                dyy[0] = osrc[0]; r[0] = osrc[512]; z[0] = osrc[2 * 512]; n[0] = osrc[3 * 512]; qq[0] = osrc[4 * 512]; hp[0] = osrc[5 * 512];
+            }
+        }
         if (s > 0) {
             if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                     // rows 0..7 instead of idling, so each load instruction brings two slices (half as many instructions
                     // and whole 128-B lines); a DPP row rotate moves them to rows 0..7 for the second MFMA.  Tile rows
                     // 8..15 then hold real but unrelated data: their output rows are never read.
-                    Frag a[KSW / 2];
+                    Frag a[(KSW + 1) / 2];
 #pragma unroll
                     for (int i2 = 0; i2 < KSW / 2; ++i2) {
                         const int r16 = lane & 15, row = r16 & 7;
@@ -875,18 +890,6 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else {
-            const float* osrc = opring + (size_t)(s % BIO_GD) * 6 * 32 * 16 + b * 16 + u0;
-            float dyy[EPT], r[EPT], z[EPT], n[EPT], qq[EPT], hp[EPT];
-            if (EPT == 2) {
-                const float2 dyv = *reinterpret_cast<const float2*>(osrc);
-                const float2 rv = *reinterpret_cast<const float2*>(osrc + 1 * 512), zv = *reinterpret_cast<const float2*>(osrc + 2 * 512);
-                const float2 nv = *reinterpret_cast<const float2*>(osrc + 3 * 512), qv = *reinterpret_cast<const float2*>(osrc + 4 * 512);
-                const float2 hpv = *reinterpret_cast<const float2*>(osrc + 5 * 512);
-                dyy[0] = dyv.x; r[0] = rv.x; z[0] = zv.x; n[0] = nv.x; qq[0] = qv.x; hp[0] = hpv.x;
-                dyy[EPT - 1] = dyv.y; r[EPT - 1] = rv.y; z[EPT - 1] = zv.y; n[EPT - 1] = nv.y; qq[EPT - 1] = qv.y; hp[EPT - 1] = hpv.y;
-            } else {
-                dyy[0] = osrc[0]; r[0] = osrc[512]; z[0] = osrc[2 * 512]; n[0] = osrc[3 * 512]; qq[0] = osrc[4 * 512]; hp[0] = osrc[5 * 512];
-            }
             uint16_t ar[EPT], az[EPT], an[EPT], aq[EPT];
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -985,6 +988,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = H >> 5;
+    constexpr bool PAIRED = KSW % 2 == 0;
     const size_t hs = (size_t)ndir * H;
     unsigned* shards = shard_base(sync, rec);
     unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
-            const int ks = i * 4 + w;
+            const int ks = PAIRED ? (((i >> 1) * 4 + w) * 2 + (i & 1)) : i * 4 + w;      // adjacent slice pairs per load
             const int k = ks * 32 + 8 * (lane >> 4);
 #pragma unroll
             for (int gg = 0; gg < 3; ++gg)
@@ -1087,6 +1091,12 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         const int t = d == 0 ? s : T - 1 - s;
         const int tp = d == 0 ? t - 1 : t + 1;
         float gh[3] = {bh[0], bh[1], bh[2]};
+        // this step's gi (in the ring since at least three steps ago) is read before the wait, off the chain
+        float gr = 0.f, gz = 0.f, gn = 0.f;
+        if (tid >= 128 && tid < 256) {
+            const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 8 * 16 + b * 16 + u;
+            gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
+        }
         if (s > 0) {
             if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
@@ -1098,6 +1108,30 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                 f32x4 acc[3];
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
+                    Frag a[(KSW + 1) / 2];
+#pragma unroll
+                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                        const int r16 = lane & 15, row = r16 & 7;
+                        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+                        const int k = ks * 32 + 8 * (lane >> 4);
+                        a[i2].u = make_uint4(0, 0, 0, 0);
+                        if (ks < nks && row < Bl) {
+                            const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + k) * 2);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                            a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                        Frag a1;
+                        a1.u = swap_half_rows(a[i2].u);
+#pragma unroll
+                        for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i2].v, bb[2 * i2][gg].v, acc[gg], 0, 0, 0);
+#pragma unroll
+                        for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1][gg].v, acc[gg], 0, 0, 0);
+                    }
+                } else {
                 Frag a[KSW];
 #pragma unroll
                 for (int i = 0; i < KSW; ++i) {
@@ -1119,6 +1153,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                 for (int i = 0; i < KSW; ++i)
 #pragma unroll
                     for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][gg].v, acc[gg], 0, 0, 0);
+                }
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
                     part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
@@ -1143,12 +1178,6 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else if (tid >= 128) {
-            const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 8 * 16 + b * 16 + u;
-            const float gr = osrc[0], gz = osrc[128], gn = osrc[256];
-#ifdef ASR_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            ASR_ST(10)
             const float r = sigmoidf_(gr + gh[0]);
             const float z = sigmoidf_(gz + gh[1]);
             const float n = tanhf_(gn + r * gh[2]);
