@@ -638,31 +638,43 @@ __device__ __forceinline__ int decide_local(unsigned* sync, int rec, int nwg, un
     return __hip_atomic_load(sync + 976 + rec, ASR_RLX_AGENT) == 0u ? 1 : 0;
 }
 
-template <int KSW, int MTT, bool LOCAL, int EPT>
-__global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* __restrict__ dy,
-                                                                const float* __restrict__ gates,
-                                                                const float* __restrict__ hseq,
-                                                                const uint16_t* __restrict__ whhT,
-                                                                uint16_t* __restrict__ dgi, uint16_t* dgh,
-                                                                float* __restrict__ db_ih, float* __restrict__ db_hh,
-                                                                unsigned* sync, int T, int B, int H, int ndir, int rows, int forge) {
+// LDS ring slot of the backward loader (bytes): r, z, n, q, h_prev as [8 rows][16 units] f32 (512 B each), dy as
+// [8 rows][16 units] bf16 (256 B).  Filled by LDS-DMA (global_load_lds_dwordx4: the wave's lanes write 16 B each,
+// lane-linear from a wave-uniform base), so the loader holds no data registers.
+constexpr int BIO_SLOT = 5 * 512 + 256;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+#define ASR_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int KSW, bool LOCAL>
+__global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_t* __restrict__ dy,
+                                                                   const float* __restrict__ gates,
+                                                                   const float* __restrict__ hseq,
+                                                                   const uint16_t* __restrict__ whhT,
+                                                                   uint16_t* __restrict__ dgi, uint16_t* dgh,
+                                                                   float* __restrict__ db_ih, float* __restrict__ db_hh,
+                                                                   unsigned* sync, int T, int B, int H, int ndir, int rows,
+                                                                   int forge) {
+    // 384 threads, at most 168 VGPRs (3 waves per SIMD): a 256-thread GEMM workgroup of the side stream fits beside this
+    // workgroup on the same CU and runs in the gaps of the latency-bound recurrence.
+    // Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would also wait for the loader's LDS-DMA in flight.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MTT][64]
-    float* opring = reinterpret_cast<float*>(part + 4 * MTT * 64);         // [BIO_GD][6: dy r z n q hp][32 rows][16 units]
-    unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * 6 * 32 * 16);   // [2][3: ar az an][32 rows][8 pairs]
-    int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 32 * 8);
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [4 waves][64]
+    char* opring = smem + 4 * 64 * 16;                                                // [BIO_GD][BIO_SLOT]
+    unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);       // [2][3: ar az an][8 rows][8 pairs]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 8 * 8);
     // LOCAL: a 1-D grid of 8 x H/16 workgroups; the hardware deals workgroup ids round-robin over the 8 XCDs, so
-    // recurrence (d, g) = id % 8 has all its workgroups on one XCD and hands off through that XCD's L2
+    // recurrence (d, g) = id % 8 has all its workgroups on one XCD and may hand off through that XCD's L2
     const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
     const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
     if (LOCAL && rec >= G_ * ndir) return;
     const int d = rec / G_, g = rec % G_;
     const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
-    const int b0 = g * rows, Bl = min(rows, B - b0);      // this workgroup's batch rows (an independent recurrence)
+    const int b0 = g * rows, Bl = min(rows, B - b0);      // this recurrence's batch rows (at most 8)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = (3 * H) >> 5;
-    constexpr bool PAIRED = EPT == 1 && MTT == 1 && (KSW % 2 == 0);
+    constexpr bool PAIRED = KSW % 2 == 0;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
     unsigned* shards = shard_base(sync, rec);
     unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
@@ -672,82 +684,43 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     const long long tstep = d == 0 ? -1 : 1;
     const int tfirst = d == 0 ? T - 1 : 0;
 
-    // ---- loader: 10 f32 pieces (16 B) + 1 bf16 piece per lane and step
-    // f32 piece p = lane + 64 i: array 1 + p / 128 (r, z, n, q, hp), row (p % 128) / 4, units 4 * (p % 4) .. + 3
-    // loader addresses advance by a constant stride per step (no 64-bit multiplies in the loop)
-    const float* lp[10];
-    const uint16_t* lpy;
-    long long lstride[2];       // floats per step for the gate arrays / for h
-    {
-        lstride[0] = tstep * (long long)B * ndir * 4 * H;
-        lstride[1] = tstep * (long long)B * (long long)hs;
-        const long long tp0 = d == 0 ? (long long)tfirst - 1 : (long long)tfirst + 1;
+    // ---- loader (wave 4): lanes 0..31 fetch (row lane / 4, units 4 (lane % 4) ..) of each f32 array, lanes 0..15 the
+    // bf16 dy row halves; addresses advance by a constant stride per step
+    const int lrow = lane >> 2, lyrow = lane >> 1;
+    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 3) * 4;
+    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
+                       (size_t)d * H + j0 + (lane & 3) * 4;          // not dereferenced for the last step
+    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 1) * 8;
+    const long long lgs = tstep * (long long)B * ndir * 4 * H, lhs = tstep * (long long)B * (long long)hs, lys = tstep * (long long)B * H;
+    auto issue = [&](int sq) {
+        if (sq < T) {
+            char* slot = opring + (sq % BIO_GD) * BIO_SLOT;
+            if (lane < 32 && lrow < Bl) {
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2, c4 = (pp & 3) * 4;
-            const int rr = b0 + (row < Bl ? row : 0);
-            lp[i] = arr < 4 ? gates + (((size_t)tfirst * B + rr) * ndir + d) * 4 * H + arr * H + j0 + c4
-                            : hseq + (tp0 * B + rr) * (long long)hs + d * H + j0 + c4;     // not dereferenced when tp0 is outside [0, T)
+                for (int arr = 0; arr < 4; ++arr)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)arr * H), (lds_ptr_t)(slot + arr * 512), 16, 0, 0);
+                if (sq < T - 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)lhp, (lds_ptr_t)(slot + 4 * 512), 16, 0, 0);
+            }
+            if (lane < 16 && lyrow < Bl) __builtin_amdgcn_global_load_lds((glb_ptr_t)lyp, (lds_ptr_t)(slot + 5 * 512), 16, 0, 0);
         }
-        const int row = lane >> 1, c8 = (lane & 1) * 8;
-        lpy = dy + ((size_t)tfirst * B + b0 + (row < Bl ? row : 0)) * H + j0 + c8;
-    }
-    const long long ystride = tstep * (long long)B * H;
-#define ASR_BIO_LOAD(S_, F, Y)                                                                                            \
-    {                                                                                                                     \
-        const int s__ = (S_);                                                                                             \
-        const bool hasp = s__ < T - 1;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                                  \
-            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2;                                            \
-            const bool ok = s__ < T && row < Bl && (arr < 4 || hasp);                                                     \
-            F[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                       \
-            if (ok) F[i] = *reinterpret_cast<const float4*>(lp[i]);                                                       \
-            lp[i] += lstride[arr < 4 ? 0 : 1];                                                                            \
-        }                                                                                                                 \
-        {                                                                                                                 \
-            const int row = lane >> 1;                                                                                    \
-            Y = make_uint4(0, 0, 0, 0);                                                                                   \
-            if (s__ < T && row < Bl) Y = *reinterpret_cast<const uint4*>(lpy);                                            \
-            lpy += ystride;                                                                                               \
-        }                                                                                                                 \
-    }
-#define ASR_BIO_PUT(S_, F, Y)                                                                                             \
-    {                                                                                                                     \
-        float* dst = opring + (size_t)((S_) % BIO_GD) * 6 * 32 * 16;                                                      \
-        _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                                  \
-            const int pp = lane + 64 * i, arr = pp >> 7, row = (pp & 127) >> 2, c4 = (pp & 3) * 4;                         \
-            *reinterpret_cast<float4*>(dst + ((1 + arr) * 32 + row) * 16 + c4) = F[i];                                    \
-        }                                                                                                                 \
-        const int row = lane >> 1, c8 = (lane & 1) * 8;                                                                   \
-        float* dd = dst + (0 * 32 + row) * 16 + c8;                                                                       \
-        *reinterpret_cast<float4*>(dd) = make_float4(bf16_to_f32((uint16_t)(Y.x & 0xffff)), bf16_to_f32((uint16_t)(Y.x >> 16)),          \
-                                                     bf16_to_f32((uint16_t)(Y.y & 0xffff)), bf16_to_f32((uint16_t)(Y.y >> 16)));          \
-        *reinterpret_cast<float4*>(dd + 4) = make_float4(bf16_to_f32((uint16_t)(Y.z & 0xffff)), bf16_to_f32((uint16_t)(Y.z >> 16)),      \
-                                                         bf16_to_f32((uint16_t)(Y.w & 0xffff)), bf16_to_f32((uint16_t)(Y.w >> 16)));      \
-    }
-    // storer: dgi rows of 16 bf16 = 32 B = 2 pieces; 3 gates x 32 rows x 2 = 192 pieces, 3 per lane
+        lgp += lgs; lhp += lhs; lyp += lys;
+    };
+    // ---- storer (wave 5): dgi rows of 16 bf16 = 32 B = 2 pieces; 3 gates x 8 rows x 2 = 48 pieces, one per lane
     auto store_step = [&](int sp) {
         const long long tq = tfirst + tstep * sp;
-        const unsigned* src = oring + (size_t)(sp & 1) * 3 * 32 * 8;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int pp = lane + 64 * i, gsel = pp >> 6, row = (pp & 63) >> 1, c4 = (pp & 1) * 4;   // 4 pairs = 16 B
-            if (row < Bl)
-                *reinterpret_cast<uint4*>(dgi + ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c4 * 2) =
-                    *reinterpret_cast<const uint4*>(src + (gsel * 32 + row) * 8 + c4);
-        }
+        const unsigned* src = oring + (size_t)(sp & 1) * 3 * 8 * 8;
+        const int gsel = lane >> 4, row = (lane & 15) >> 1, c4 = (lane & 1) * 4;
+        if (lane < 48 && row < Bl)
+            *reinterpret_cast<uint4*>(dgi + ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c4 * 2) =
+                *reinterpret_cast<const uint4*>(src + (gsel * 8 + row) * 8 + c4);
     };
-    float4 fa[10];      // one step of loads in flight: a step (~5 us) is longer than the HBM latency
-    uint4 ya = make_uint4(0, 0, 0, 0);
     if (is_loader) {
-        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) {
-            ASR_BIO_LOAD(s0, fa, ya)
-            ASR_BIO_PUT(s0, fa, ya)
-        }
-        ASR_BIO_LOAD(BIO_GD - 1, fa, ya)
+        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) issue(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     Frag bb[KSW];
     if (is_compute) {
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < KSW; ++i) {
             // PAIRED: this wave's slices come in adjacent pairs (2p, 2p + 1), p = (i / 2) * 4 + w, so that one load
@@ -758,17 +731,13 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                                : make_uint4(0, 0, 0, 0);
         }
     }
-    // gate phase: EPT = 2: thread (row tid / 8, unit pair tid % 8); EPT = 1 (at most 8 rows): thread (row tid / 16, unit tid % 16)
-    // (waves 2 and 3: they do not share a SIMD with the I/O waves 4 and 5)
-    const int b = EPT == 2 ? (tid >> 3) & 31 : ((tid - 128) >> 4) & 15;
-    const int u0 = EPT == 2 ? 2 * (tid & 7) : (tid & 15);      // first unit of this thread
+    // gate phase on waves 2 and 3 (they do not share a SIMD with the I/O waves): thread (row (tid - 128) / 16, unit tid % 16)
+    const int b = ((tid - 128) >> 4) & 7, u0 = tid & 15;
     const int j = j0 + (u0 & ~1);                              // the even unit of the stored pair
-    const bool act = is_compute && b < Bl && (EPT == 2 || tid >= 128);
+    const bool gate_wave = tid >= 128 && tid < 256;
+    const bool act = gate_wave && b < Bl;
     constexpr int kPoller = 128;                               // first lane of wave 2
-    if (is_compute) __builtin_amdgcn_s_setprio(3);
-    float carry[EPT], sb[4][EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) { carry[e] = 0.f; sb[0][e] = sb[1][e] = sb[2][e] = sb[3][e] = 0.f; }
+    float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
@@ -778,7 +747,7 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
 
 #ifdef ASR_STAMP
@@ -790,33 +759,25 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? t + 1 : t - 1;
-        float rcr[2] = {0.f, 0.f};      // [1] unused when EPT == 1
-        // this step's operands (in the ring since at least three steps ago) are read before the wait, off the chain
-        float dyy[EPT], r[EPT], z[EPT], n[EPT], qq[EPT], hp[EPT];
-        {
-            const float* osrc = opring + (size_t)(s % BIO_GD) * 6 * 32 * 16 + b * 16 + u0;
-            if (EPT == 2) {
-                const float2 dyv = *reinterpret_cast<const float2*>(osrc);
-                const float2 rv = *reinterpret_cast<const float2*>(osrc + 1 * 512), zv = *reinterpret_cast<const float2*>(osrc + 2 * 512);
-                const float2 nv = *reinterpret_cast<const float2*>(osrc + 3 * 512), qv = *reinterpret_cast<const float2*>(osrc + 4 * 512);
-                const float2 hpv = *reinterpret_cast<const float2*>(osrc + 5 * 512);
-                dyy[0] = dyv.x; r[0] = rv.x; z[0] = zv.x; n[0] = nv.x; qq[0] = qv.x; hp[0] = hpv.x;
-                dyy[EPT - 1] = dyv.y; r[EPT - 1] = rv.y; z[EPT - 1] = zv.y; n[EPT - 1] = nv.y; qq[EPT - 1] = qv.y; hp[EPT - 1] = hpv.y;
-            } else {
-                dyy[0] = osrc[0]; r[0] = osrc[512]; z[0] = osrc[2 * 512]; n[0] = osrc[3 * 512]; qq[0] = osrc[4 * 512]; hp[0] = osrc[5 * 512];
-            }
+        float rcr = 0.f;
+        // this step's operands (in the ring since at least two steps ago) are read before the wait, off the chain
+        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f;
+        if (gate_wave) {
+            const char* slot = opring + (s % BIO_GD) * BIO_SLOT;
+            const float* of = reinterpret_cast<const float*>(slot) + b * 16 + u0;
+            r = of[0]; z = of[128]; n = of[256]; qq = of[384];
+            hp = s < T - 1 ? of[512] : 0.f;
+            dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(slot + 5 * 512)[b * 16 + u0]);
         }
         if (s > 0) {
             if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
             ASR_ST(0)
-            __syncthreads();
+            ASR_RAW_BARRIER();
             ASR_ST(1)
             if (*s_abort) break;
             if (is_compute) {
-                f32x4 acc[MTT];
-#pragma unroll
-                for (int m = 0; m < MTT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (PAIRED) {
                     // the MFMA tile has 16 rows and the recurrence 8: lanes of tile rows 8..15 fetch the NEXT K slice of
                     // rows 0..7 instead of idling, so each load instruction brings two slices (half as many instructions
@@ -829,9 +790,9 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                         const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
                         const int k = ks * 32 + 8 * (lane >> 4);
                         a[i2].u = make_uint4(0, 0, 0, 0);
-                        if (ks < nks && row < Bl) {
+                        if (ks < nks && row < Bl) {      // masked lanes send no request
                             const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1: bypasses the L1, served by the L2 */);
                             a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
@@ -839,91 +800,68 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                     for (int i2 = 0; i2 < KSW / 2; ++i2) {
                         Frag a1;
                         a1.u = swap_half_rows(a[i2].u);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i2].v, bb[2 * i2].v, acc[0], 0, 0, 0);
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1].v, acc[0], 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i2].v, bb[2 * i2].v, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1].v, acc, 0, 0, 0);
                     }
                 } else {
-                Frag a[KSW][MTT];
+                    Frag a[KSW];
 #pragma unroll
-                for (int i = 0; i < KSW; ++i) {
-                    const int ks = i * 4 + w;
-                    const int k = ks * 32 + 8 * (lane >> 4);
-#pragma unroll
-                    for (int m = 0; m < MTT; ++m) {
-                        const int row = m * 16 + (lane & 15);
-                        const bool ok = ks < nks && row < Bl;
-                        // lanes of rows beyond the group are masked off: no request leaves the CU for them
+                    for (int i = 0; i < KSW; ++i) {
+                        const int ks = i * 4 + w;
+                        const int k = ks * 32 + 8 * (lane >> 4);
+                        const int row = lane & 15;
                         // (an out-of-range descriptor offset also returns zeros, but measured 2.3 us slower per step)
-                        a[i][m].u = make_uint4(0, 0, 0, 0);
-                        if (ok) {
+                        a[i].u = make_uint4(0, 0, 0, 0);
+                        if (ks < nks && row < Bl) {
                             const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1: bypasses the L1, served by the L2 */);
-                            a[i][m].u = make_uint4(v[0], v[1], v[2], v[3]);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                            a[i].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
+#pragma unroll
+                    for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < KSW; ++i)
-#pragma unroll
-                    for (int m = 0; m < MTT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i].v, acc[m], 0, 0, 0);
-                }
-#pragma unroll
-                for (int m = 0; m < MTT; ++m)
-                    part[(w * MTT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+                part[w * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
             ASR_ST(2)
-            __syncthreads();
+            ASR_RAW_BARRIER();
             ASR_ST(3)
             if (act) {
-                const int m = b >> 4, row = b & 15;
+                // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
+                // nest of divergent branches around narrow reads (measured 0.95 us per step)
+                const float* pf = reinterpret_cast<const float*>(part) + ((b >> 2) * 16 + u0) * 4 + (b & 3);
 #pragma unroll
-                for (int e = 0; e < EPT; ++e) {      // scalar reads (see fwd_persistent_io_kernel)
-                    const float* pf = reinterpret_cast<const float*>(part) + ((row >> 2) * 16 + u0 + e) * 4 + (row & 3);
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) rcr[e] += pf[(ww * MTT + m) * 256];
-                }
+                for (int ww = 0; ww < 4; ++ww) rcr += pf[ww * 256];
             }
         }
         if (is_loader) {
-            ASR_BIO_PUT(s + BIO_GD - 1, fa, ya)
-            ASR_BIO_LOAD(s + BIO_GD, fa, ya)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot issued one step ago has landed (read two steps from now)
+            issue(s + BIO_GD - 1);
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
-        } else {
-            uint16_t ar[EPT], az[EPT], an[EPT], aq[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const float dh = dyy[e] + carry[e] + rcr[e];
-                const float dn = dh * (1.0f - z[e]);
-                const float dz = dh * (hp[e] - n[e]);
-                const float dan = dn * (1.0f - n[e] * n[e]);
-                const float daz = dz * z[e] * (1.0f - z[e]);
-                const float dq = dan * r[e];
-                const float dar = dan * qq[e] * r[e] * (1.0f - r[e]);
-                carry[e] = dh * z[e];
-                ar[e] = f32_to_bf16(dar); az[e] = f32_to_bf16(daz); an[e] = f32_to_bf16(dan); aq[e] = f32_to_bf16(dq);
-                if (act) {      // bias gradients see the bf16-rounded values the weight-gradient GEMMs see
-                    sb[0][e] += bf16_to_f32(ar[e]); sb[1][e] += bf16_to_f32(az[e]);
-                    sb[2][e] += bf16_to_f32(an[e]); sb[3][e] += bf16_to_f32(aq[e]);
-                }
+        } else if (gate_wave) {
+            const float dh = dyy + carry + rcr;
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (hp - n);
+            const float dan = dn * (1.0f - n * n);
+            const float daz = dz * z * (1.0f - z);
+            const float dq = dan * r;
+            const float dar = dan * qq * r * (1.0f - r);
+            carry = dh * z;
+            const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
+            if (act) {      // bias gradients see the bf16-rounded values the weight-gradient GEMMs see
+                sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq);
             }
-            unsigned pr_, pz_, pn_, pq_;
-            bool st_rz = act, st_qn = act;       // who stores which packed pair
-            if (EPT == 2) {
-                pr_ = (unsigned)ar[0] | ((unsigned)ar[EPT - 1] << 16); pz_ = (unsigned)az[0] | ((unsigned)az[EPT - 1] << 16);
-                pn_ = (unsigned)an[0] | ((unsigned)an[EPT - 1] << 16); pq_ = (unsigned)aq[0] | ((unsigned)aq[EPT - 1] << 16);
-            } else {            // neighbouring lanes hold the two units of a pair: the even lane stores r and z, the odd lane q and n
-                const unsigned m1 = (unsigned)ar[0] | ((unsigned)az[0] << 16), m2 = (unsigned)an[0] | ((unsigned)aq[0] << 16);
-                const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
-                const bool odd = u0 & 1;
-                const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;   // e: even unit, d: odd unit
-                pr_ = (e1 & 0xffffu) | (d1 << 16); pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
-                pn_ = (e2 & 0xffffu) | (d2 << 16); pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
-                st_rz = act && !odd; st_qn = act && odd;
-            }
+            // neighbouring lanes hold the two units of a pair: the even lane stores r and z, the odd lane q and n
+            const unsigned m1 = (unsigned)ar | ((unsigned)az << 16), m2 = (unsigned)an | ((unsigned)aq << 16);
+            const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
+            const bool odd = u0 & 1;
+            const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;   // e: even unit, d: odd unit
+            const unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
+            const unsigned pn_ = (e2 & 0xffffu) | (d2 << 16), pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
             const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
-            unsigned* od = oring + (size_t)(s & 1) * 3 * 32 * 8 + b * 8 + (u0 >> 1);
-            if (st_rz) {
+            unsigned* od = oring + (size_t)(s & 1) * 3 * 8 * 8 + b * 8 + (u0 >> 1);
+            if (act && !odd) {
                 if (local) {        // plain stores: the line stays in this XCD's L2, where the consumers read it
                     __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
@@ -933,16 +871,16 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
                 }
                 od[0] = pr_;
             }
-            if (st_qn) {
+            if (act && odd) {
                 if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
                 else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
-                od[32 * 8] = pz_; od[2 * 32 * 8] = pn_;
+                od[8 * 8] = pz_; od[2 * 8 * 8] = pn_;
             }
             ASR_ST(4)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ASR_ST(5)
         }
-        __syncthreads();
+        ASR_RAW_BARRIER();
         ASR_ST(6)
         if (tid == kPoller) { if (local) __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT); }
     }
@@ -950,19 +888,15 @@ __global__ __launch_bounds__(384) void bwd_persistent_io_kernel(const uint16_t* 
     if (blockIdx.x < 8 && lane == 0)
         for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[((blockIdx.x * 6) + w) * 8 + i] = st_acc[i];
 #endif
-    __syncthreads();
+    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+    ASR_RAW_BARRIER();
     if (is_storer && !*s_abort) store_step(T - 1);
     if (act && db_ih && db_hh) {
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            float* bi = db_ih + (size_t)d * 3 * H + j0 + u0 + e;
-            float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0 + e;
-            atomicAdd(bi, sb[0][e]); atomicAdd(bi + H, sb[1][e]); atomicAdd(bi + 2 * H, sb[2][e]);
-            atomicAdd(bh2, sb[0][e]); atomicAdd(bh2 + H, sb[1][e]); atomicAdd(bh2 + 2 * H, sb[3][e]);
-        }
+        float* bi = db_ih + (size_t)d * 3 * H + j0 + u0;
+        float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0;
+        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
+        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
     }
-#undef ASR_BIO_LOAD
-#undef ASR_BIO_PUT
 #undef ASR_ST
 }
 
@@ -1842,13 +1776,13 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
 #define ASR_BWDIO(K)                                                                                                      \
     do {                                                                                                                  \
         if (local) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, 1, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, 1, true, 1>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, true>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
                                (unsigned*)sync_ws, T, B, H, ndir, rows, forge);                                                   \
         } else {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, 1, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, 1, false, 1>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, false>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
                                (unsigned*)sync_ws, T, B, H, ndir, rows, 0);                                                       \
         }                                                                                                                 \
