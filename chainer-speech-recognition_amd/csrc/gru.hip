@@ -903,8 +903,9 @@ __global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_
 // Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
 // most 8 rows, 4 compute waves (K = H split in 4) + loader (gi ring) + storer (f32 state and the four saved gate arrays,
 // one step behind).  The exchanged payload is the bf16 h row (hseq16), written sc1 by the gate threads themselves.
+// Raw barriers (s_barrier + lgkmcnt(0)): __syncthreads() would also wait for the loader's LDS-DMA in flight.
 template <int KSW, bool LOCAL>
-__global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+__global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
                                                                 int T, int B, int H, int ndir, int rows, int forge) {
@@ -932,32 +933,20 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
     const long long tstep = d == 0 ? 1 : -1;
     const int tfirst = d == 0 ? 0 : T - 1;
 
-    // loader: 3 gates x 8 rows x 64 B = 96 pieces of 16 B: piece p = lane + 64 i (i < 2, p < 96): gate p / 32, row (p % 32) / 4
-    const float* lp[2];
+    // loader (wave 4), LDS-DMA: lanes 0..31 fetch (row lane / 4, units 4 (lane % 4) ..) of each of the three gi gate
+    // arrays straight into the ring slot (lane-linear image = [3 gates][8 rows][16 units] f32); no data registers
+    const int lrow = lane >> 2;
+    const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 3) * 4;
     const long long lstride = tstep * (long long)B * 3 * (long long)hs;
+    auto issue = [&](int sq) {
+        if (sq < T && lane < 32 && lrow < Bl) {
+            char* slot = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pp = lane + 64 * i, gg = pp >> 5, row = (pp & 31) >> 2, c4 = (pp & 3) * 4;
-        lp[i] = gi + ((size_t)tfirst * B + b0 + (row < Bl ? row : 0)) * (3 * hs) + (size_t)d * 3 * H + (gg < 3 ? gg : 0) * H + j0 + c4;
-    }
-    float4 fa[2];
-#define ASR_FIO_LOAD(S_)                                                                                                  \
-    {                                                                                                                     \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
-            const int pp = lane + 64 * i, row = (pp & 31) >> 2;                                                            \
-            fa[i] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                      \
-            if ((S_) < T && pp < 96 && row < Bl) fa[i] = *reinterpret_cast<const float4*>(lp[i]);                          \
-            lp[i] += lstride;                                                                                             \
-        }                                                                                                                 \
-    }
-#define ASR_FIO_PUT(S_)                                                                                                   \
-    {                                                                                                                     \
-        float* dst = opring + (size_t)((S_) % BIO_GD) * 3 * 8 * 16;                                                       \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                   \
-            const int pp = lane + 64 * i;                                                                                 \
-            if (pp < 96) *reinterpret_cast<float4*>(dst + pp * 4) = fa[i];                                                \
-        }                                                                                                                 \
-    }
+            for (int gg = 0; gg < 3; ++gg)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)gg * H), (lds_ptr_t)(slot + gg * 512), 16, 0, 0);
+        }
+        lgp += lstride;
+    };
     // storer: 5 arrays x 8 rows x 64 B = 160 pieces: piece p = lane + 64 i (i < 3, p < 160): array p / 32, row (p % 32) / 4
     auto store_step = [&](int sp) {
         const long long tq = tfirst + tstep * sp;
@@ -974,11 +963,8 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         }
     };
     if (is_loader) {
-        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) {
-            ASR_FIO_LOAD(s0)
-            ASR_FIO_PUT(s0)
-        }
-        ASR_FIO_LOAD(BIO_GD - 1)
+        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) issue(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     Frag bb[KSW][3];
     if (is_compute) {
@@ -1012,7 +998,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
 #ifdef ASR_STAMP
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -1035,7 +1021,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
             if (tid == kPoller && !(local ? wait_shards<true>(shards, nwg, (unsigned)s, abort_word) : wait_shards<false>(shards, nwg, (unsigned)s, abort_word)))
                 *s_abort = 1;
             ASR_ST(0)
-            __syncthreads();
+            ASR_RAW_BARRIER();
             ASR_ST(1)
             if (*s_abort) break;
             if (is_compute) {
@@ -1093,7 +1079,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
                     part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
             }
             ASR_ST(3)
-            __syncthreads();
+            ASR_RAW_BARRIER();
             ASR_ST(4)
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
@@ -1107,8 +1093,8 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
             ASR_ST(9)
         }
         if (is_loader) {
-            ASR_FIO_PUT(s + BIO_GD - 1)
-            ASR_FIO_LOAD(s + BIO_GD)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot issued one step ago has landed (read two steps from now)
+            issue(s + BIO_GD - 1);
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else if (tid >= 128) {
@@ -1134,7 +1120,7 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ASR_ST(7)
         }
-        __syncthreads();
+        ASR_RAW_BARRIER();
         ASR_ST(8)
         if (tid == kPoller) { if (local) __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_WG); else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT); }
     }
@@ -1142,10 +1128,9 @@ __global__ __launch_bounds__(384) void fwd_persistent_io_kernel(const float* __r
     if (blockIdx.x < 8 && lane == 0)
         for (int i = 0; i < 12; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[((blockIdx.x * 6) + w) * 12 + i] = st_acc[i];
 #endif
-    __syncthreads();
+    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
+    ASR_RAW_BARRIER();
     if (is_storer && !*s_abort) store_step(T - 1);
-#undef ASR_FIO_LOAD
-#undef ASR_FIO_PUT
 }
 
 // ================================================================================================ grouped persistent form
