@@ -270,11 +270,11 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_path):
             ks = json.load(open(pmc_path))["kernels"]
-            sel = [v for k, v in ks.items() if "gru::fwd_group_kernel" in k or "gru::bwd_persistent_io_kernel" in k]
+            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_persistent_io_kernel" in k]
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
                 traffic_src = "profiles/r01_pmc_traffic.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_group_kernel / bwd_persistent_io_kernel (one launch per layer)",
+        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_persistent_io_kernel (one launch per layer)",
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "ms_per_launch": per_launch_s * 1e3, "launches_per_step": launches,
@@ -285,7 +285,13 @@ def main():
         ctc_ms = ctc["ctc_forward"] + ctc["ctc_grad"]
         out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                                      "unit": "GB/s", "frac": ctc_bytes / (ctc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                     "ms": ctc_ms, "algorithmic_bytes": ctc_bytes}
+                                     "ms": ctc_ms, "algorithmic_bytes": ctc_bytes,
+                                     "note": "forward = prep + rows (one read of the logits) + lattice (T serial steps per "
+                                             "utterance, latency-bound, no HBM stream); backward = grad (one read of the "
+                                             "logits + one write of the gradient)",
+                                     "grad_kernel": {"ms": ctc["ctc_grad"], "bytes": ctc_bytes,
+                                                     "achieved": ctc_bytes / (ctc["ctc_grad"] * 1e-3) / 1e9,
+                                                     "frac": ctc_bytes / (ctc["ctc_grad"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         frames = T * B
         macs_fwd = frames * 15.25e6
         gemm_ms = tot["gemm_nt"][0] + tot["gemm_tn_acc"][0]
