@@ -39,7 +39,14 @@ template <>
 __device__ __forceinline__ void store_out<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
 
 // ------------------------------------------------------------------------------------------------ NT
-template <typename OutT>
+// GLDS: operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: each lane's 16 B land lane-linear behind a
+// wave-uniform base, so the XOR swizzle is applied to the SOURCE address); needs K % 64 == 0 and 16-B aligned rows.
+// The register-staged form pays ~80 B/clk/CU for its ds_write_b128 pass, which with two workgroups per CU costs more
+// LDS time than the MFMAs take.  Rows beyond M / N are clamped to the last row (computed, never stored).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <typename OutT, bool GLDS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict__ A, int lda,
                                                       const uint16_t* __restrict__ B, int ldb, OutT* __restrict__ C,
                                                       int ldc, const float* __restrict__ bias, int M, int N, int K,
@@ -96,12 +103,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
     };
 
     const int nk = (K + BK - 1) / BK;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_global((kt + 1) * BK);
+    auto compute_tile = [&](int buf) {
         const char* Ab = As + buf * (BM * BK * 2);
         const char* Bb = Bs + buf * (BN * BK * 2);
 #pragma unroll
@@ -121,8 +123,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_lds(buf ^ 1);
+    };
+    if (GLDS) {
+        // slot s = i * 256 + wid * 64 + lane of a tile image: row s / 8, 16-B position s % 8, which holds chunk (s % 8) ^ (row & 7)
+        const uint16_t* ga[4];
+        const uint16_t* gb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sl = i * 256 + tid, row = sl >> 3, c = (sl & 7) ^ (row & 7);
+            ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+            gb[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+        }
+        auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int base = (i * 256 + wid * 64) * 16;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + kt * BK), (lds_ptr_t)(As + buf * (BM * BK * 2) + base), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[i] + kt * BK), (lds_ptr_t)(Bs + buf * (BN * BK * 2) + base), 16, 0, 0);
+            }
+        };
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) issue_tile(kt + 1, buf ^ 1);
+            compute_tile(buf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        load_global(0);
+        store_lds(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_global((kt + 1) * BK);
+            compute_tile(buf);
+            if (kt + 1 < nk) store_lds(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // epilogue: stage 64 rows at a time through LDS (f32, row pitch 132 floats) and write whole rows
@@ -297,16 +337,19 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
-    if (out_bf16)
-        hipLaunchKernelGGL(gemm_nt_kernel<uint16_t>, dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream,
-                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, tiles_n);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream,
-                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_n);
+    const bool glds = (K % BK) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
+#define ASR_NT(T, G, CT)                                                                                                  \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, G>), dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream, (const uint16_t*)A, lda, \
+                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_n)
+    if (out_bf16) { if (glds) ASR_NT(uint16_t, true, uint16_t); else ASR_NT(uint16_t, false, uint16_t); }
+    else          { if (glds) ASR_NT(float, true, float); else ASR_NT(float, false, float); }
+#undef ASR_NT
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
