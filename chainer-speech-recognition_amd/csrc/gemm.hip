@@ -218,6 +218,151 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256 x 128 tile
+// At 128 x 128 x 64 every MFMA cycle needs 64 B/clk of operand fill per CU -- the whole L1-miss path -- so the K = 512
+// projections of the model ran at ~450 TFLOP/s.  256 x 128 halves the fill per flop: 4 waves as 2 (M) x 2 (N), each
+// 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers); BK = 32, two LDS stages of 24 KB filled by LDS-DMA, so two or
+// three workgroups share a CU and one's prologue / epilogue hides behind another's main loop.
+// LDS image: rows of 64 B (32 k), 16-B chunk c of row r stored at position c ^ g[(r >> 2) & 3], g = {0, 2, 3, 1}: the
+// ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) then touch 16 distinct 16-B slots of the 256-B bank row.
+constexpr int B2M = 256, B2N = 128, B2K = 32;
+constexpr int NT2_STAGES = 3;
+constexpr int NT2_LDS_BYTES = NT2_STAGES * (B2M + B2N) * B2K * 2;      // 72 KiB: two workgroups per CU
+
+template <typename OutT>
+__global__ __launch_bounds__(256, 2) void gemm_nt256_kernel(const uint16_t* __restrict__ A, int lda,
+                                                            const uint16_t* __restrict__ B, int ldb, OutT* __restrict__ C,
+                                                            int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                            int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * B2M, n0 = tn * B2N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = B2N * B2K * 2;
+    char* As = smem;                           // [3][256 rows][64 B]
+    char* Bs = smem + NT2_STAGES * A_STAGE;    // [3][128 rows][64 B]
+    auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS-DMA sources: slot s of an image = (row s / 4, position s % 4) holds chunk (s % 4) ^ g(row); a wave-instruction
+    // fills 64 consecutive slots.  A: 1024 slots = 4 per thread, B: 512 = 2 per thread.
+    const uint16_t* ga[4];
+    const uint16_t* gb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sl = i * 256 + tid, row = sl >> 2, c = (sl & 3) ^ g4(row);
+        ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = i * 256 + tid, row = sl >> 2, c = (sl & 3) ^ g4(row);
+        gb[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + kt * B2K), (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[i] + kt * B2K), (lds_ptr_t)(Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+    };
+    // fragment addresses (bytes inside a stage) are loop invariant
+    int aoff[8], boff[4];
+    {
+        const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wm * 128 + i * 16 + r;
+            aoff[i] = row * 64 + ((q ^ g4(row)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wn * 64 + j * 16 + r;
+            boff[j] = row * 64 + ((q ^ g4(row)) << 4);
+        }
+    }
+    // three stages, two tiles in flight: by Little's law 48 B/clk of fill at ~2000 cycles of latency is ~96 KB per CU.
+    // Tile kt + 2 is issued while tile kt is computed; before the barrier each wave waits until only its newest 6
+    // DMAs are outstanding (tile kt + 1 has landed).  Raw s_barrier: __syncthreads() would drain the DMAs in flight.
+    const int nk = K / B2K;
+    issue_tile(0, 0);
+    if (nk > 1) issue_tile(1, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) issue_tile(kt + 2, buf >= 1 ? buf - 1 : 2);
+        const char* Ab = As + buf * A_STAGE;
+        const char* Bb = Bs + buf * B_STAGE;
+        Frag b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const uint4*>(Bb + boff[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Frag a;
+            a.u = *reinterpret_cast<const uint4*>(Ab + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // epilogue: 64 rows at a time through LDS (f32, row pitch 132 floats = 33 KB) and whole rows out
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CP = B2N + 4;
+#pragma unroll
+    for (int chunk = 0; chunk < 4; ++chunk) {
+        if (wm == (chunk >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ii * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * CP + col] = acc[(chunk & 1) * 4 + ii][j][r];
+                    }
+        }
+        __syncthreads();
+        for (int id = tid; id < 64 * (B2N / 4); id += 256) {
+            const int row = id / (B2N / 4), c4 = (id - row * (B2N / 4)) * 4;
+            const int gm = m0 + chunk * 64 + row, gn = n0 + c4;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            OutT* dst = C + (size_t)gm * ldc + gn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (bias && gn + e < N) vv[e] += bias[gn + e];
+            if (gn + 3 < N && ((((uintptr_t)dst) & (sizeof(OutT) * 4 - 1)) == 0)) {
+                if (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(vv[0]) | ((uint32_t)f32_to_bf16(vv[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(vv[2]) | ((uint32_t)f32_to_bf16(vv[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) store_out<OutT>(dst + e, vv[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 constexpr int TK = 32;               // k rows per LDS tile (one MFMA K step)
 constexpr int TP = BM + 16;          // padded row pitch in elements (288 B): 8 consecutive rows cover all 64 banks
@@ -342,6 +487,24 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
+    }
+    const bool aligned = (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
+    if (aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024) {      // at least two rounds of 2 workgroups per CU
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            attr2 = true;
+        }
+        const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N);
+        if (out_bf16)
+            hipLaunchKernelGGL(gemm_nt256_kernel<uint16_t>, dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, t2n);
+        else
+            hipLaunchKernelGGL(gemm_nt256_kernel<float>, dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, t2n);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
     }
     const bool glds = (K % BK) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
 #define ASR_NT(T, G, CT)                                                                                                  \
