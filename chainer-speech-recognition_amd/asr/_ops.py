@@ -47,12 +47,13 @@ def gemm_tn_acc(a, b, c):
     return c
 
 
-def cast_bf16(src, transpose=False):
-    """f32 (rows, cols) -> bf16 copy, optionally transposed."""
+def cast_bf16(src, transpose=False, out=None):
+    """f32 (rows, cols) -> bf16 copy, optionally transposed; `out`: a contiguous bf16 tensor of the result's size."""
     assert src.dtype == F32 and src.is_contiguous()
     s2 = src.reshape(src.shape[0], -1) if src.dim() != 2 else src
     rows, cols = s2.shape
-    dst = torch.empty((cols, rows) if transpose else (rows, cols), dtype=BF16, device=src.device)
+    dst = out if out is not None else torch.empty((cols, rows) if transpose else (rows, cols), dtype=BF16, device=src.device)
+    assert dst.dtype == BF16 and dst.is_contiguous() and dst.numel() == rows * cols
     check(_lib.lib().asr_cast_bf16(stream(), ptr(s2), ptr(dst), rows, cols, int(transpose)), "asr_cast_bf16")
     return dst
 

@@ -166,7 +166,7 @@ class _Conv2D(torch.autograd.Function):
         B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx = ctx.meta
         gy = gy.contiguous()
         if gy.dtype != BF16:
-            gy = _ops.permute4(gy, (1, 1, gy.numel() // Co, Co), (0, 0, Co, 1), BF16)
+            gy = _ops.cast_bf16(gy.reshape(-1, Co))
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
         Kp = col.shape[1]
@@ -257,7 +257,7 @@ class _Dense(torch.autograd.Function):
         W, b = ctx.params
         gy = gy.contiguous()
         if gy.dtype != BF16:
-            gy = _ops.permute4(gy, (1, 1, gy.shape[0], gy.shape[1]), (0, 0, gy.shape[1], 1), BF16).reshape(gy.shape)
+            gy = _ops.cast_bf16(gy)
         gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         gW = grad_buffer(W).reshape(W.shape[0], -1)
         gb = grad_buffer(b) if b is not None else None
@@ -485,6 +485,14 @@ def layer_normalization(x, gamma, beta, out_f32=False):
 
 
 # ---------------------------------------------------------------------------------------------- GRU
+def _cast_transposed_per_direction(w):
+    """(ndir, 3H, H) f32 -> (ndir, H, 3H) bf16, written in place (no torch.stack copy)."""
+    out = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+    for d in range(w.shape[0]):
+        _ops.cast_bf16(w[d], transpose=True, out=out[d])
+    return out
+
+
 class _GRU(torch.autograd.Function):
     """x rows (T*B, I) bf16 -> y rows (T*B, H) bf16 (directions summed)."""
 
@@ -532,7 +540,7 @@ def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
         link.compute_copy("wih16", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]))),
         link.compute_copy("wih16t", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]), transpose=True)),
         link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape)),
-        link.compute_copy("whh16t", w_hh, lambda w: torch.stack([_ops.cast_bf16(w[d], transpose=True) for d in range(w.shape[0])])),
+        link.compute_copy("whh16t", w_hh, _cast_transposed_per_direction),
     )
     y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir)
     return logical3(y.reshape(T, B, H))

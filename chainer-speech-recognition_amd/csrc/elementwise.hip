@@ -25,6 +25,18 @@ __global__ void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __rest
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = f32_to_bf16(src[i]);
 }
+// 8 elements per thread: two float4 in, one 16-B store out (n % 8 == 0, 16-B aligned)
+__global__ void cast_bf16_vec8_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long long n8) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+        dst[i] = o;
+    }
+}
 // dst[c][r] = src[r][c]   (small weight matrices; 32x32 LDS tile)
 __global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
@@ -483,7 +495,10 @@ extern "C" int asr_cast_bf16(void* stream, const float* src, void* dst, int rows
     hipStream_t s = (hipStream_t)stream;
     if (!transpose) {
         const long long n = (long long)rows * cols;
-        hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, src, (uint16_t*)dst, n);
+        if ((n & 7) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0)
+            hipLaunchKernelGGL(cast_bf16_vec8_kernel, dim3(grid_for(n >> 3)), dim3(kThreads), 0, s, (const float4*)src, (uint4*)dst, n >> 3);
+        else
+            hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(kThreads), 0, s, src, (uint16_t*)dst, n);
     } else {
         hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, src,
                            (uint16_t*)dst, rows, cols);
