@@ -27,6 +27,13 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_int, c_void_p]),
     "asr_logmel": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_void_p]),
     "asr_deltas": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
+    "asr_cmn_pspec": (c_int, [c_void_p] * 3 + [c_int] * 3),
+    "asr_add_white_noise": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_void_p, ctypes.c_ulonglong]),
+    "asr_running_stats_update": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_longlong] + [c_void_p] * 4),
+    "asr_normalize_bcmt": (c_int, [c_void_p] * 4 + [c_int] * 3),
+    "asr_argmax_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "asr_ctc_collapse": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2),
+    "asr_edit_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "asr_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),

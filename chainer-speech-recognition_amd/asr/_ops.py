@@ -357,3 +357,63 @@ def channel_affine(x2, scale, shift):
     y = torch.empty(x2.shape, dtype=BF16, device=x2.device)
     check(_lib.lib().asr_channel_affine(stream(), ptr(x2), ptr(scale), ptr(shift), ptr(y), x2.numel(), x2.shape[1]), "asr_channel_affine")
     return y
+
+
+# ------------------------------------------------------------------------------------------------ decode / CER / loader extras
+I32 = torch.int32
+
+
+def argmax_rows(logits):
+    """(T, B, V) f32 logits -> (B, T) int32 greedy ids."""
+    T, B, V = logits.shape
+    ids = torch.empty((B, T), dtype=I32, device=logits.device)
+    check(_lib.lib().asr_argmax_rows(stream(), ptr(logits), T, B, V, ptr(ids)), "asr_argmax_rows")
+    return ids
+
+
+def ctc_collapse(ids, lengths, blank, merge_repeats=True):
+    """(B, T) int32 -> (compacted ids (B, T) padded with blank, lengths (B))."""
+    B, T = ids.shape
+    out = torch.empty_like(ids)
+    out_len = torch.empty((B,), dtype=I32, device=ids.device)
+    rc = _lib.lib().asr_ctc_collapse(stream(), ptr(ids), None if lengths is None else ptr(lengths), B, T, int(blank), int(merge_repeats),
+                                     ptr(out), ptr(out_len))
+    check(rc, "asr_ctc_collapse")
+    return out, out_len
+
+
+def edit_distance(ref, ref_len, hyp, hyp_len):
+    """row-wise Levenshtein distance of two padded int32 id matrices -> (pairs,) int32."""
+    pairs = ref.shape[0]
+    dist = torch.empty((pairs,), dtype=I32, device=ref.device)
+    rc = _lib.lib().asr_edit_distance(stream(), ptr(ref), ptr(ref_len), ref.shape[1], ptr(hyp), ptr(hyp_len), hyp.shape[1], pairs, ptr(dist))
+    check(rc, "asr_edit_distance")
+    return dist
+
+
+def cmn_pspec(pspec, nframes):
+    B, Fmax, nbins = pspec.shape
+    check(_lib.lib().asr_cmn_pspec(stream(), ptr(pspec), ptr(nframes), B, Fmax, nbins), "asr_cmn_pspec")
+    return pspec
+
+
+def add_white_noise(signals, lengths, gain, seed):
+    B, pitch = signals.shape
+    check(_lib.lib().asr_add_white_noise(stream(), ptr(signals), ptr(lengths), pitch, B, ptr(gain), int(seed) & (2 ** 64 - 1)),
+          "asr_add_white_noise")
+    return signals
+
+
+def running_stats_update(x, lengths, total_before, mean, nvar, mean32, std32):
+    B, T = x.shape[0], x.shape[-1]
+    CM = x.numel() // (B * T)
+    rc = _lib.lib().asr_running_stats_update(stream(), ptr(x), ptr(lengths), B, CM, T, int(total_before), ptr(mean), ptr(nvar),
+                                             ptr(mean32), ptr(std32))
+    check(rc, "asr_running_stats_update")
+
+
+def normalize_bcmt(x, mean32, std32):
+    B, T = x.shape[0], x.shape[-1]
+    CM = x.numel() // (B * T)
+    check(_lib.lib().asr_normalize_bcmt(stream(), ptr(x), ptr(mean32), ptr(std32), B, CM, T), "asr_normalize_bcmt")
+    return x

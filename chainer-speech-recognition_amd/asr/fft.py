@@ -121,6 +121,16 @@ def compute_delta(feat, N=1):
     return x[0, 1].T
 
 
+def _ops_mod():
+    from . import _ops
+    return _ops
+
+
+def _int16_to_f32(t):
+    """exact widening of the int16 samples (a dtype conversion, no arithmetic)"""
+    return t if t.dtype == F32 else t.to(F32)
+
+
 class Processor(object):
     """The feature half of asr/data/processing.py:44-111 (defaults = run/ctc/cnn/args.py:18-25), batched on the GPU."""
 
@@ -134,14 +144,18 @@ class Processor(object):
         self.frame_len = int(round(frame_width * sampling_rate))
         self.frame_step = int(round(frame_shift * sampling_rate))
         self.num_mel_filters = num_mel_filters
+        self.using_delta = using_delta
+        self.using_delta_delta = using_delta_delta
         self.window = np.hanning(self.frame_len) if window_func == "hanning" else np.hamming(self.frame_len)
         self.fbank = get_filterbanks(nfft=self.num_fft, nfilt=num_mel_filters, samplerate=sampling_rate)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._window_d = self._fbank_d = None
 
-    def logfbank_batch(self, signals, mean=None, std=None):
+    def logfbank_batch(self, signals, mean=None, std=None, noise=None, apply_cmn=False):
         """signals: list of 1-d int16 arrays/tensors (or a padded (B, N) tensor + lengths tuple).  Returns
-        x (B, 3, nmel, Tmax) float32 on the GPU, zero padded, and x_length (B) int32 (asr/data/processing.py:113-173)."""
+        x (B, 3, nmel, Tmax) float32 on the GPU, zero padded, and x_length (B) int32 (asr/data/processing.py:113-173).
+        noise = (gain per utterance, seed): white-noise augmentation (:74-78); apply_cmn: cepstral mean normalisation in
+        the log-power domain (:86-89)."""
         dev = self.device
         if self._window_d is None:
             self._window_d, self._fbank_d = _dev_const(self.window, dev), _dev_const(self.fbank, dev)
@@ -160,8 +174,18 @@ class Processor(object):
         Tmax = max(Fmax - 2, 1)
         lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
         nfr = torch.tensor(frames, dtype=torch.int32, device=dev)
-        _, logmel = _specgram(padded.contiguous(), lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,
-                              self._window_d, self._fbank_d, False)
+        padded = padded.contiguous()
+        if noise is not None:
+            gains, seed = noise
+            padded = _ops_mod().add_white_noise(_int16_to_f32(padded), lengths, _dev_const(gains, dev), seed)
+        if apply_cmn:
+            pspec, _ = _specgram(padded, lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,
+                                 self._window_d, None, True)
+            _ops_mod().cmn_pspec(pspec, nfr)
+            logmel = compute_logmel(pspec.reshape(len(lens) * Fmax, -1), fbank=self._fbank_d).reshape(len(lens), Fmax, -1)
+        else:
+            _, logmel = _specgram(padded, lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,
+                                  self._window_d, self._fbank_d, False)
         m = None if mean is None else _dev_const(mean, dev).reshape(-1)
         s = None if std is None else _dev_const(std, dev).reshape(-1)
         x = _deltas(logmel, nfr, Tmax, m, s)

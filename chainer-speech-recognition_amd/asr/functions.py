@@ -560,6 +560,16 @@ def reshape(x, shape):
     return x.reshape(shape)
 
 
+def argmax(x, axis=2):
+    """xp.argmax(y_batch.data, axis=2) of the evaluation loop (run/ctc/cnn/dev.py:106): x is the (B, T, V) float32 view
+    a model returns with split_into_variables=False; -> (B, T) int32 ids, first maximum on ties."""
+    assert x.dim() == 3 and axis in (2, -1)
+    tbv = x.detach().permute(1, 0, 2)
+    if not tbv.is_contiguous():
+        tbv = tbv.contiguous()
+    return _ops.argmax_rows(tbv.float() if tbv.dtype != torch.float32 else tbv)
+
+
 def swapaxes(x, a, b):
     return x.transpose(a, b)
 

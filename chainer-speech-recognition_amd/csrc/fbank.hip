@@ -134,6 +134,94 @@ __global__ void deltas_kernel(const float* __restrict__ logmel, const int* __res
     }
 }
 
+// cepstral mean normalisation in the log-power domain (asr/data/processing.py:86-89):
+// pspec[f][k] <- exp(log pspec[f][k] - mean_f log pspec[f][k]); one thread per (utterance, bin), frames in sequence
+__global__ void cmn_pspec_kernel(float* __restrict__ pspec, const int* __restrict__ nframes, int B, int Fmax, int nbins) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nbins) return;
+    const int b = i / nbins, k = i - b * nbins;
+    const int F = nframes[b];
+    float* p = pspec + (size_t)b * Fmax * nbins + k;
+    double acc = 0.0;
+    for (int f = 0; f < F; ++f) acc += (double)logf(p[(size_t)f * nbins]);
+    const float mean = F > 0 ? (float)(acc / F) : 0.f;
+    for (int f = 0; f < F; ++f) p[(size_t)f * nbins] = expf(logf(p[(size_t)f * nbins]) - mean);
+}
+
+// white-noise augmentation (asr/data/processing.py:74-78): signal += trunc(gain_b * n), n ~ N(0, 1) from a counter-based
+// generator (Box-Muller over two 32-bit hashes of (seed, utterance, sample)); the reference draws from NumPy's global
+// stream, so only the distribution can match, not the samples
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ void add_white_noise_kernel(float* __restrict__ signals, const int* __restrict__ lengths, long long pitch, int B,
+                                       const float* __restrict__ gain, unsigned long long seed) {
+    const int b = blockIdx.y;
+    const int N = lengths[b];
+    const float g = gain[b];
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const unsigned c = (unsigned)n * 2u;
+        const unsigned k = hash32((unsigned)seed ^ (unsigned)(seed >> 32) ^ ((unsigned)b * 0x9e3779b9u));
+        const unsigned u1 = hash32(c ^ k), u2 = hash32((c + 1u) ^ k);
+        const float f1 = ((float)(u1 >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+        const float f2 = (float)(u2 >> 8) * (1.0f / 16777216.0f);
+        const float z = sqrtf(-2.0f * logf(f1)) * cosf(6.283185307179586f * f2);
+        signals[(size_t)b * pitch + n] += truncf(g * z);                        // noise.astype(np.int16) truncates toward zero
+    }
+}
+
+// running per-(channel, mel) statistics over every frame seen (asr/data/loaders/base.py:64-80), updated utterance by
+// utterance with the reference's recursion, in float64; one workgroup per (channel, mel) pair.
+//   new_mean = old_mean + (sum - n old_mean) / (total + n)
+//   new_nvar = old_nvar + sqsum - sum (new_mean + old_mean) + n new_mean old_mean
+// also writes mean and the unbiased standard deviation sqrt(nvar / (total - 1)) (:39-41) as float32
+__global__ __launch_bounds__(256) void running_stats_kernel(const float* __restrict__ x, const int* __restrict__ lengths, int B,
+                                                            int CM, int T, long long total_before, double* __restrict__ mean,
+                                                            double* __restrict__ nvar, float* __restrict__ mean32,
+                                                            float* __restrict__ std32) {
+    __shared__ double ssum[4], ssq[4];
+    const int cm = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double mu = mean[cm], nv = nvar[cm];
+    long long total = total_before;
+    for (int b = 0; b < B; ++b) {
+        const int n = min(lengths[b], T);
+        if (n <= 0) continue;
+        const float* p = x + ((size_t)b * CM + cm) * T;
+        double s = 0.0, q = 0.0;
+        for (int t = tid; t < n; t += 256) {
+            const double v = (double)p[t];
+            s += v; q += v * v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+        __syncthreads();
+        if (lane == 0) { ssum[wave] = s; ssq[wave] = q; }
+        __syncthreads();
+        s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+        q = ssq[0] + ssq[1] + ssq[2] + ssq[3];
+        const double new_mu = mu + (s - (double)n * mu) / (double)(total + n);
+        nv = nv + q - s * (new_mu + mu) + (double)n * new_mu * mu;
+        mu = new_mu;
+        total += n;
+    }
+    if (tid == 0) {
+        mean[cm] = mu;
+        nvar[cm] = nv;
+        mean32[cm] = (float)mu;
+        std32[cm] = total > 1 ? (float)sqrt(nv / (double)(total - 1)) : 1.0f;
+    }
+}
+
+// x[b][cm][t] <- (x - mean[cm]) / std[cm] over the whole padded array (asr/data/loaders/base.py:24)
+__global__ void normalize_bcmt_kernel(float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                      long long n, int CM, int T) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int cm = (int)((i / T) % CM);
+        x[i] = (x[i] - mean[cm]) / stdv[cm];
+    }
+}
+
 }  // namespace fbank
 }  // namespace asr
 
@@ -180,6 +268,42 @@ extern "C" int asr_deltas(void* stream, const float* logmel, const int32_t* nfra
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(deltas_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, logmel, nframes, Fmax, nfilt, Tmax,
                        mean, stdv, out, B);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_cmn_pspec(void* stream, float* pspec, const int32_t* nframes, int B, int Fmax, int nbins) {
+    if (!pspec || !nframes || B <= 0 || Fmax <= 0 || nbins <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cmn_pspec_kernel, dim3((B * nbins + 255) / 256), dim3(256), 0, (hipStream_t)stream, pspec, nframes, B, Fmax, nbins);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_add_white_noise(void* stream, float* signals, const int32_t* lengths, long long pitch, int B,
+                                   const float* gain, unsigned long long seed) {
+    if (!signals || !lengths || !gain || B <= 0 || pitch <= 0) return ASR_ERR_BAD_ARG;
+    long long g = (pitch + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(add_white_noise_kernel, dim3((unsigned)g, B), dim3(256), 0, (hipStream_t)stream, signals, lengths, pitch, B, gain, seed);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_running_stats_update(void* stream, const float* x, const int32_t* lengths, int B, int CM, int T,
+                                        long long total_before, double* mean, double* nvar, float* mean32, float* std32) {
+    if (!x || !lengths || !mean || !nvar || !mean32 || !std32 || B <= 0 || CM <= 0 || T <= 0 || total_before < 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(running_stats_kernel, dim3(CM), dim3(256), 0, (hipStream_t)stream, x, lengths, B, CM, T, total_before, mean, nvar,
+                       mean32, std32);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_normalize_bcmt(void* stream, float* x, const float* mean, const float* stdv, int B, int CM, int T) {
+    if (!x || !mean || !stdv || B <= 0 || CM <= 0 || T <= 0) return ASR_ERR_BAD_ARG;
+    const long long n = (long long)B * CM * T;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(normalize_bcmt_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, n, CM, T);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

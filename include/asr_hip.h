@@ -64,6 +64,39 @@ int asr_logmel(void* stream, const float* pspec, const float* fbank, long long F
 int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B, int Fmax, int nfilt, int Tmax,
                const float* mean, const float* stdv, float* out);
 
+/* optional steps of Processor.extract_batch_features and the Loader's running statistics
+ *   asr_cmn_pspec            cepstral mean normalisation in the log-power domain (asr/data/processing.py:86-89), in place
+ *                            on the (B, Fmax, nbins) power spectrum, frames < nframes[b]
+ *   asr_add_white_noise      signal[b] += trunc(gain[b] * n), n ~ N(0, 1) (asr/data/processing.py:74-78; counter-based
+ *                            generator: the distribution matches, NumPy's stream does not), f32 signals in place
+ *   asr_running_stats_update asr/data/loaders/base.py:64-80 for every utterance of x (B, CM, T) f32 in turn (frames
+ *                            < lengths[b]); mean / nvar (CM) float64 state, total_before = frames seen so far; also
+ *                            writes mean32 and the unbiased std32 = sqrt(nvar / (total - 1)) (:39-41)
+ *   asr_normalize_bcmt       x <- (x - mean[cm]) / std[cm] over the whole padded array (:24), in place
+ */
+int asr_cmn_pspec(void* stream, float* pspec, const int32_t* nframes, int B, int Fmax, int nbins);
+int asr_add_white_noise(void* stream, float* signals, const int32_t* lengths, long long pitch, int B, const float* gain,
+                        unsigned long long seed);
+int asr_running_stats_update(void* stream, const float* x, const int32_t* lengths, int B, int CM, int T,
+                             long long total_before, double* mean, double* nvar, float* mean32, float* std32);
+int asr_normalize_bcmt(void* stream, float* x, const float* mean, const float* stdv, int B, int CM, int T);
+
+/* ---------------------------------------------------------------------------------------- greedy decode + CER
+ * The evaluation loop of run/ctc/cnn/dev.py:100-108 and asr/error.py:7-68 for a whole minibatch.
+ *   asr_argmax_rows    ids[b][t] = argmax_v logits[t][b][v] (first maximum, as np.argmax), logits (T, B, V) f32
+ *   asr_ctc_collapse   per utterance: drop blanks and repeats (asr/error.py:38-47) of ids (B, T), frames < lengths[b]
+ *                      (NULL: all T, as the reference), compacted into out (B, T) padded with blank, out_len (B);
+ *                      merge_repeats = 0 drops blanks only (the label side, asr/error.py:33-37)
+ *   asr_edit_distance  Levenshtein distance of `pairs` (reference, hypothesis) id rows (asr/error.py:7-24, without the
+ *                      division by len(r)); dist = len(h) when len(r) == 0.  int32 arithmetic (the reference's uint8
+ *                      table is defined up to 255 tokens)
+ */
+int asr_argmax_rows(void* stream, const float* logits, int T, int B, int V, int32_t* ids);
+int asr_ctc_collapse(void* stream, const int32_t* ids, const int32_t* lengths, int B, int T, int blank, int merge_repeats,
+                     int32_t* out, int32_t* out_len);
+int asr_edit_distance(void* stream, const int32_t* ref, const int32_t* ref_len, int ref_pitch, const int32_t* hyp,
+                      const int32_t* hyp_len, int hyp_pitch, int pairs, int32_t* dist);
+
 /* ---------------------------------------------------------------------------------------- dense projections
  * bf16 MFMA GEMMs (f32 accumulate).  Replace the BLAS/cuDNN calls behind chainer.links.Linear, the 1x1
  * ConvolutionND of asr/nn/convolution_1d.py:7-38, the SRU projection asr/nn/sru.py:340-341,421-429 and -- through

@@ -213,7 +213,8 @@ def g_sru(sru):
 
 def g_text(vocab, error):
     ids, inv = vocab.get_unigram_ids()
-    sents = ["キョウワイイテンキデス", "ヴァイオリン", "ファッション", "シェークスピア", "ア"]
+    sents = ["キョウワイイテンキデス", "ヴァイオリン", "ファッション", "シェークスピア", "ア", "ヴェルディ", "クヮルテット", "スィート",
+             "テュニス", "ミェヴ", "フュージョン"]
     toks = [vocab.convert_sentence_to_unigram_tokens(s) for s in sents]
     tok_ids = [vocab.convert_sentence_to_unigram_ids(s, ids) for s in sents]
     rs = np.random.RandomState(3)
@@ -231,9 +232,42 @@ def g_text(vocab, error):
     lev = [error.compute_character_error_rate(r, h) for r, h in zip(pairs_r, pairs_h)]
     import json
     with open(os.path.join(OUT, "text.json"), "w") as f:
-        json.dump(dict(vocab_size=len(ids), blank=vocab.ID_BLANK, sentences=sents, tokens=toks, token_ids=tok_ids,
+        json.dump(dict(vocab_size=len(ids), blank=vocab.ID_BLANK, unigram_tokens=list(vocab.UNIGRAM_TOKENS),
+                       sutegana=list(vocab.SUTEGANA), collapse=dict(vocab.UNIGRAM_COLLAPSE),
+                       sentences=sents, tokens=toks, token_ids=tok_ids,
                        y=y.tolist(), t=t.tolist(), cer_mean=cer, cer_each=per, lev_r=pairs_r, lev_h=pairs_h, lev=lev),
                   f, ensure_ascii=False, indent=1)
+
+
+def g_minibatch(vocab):
+    """asr/data/processing.py:113-173 (Processor.features_to_minibatch) called unbound on a stand-in self: padding,
+    unigram / bigram ids, and the truncation of labels that cannot be aligned in x_length frames."""
+    spec = importlib.util.spec_from_file_location("refasr.data.processing", os.path.join(REF, "asr/data/processing.py"))
+    proc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(proc)
+    ids, _ = vocab.get_unigram_ids()
+    ids = dict(ids)
+    for tok in ("キョ" + "ウ", "イ" + "イ", "テ" + "ン"):          # a few bigram entries, the rest stay out of vocabulary (-1)
+        ids[tok] = len(ids)
+    sents = ["キョウワイイテンキデス", "アアアアアア", "ファッション", "ア", "ヴァイオリンノオト"]
+    lens = [40, 9, 6, 3, 11]           # utterances 1, 2 and 4 are too short for their transcription
+    rs = np.random.RandomState(11)
+    feats = [tuple(rs.randn(40, n).astype(np.float64) for _ in range(3)) for n in lens]
+
+    class Self(object):
+        using_delta = True
+        using_delta_delta = True
+        num_mel_filters = 40
+    maxs = max(len(s) for s in sents)
+    x, xl, t, tl, bg = proc.Processor.features_to_minibatch(Self(), feats, sents, max(lens), maxs, ids, 0)
+    out = dict(x=x, x_length=np.asarray(xl), t=t, t_length=np.asarray(tl), bigram=bg, lens=np.asarray(lens), max_sentence_length=np.asarray(maxs))
+    for i, f in enumerate(feats):
+        for c in range(3):
+            out["feat%d_%d" % (i, c)] = f[c]
+    np.savez_compressed(os.path.join(OUT, "minibatch.npz"), **out)
+    import json
+    with open(os.path.join(OUT, "minibatch.json"), "w") as f:
+        json.dump(dict(sentences=sents, token_ids=ids), f, ensure_ascii=False, indent=1)
 
 
 def g_stats():
@@ -277,12 +311,16 @@ def main():
     sys.modules["refasr"] = pkg
     sys.modules["refasr.vocab"] = vocab
     sys.modules["refasr.utils"] = types.ModuleType("refasr.utils")
-    for n in ("printb", "printr", "stdout"):
+    for n in ("printb", "printr", "printc", "stdout"):
         setattr(sys.modules["refasr.utils"], n, print)
     spec = importlib.util.spec_from_file_location("refasr.error", os.path.join(REF, "asr/error.py"))
     error = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(error)
     g_text(vocab, error)
+    sys.modules["refasr.data"] = types.ModuleType("refasr.data")
+    sys.modules["refasr.data"].__path__ = [os.path.join(REF, "asr/data")]
+    sys.modules["refasr.fft"] = fft
+    g_minibatch(vocab)
     g_stats()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
