@@ -29,6 +29,7 @@ SIGNATURES = {
     "asr_deltas": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     "asr_cmn_pspec": (c_int, [c_void_p] * 3 + [c_int] * 3),
     "asr_add_white_noise": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_void_p, ctypes.c_ulonglong]),
+    "asr_augment_specgram": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "asr_running_stats_update": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_longlong] + [c_void_p] * 4),
     "asr_normalize_bcmt": (c_int, [c_void_p] * 4 + [c_int] * 3),
     "asr_argmax_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -417,3 +417,12 @@ def normalize_bcmt(x, mean32, std32):
     CM = x.numel() // (B * T)
     check(_lib.lib().asr_normalize_bcmt(stream(), ptr(x), ptr(mean32), ptr(std32), B, CM, T), "asr_normalize_bcmt")
     return x
+
+
+def augment_specgram(pspec, nframes_out, speed, ratio, Fmax_out):
+    """(B, Fin, nbins) f32 power spectra -> (B, Fmax_out, nbins): asr/fft.py:21-50 with given float64 factors per utterance."""
+    B, Fin, nbins = pspec.shape
+    out = torch.empty((B, Fmax_out, nbins), dtype=F32, device=pspec.device)
+    rc = _lib.lib().asr_augment_specgram(stream(), ptr(pspec), ptr(nframes_out), ptr(speed), ptr(ratio), B, Fin, Fmax_out, nbins, ptr(out))
+    check(rc, "asr_augment_specgram")
+    return out

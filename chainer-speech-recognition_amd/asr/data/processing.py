@@ -42,16 +42,26 @@ class Processor(fft.Processor):
 
     def extract_batch_features(self, batch, augmentation=None, apply_cmn=False):
         """batch: list of (signal int16 1-d array, sentence).  White-noise augmentation (asr/data/processing.py:74-78) and
-        CMN in the log-power domain (:86-89) run on the GPU; the spectrogram warps of :83-84 are SURVEY row f3."""
+        the speed / vocal-tract warps (:83-84, asr/fft.py:21-50; random factors drawn on the host in the reference's order)
+        and CMN in the log-power domain (:86-89) all run on the GPU."""
         signals = [np.asarray(s) for s, _ in batch]
         sentences = [sent for _, sent in batch]
         noise = None
         if augmentation is not None and getattr(augmentation, "add_noise", False):
             gains = np.clip(np.random.normal(200, 100, size=len(signals)), 0, 500).astype(np.float32)
             noise = (gains, int(np.random.randint(0, 2 ** 31 - 1)))
+        warp = None
         if augmentation is not None and hasattr(augmentation, "using_augmentation") and augmentation.using_augmentation():
-            raise NotImplementedError("speed / vocal-tract spectrogram warps (asr/fft.py:21-50) are not on the device path yet")
-        x, x_length = self.logfbank_batch(signals, noise=noise, apply_cmn=apply_cmn)
+            # the reference's draw order per utterance (asr/fft.py:26,39): speed, then vocal-tract ratio
+            speed, ratio = np.ones(len(signals)), np.ones(len(signals))
+            for i in range(len(signals)):
+                if augmentation.change_speech_rate:
+                    speed[i] = max(min(np.random.normal(1, 0.15), 1.2), 0.8)
+                if augmentation.change_vocal_tract:
+                    ratio[i] = max(min(np.random.normal(1, 0.15), 1.2), 0.8)
+            if augmentation.change_speech_rate or augmentation.change_vocal_tract:
+                warp = (speed, ratio)
+        x, x_length = self.logfbank_batch(signals, noise=noise, apply_cmn=apply_cmn, warp=warp)
         lengths = [int(v) for v in x_length.cpu().numpy()]
         keep = [i for i, n in enumerate(lengths) if n > 0]              # :102-103 drops empty utterances
         assert len(keep) > 0

@@ -151,11 +151,11 @@ class Processor(object):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._window_d = self._fbank_d = None
 
-    def logfbank_batch(self, signals, mean=None, std=None, noise=None, apply_cmn=False):
+    def logfbank_batch(self, signals, mean=None, std=None, noise=None, apply_cmn=False, warp=None):
         """signals: list of 1-d int16 arrays/tensors (or a padded (B, N) tensor + lengths tuple).  Returns
         x (B, 3, nmel, Tmax) float32 on the GPU, zero padded, and x_length (B) int32 (asr/data/processing.py:113-173).
         noise = (gain per utterance, seed): white-noise augmentation (:74-78); apply_cmn: cepstral mean normalisation in
-        the log-power domain (:86-89)."""
+        the log-power domain (:86-89); warp = (speed per utterance, ratio per utterance) float64: asr/fft.py:21-50."""
         dev = self.device
         if self._window_d is None:
             self._window_d, self._fbank_d = _dev_const(self.window, dev), _dev_const(self.fbank, dev)
@@ -178,10 +178,18 @@ class Processor(object):
         if noise is not None:
             gains, seed = noise
             padded = _ops_mod().add_white_noise(_int16_to_f32(padded), lengths, _dev_const(gains, dev), seed)
-        if apply_cmn:
+        if apply_cmn or warp is not None:
             pspec, _ = _specgram(padded, lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,
                                  self._window_d, None, True)
-            _ops_mod().cmn_pspec(pspec, nfr)
+            if warp is not None:
+                speed, ratio = (np.asarray(w, dtype=np.float64) for w in warp)
+                frames = [int(f / sp) for f, sp in zip(frames, speed)]          # new_length = int(len(specgram) / speed)
+                Fmax = max(frames)
+                Tmax = max(Fmax - 2, 1)
+                nfr = torch.tensor(frames, dtype=torch.int32, device=dev)
+                pspec = _ops_mod().augment_specgram(pspec, nfr, torch.from_numpy(speed).to(dev), torch.from_numpy(ratio).to(dev), Fmax)
+            if apply_cmn:
+                _ops_mod().cmn_pspec(pspec, nfr)
             logmel = compute_logmel(pspec.reshape(len(lens) * Fmax, -1), fbank=self._fbank_d).reshape(len(lens), Fmax, -1)
         else:
             _, logmel = _specgram(padded, lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,

@@ -148,6 +148,29 @@ __global__ void cmn_pspec_kernel(float* __restrict__ pspec, const int* __restric
     for (int f = 0; f < F; ++f) p[(size_t)f * nbins] = expf(logf(p[(size_t)f * nbins]) - mean);
 }
 
+// speed / vocal-tract-length perturbation by nearest-index resampling (asr/fft.py:21-50):
+//   out[f][k] = in[int(f * speed)][min(int(k * ratio), nbins - 1)],  f < nframes_out[b] = int(nframes_in[b] / speed)
+// index arithmetic in float64 like NumPy's (np.arange(n) * speed).astype(int); speed = ratio = 1 is the identity
+__global__ void augment_specgram_kernel(const float* __restrict__ in, const int* __restrict__ nframes_out,
+                                        const double* __restrict__ speed, const double* __restrict__ ratio, int B, int Fin,
+                                        int Fout, int nbins, float* __restrict__ out) {
+    const long long n = (long long)B * Fout * nbins;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % nbins);
+        const int f = (int)((i / nbins) % Fout);
+        const int b = (int)(i / ((long long)nbins * Fout));
+        float v = 0.f;
+        if (f < nframes_out[b]) {
+            int fs = (int)((double)f * speed[b]);
+            if (fs > Fin - 1) fs = Fin - 1;
+            int ks = (int)((double)k * ratio[b]);
+            if (ks > nbins - 1) ks = nbins - 1;
+            v = in[((size_t)b * Fin + fs) * nbins + ks];
+        }
+        out[i] = v;
+    }
+}
+
 // white-noise augmentation (asr/data/processing.py:74-78): signal += trunc(gain_b * n), n ~ N(0, 1) from a counter-based
 // generator (Box-Muller over two 32-bit hashes of (seed, utterance, sample)); the reference draws from NumPy's global
 // stream, so only the distribution can match, not the samples
@@ -304,6 +327,19 @@ extern "C" int asr_normalize_bcmt(void* stream, float* x, const float* mean, con
     long long g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(normalize_bcmt_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, n, CM, T);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_augment_specgram(void* stream, const float* pspec_in, const int32_t* nframes_out, const double* speed,
+                                    const double* ratio, int B, int Fmax_in, int Fmax_out, int nbins, float* pspec_out) {
+    if (!pspec_in || !nframes_out || !speed || !ratio || !pspec_out || B <= 0 || Fmax_in <= 0 || Fmax_out <= 0 || nbins <= 0)
+        return ASR_ERR_BAD_ARG;
+    const long long n = (long long)B * Fmax_out * nbins;
+    long long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(augment_specgram_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pspec_in, nframes_out, speed, ratio,
+                       B, Fmax_in, Fmax_out, nbins, pspec_out);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -69,6 +69,9 @@ int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B,
  *                            on the (B, Fmax, nbins) power spectrum, frames < nframes[b]
  *   asr_add_white_noise      signal[b] += trunc(gain[b] * n), n ~ N(0, 1) (asr/data/processing.py:74-78; counter-based
  *                            generator: the distribution matches, NumPy's stream does not), f32 signals in place
+ *   asr_augment_specgram     speed / vocal-tract perturbation by nearest-index resampling (asr/fft.py:21-50):
+ *                            out[b][f][k] = in[b][int(f speed_b)][min(int(k ratio_b), nbins-1)], f < nframes_out[b]
+ *                            (= int(nframes_in[b] / speed_b), computed by the caller), zero beyond
  *   asr_running_stats_update asr/data/loaders/base.py:64-80 for every utterance of x (B, CM, T) f32 in turn (frames
  *                            < lengths[b]); mean / nvar (CM) float64 state, total_before = frames seen so far; also
  *                            writes mean32 and the unbiased std32 = sqrt(nvar / (total - 1)) (:39-41)
@@ -77,6 +80,8 @@ int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B,
 int asr_cmn_pspec(void* stream, float* pspec, const int32_t* nframes, int B, int Fmax, int nbins);
 int asr_add_white_noise(void* stream, float* signals, const int32_t* lengths, long long pitch, int B, const float* gain,
                         unsigned long long seed);
+int asr_augment_specgram(void* stream, const float* pspec_in, const int32_t* nframes_out, const double* speed,
+                         const double* ratio, int B, int Fmax_in, int Fmax_out, int nbins, float* pspec_out);
 int asr_running_stats_update(void* stream, const float* x, const int32_t* lengths, int B, int CM, int T,
                              long long total_before, double* mean, double* nvar, float* mean32, float* std32);
 int asr_normalize_bcmt(void* stream, float* x, const float* mean, const float* stdv, int B, int CM, int T);

@@ -215,3 +215,44 @@ def test_eval_loop_on_a_model(device):
     got = error.compute_minibatch_error(ids, labels.to(device), 0, tok, inv)
     want = otext.minibatch_error(ids.cpu().numpy(), labels.numpy(), 0)
     assert abs(got - want) < 1e-12
+
+
+def test_augment_specgram_against_reference(device):
+    """asr/fft.py:21-50 under the reference's seeds (tests/golden/augment.npz): bit-identical gather"""
+    from asr import _ops
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    pspec = g["pspec"].astype(np.float32)
+    for seed, want, use_ratio in ((int(g["seed_both"]), g["aug_both"], True), (int(g["seed_speed"]), g["aug_speed"], False)):
+        rs = np.random.RandomState(seed)
+        speed = max(min(rs.normal(1, 0.15), 1.2), 0.8)
+        ratio = max(min(rs.normal(1, 0.15), 1.2), 0.8) if use_ratio else 1.0
+        n_out = int(len(pspec) / speed)
+        assert n_out == want.shape[0]
+        pd = torch.from_numpy(np.stack([pspec, pspec])).to(device)
+        out = _ops.augment_specgram(pd, torch.tensor([n_out, n_out], dtype=torch.int32, device=device),
+                                    torch.tensor([speed, 1.0], dtype=torch.float64, device=device),
+                                    torch.tensor([ratio, 1.0], dtype=torch.float64, device=device), n_out + 3)
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got[0, :n_out], want.astype(np.float32))
+        assert (got[0, n_out:] == 0).all()
+        np.testing.assert_array_equal(got[1, :n_out], pspec[:n_out])          # speed = ratio = 1: identity
+
+
+def test_extract_batch_features_with_warps(device):
+    from asr.data.augment import AugmentationOption
+    from asr.data.processing import Processor
+    rs = np.random.RandomState(9)
+    sigs = [(rs.randn(12000 + 1600 * i) * 2000).astype(np.int16) for i in range(3)]
+    aug = AugmentationOption()
+    aug.change_speech_rate = aug.change_vocal_tract = True
+    proc = Processor(device=device)
+    np.random.seed(77)
+    feats, sents, maxf, maxs = proc.extract_batch_features([(s_, "アイ") for s_ in sigs], aug)
+    np.random.seed(77)
+    for i, s_ in enumerate(sigs):
+        spec = offt.get_specgram(s_, 16000, 0.032, 0.01, 512, 0.97, np.hanning)
+        spec = offt.augment_specgram(spec, True, True)              # draws speed, ratio from np.random in the same order
+        lm, dl, dd = offt.compute_deltas(offt.compute_logmel(spec, proc.fbank))
+        assert feats[i][0].shape[1] == lm.shape[0]
+        np.testing.assert_allclose(feats[i][0].cpu().numpy(), lm.T, rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(feats[i][2].cpu().numpy(), dd.T, rtol=2e-3, atol=4e-3)
