@@ -228,10 +228,43 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
 GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only, 3 persistent + grouped backward
 
 
+_SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky
+_STATUS = {}        # device index -> [pinned host word, event of the copy in flight]
+
+
+def _sync_buffer(dev, nbytes):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _SYNC.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros(max(nbytes // 4 + 1, 2048), dtype=torch.int32, device=dev)
+        _SYNC[key] = buf
+    return buf
+
+
+def gru_poll_status():
+    """Called once per step (optimizer.update): looks, without synchronising, at the abort words copied out during the
+    previous step and raises if a persistent GRU launch gave up; then queues this step's copy."""
+    for (idx, _), buf in list(_SYNC.items()):
+        st = _STATUS.get(idx)
+        if st is None:
+            st = _STATUS[idx] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+        if st[1] is not None and st[1].query() and int(st[0][0]) != 0:
+            code = int(st[0][0])
+            buf[1023:1024].zero_()
+            st[0][0] = 0
+            st[1] = None
+            raise _lib.AsrHipError("a persistent GRU kernel gave up an in-launch wait (code %d): the results of that step are "
+                                   "invalid" % code)
+        if st[1] is None or st[1].query():
+            st[0].copy_(buf[1023:1024], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st[1] = ev
+
+
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
-    sync = torch.empty(_lib.lib().asr_gru_sync_bytes(B, H, ndir) // 4, dtype=torch.int32, device=dev)
-    sync[1023:1024].zero_()
+    sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
@@ -249,7 +282,8 @@ LAST_SYNC = [None]
 def gru_check_sync():
     """(debug / tests) synchronise and raise if the last persistent GRU launch abandoned an in-launch wait"""
     s = LAST_SYNC[0]
-    if s is not None and int(s.cpu()[1023]) != 0:
+    if s is not None and int(s[1023:1024].cpu()[0]) != 0:
+        s[1023:1024].zero_()
         raise _lib.AsrHipError("persistent GRU kernel timed out waiting for another workgroup")
 
 
@@ -258,9 +292,8 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
     dev = dy.device
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
+    sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
-    sync = torch.empty(_lib.lib().asr_gru_sync_bytes(B, H, ndir) // 4, dtype=torch.int32, device=dev)
-    sync[1023:1024].zero_()
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
                                 ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_bwd")

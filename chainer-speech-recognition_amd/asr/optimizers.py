@@ -65,6 +65,7 @@ class Optimizer(object):
         self._ensure_flat()
         from .functions import join_side_stream
         join_side_stream()                  # weight-gradient GEMMs issued on the side stream
+        _ops.gru_poll_status()              # raises if a persistent GRU launch of the previous step gave up a wait
         scale = 1.0
         if self.communicator is not None:
             self.communicator.finish_backward(self)

@@ -1625,6 +1625,14 @@ static int check_dims(int T, int B, int H, int ndir) {
 // grouped form: 8 workgroups x 64 units, groups of 8 utterances; at most 4 groups x 2 directions x 8 = 64 workgroups
 static bool can_group(int B, int H) { return H % 128 == 0 && H <= 512 && B <= 4 * RG; }
 
+// control words [0, 4092) and the area behind them are zeroed by every call; the abort word (int 1023) is NOT: it is
+// sticky, so that a caller reusing one sync_ws sees a failed launch later (and every later launch gives up at once)
+static bool clear_sync(void* sync_ws, size_t extra, hipStream_t st) {
+    if (hipMemsetAsync(sync_ws, 0, 4092, st) != hipSuccess) return false;
+    if (extra && hipMemsetAsync((char*)sync_ws + 4096, 0, extra, st) != hipSuccess) return false;
+    return true;
+}
+
 static bool can_persist(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
     if (mode == 1 || !sync_ws) return false;
     if (B > 16 * MT || (H / 16) * ndir > 128 || H > 1024) return false;
@@ -1647,7 +1655,7 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     const bool grouped = persist && can_group(B, H);
     const int Gio = (B + 7) / 8;
     if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
-        if (hipMemsetAsync(sync_ws, 0, 4096 + kShardBytes, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
         const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
         const int forge = mode == 7;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
@@ -1667,7 +1675,7 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
 #undef ASR_FWDIO
     } else if (grouped) {
         const int G = (B + RG - 1) / RG;
-        if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!clear_sync(sync_ws, (size_t)ndir * G * 2 * RG * (H / 2) * 8, st)) return ASR_ERR_LAUNCH;
         const dim3 ggrid(H / UW, G, ndir), gblock(640);
 #define ASR_FWDG(K)                                                                                                       \
     do {                                                                                                                  \
@@ -1684,7 +1692,7 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
         }
 #undef ASR_FWDG
     } else if (persist) {
-        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!clear_sync(sync_ws, 0, st)) return ASR_ERR_LAUNCH;
 #define ASR_FWDP(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)fwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
@@ -1728,7 +1736,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
     const bool grouped = persist && can_group(B, H) && db_ih && db_hh && mode == 3;
     if (grouped) {
         const int G = (B + RG - 1) / RG;
-        if (hipMemsetAsync(sync_ws, 0, 4096 + (size_t)ndir * G * 2 * RG * (3 * H / 2) * 8, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!clear_sync(sync_ws, (size_t)ndir * G * 2 * RG * (3 * H / 2) * 8, st)) return ASR_ERR_LAUNCH;
         const dim3 ggrid(H / UW, G, ndir), gblock(704);
         constexpr int kBwdLds = 150 * 1024;
 #define ASR_BWDG(K)                                                                                                       \
@@ -1754,7 +1762,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         const int rows = 8;
         const int G = (B + rows - 1) / rows;
         if (ndir * G <= 16) {
-            if (hipMemsetAsync(sync_ws, 0, 4096 + kShardBytes, st) != hipSuccess) return ASR_ERR_LAUNCH;
+            if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
             const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
             const int forge = mode == 7;
             const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
@@ -1779,7 +1787,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         }
     }
     if (persist) {
-        if (hipMemsetAsync(sync_ws, 0, 4096, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        if (!clear_sync(sync_ws, 0, st)) return ASR_ERR_LAUNCH;
 #define ASR_BWDP(K)                                                                                                       \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)bwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \

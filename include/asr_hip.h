@@ -188,7 +188,9 @@ int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, floa
  * find themselves on one XCD (what mode 0 selects; decided inside the launch, falls back to the mode-2 protocol
  * otherwise), 7 = mode 4 with a forged split placement (test hook for that fall-back).  Modes >= 2 return
  * ASR_ERR_UNSUPPORTED instead of falling back to mode 1.
- * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).
+ * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).  That word
+ * is sticky: the calls zero every other control word but never this one, so a caller that reuses one sync_ws (zeroed
+ * once) can look at it whenever convenient; once set, later launches give up immediately.
  */
 size_t asr_gru_sync_bytes(int B, int H, int ndir);
 int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,

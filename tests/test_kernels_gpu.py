@@ -273,3 +273,30 @@ def test_cast_transpose_permute(device):
     x = torch.randn(3, 4, 5, 6, generator=g).to(device)
     y = _ops.permute4(x, (6, 3, 5, 4), (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), BF16)
     assert torch.equal(y.cpu(), x.permute(3, 0, 2, 1).contiguous().to(BF16).cpu())
+
+
+def test_gru_abort_word_is_sticky_and_reported(device):
+    """a set abort word survives later launches (they give up at once) and optimizer-side polling raises"""
+    from asr import _ops, _lib
+    T, B, H, ndir = 6, 4, 64, 2
+    g = torch.Generator().manual_seed(0)
+    gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device)
+    whh = (torch.randn(ndir, 3 * H, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    bhh = torch.zeros(ndir * 3 * H, device=device)
+    _ops.gru_fwd(gi, whh, bhh, T, B, H, ndir)
+    torch.cuda.synchronize()
+    _ops.gru_check_sync()
+    _ops.gru_poll_status(); torch.cuda.synchronize(); _ops.gru_poll_status()      # clean: no exception
+    _ops.LAST_SYNC[0][1023:1024].fill_(1)                                          # pretend a launch gave up
+    _ops.gru_fwd(gi, whh, bhh, T, B, H, ndir)                                     # must terminate (bounded, gives up at once)
+    torch.cuda.synchronize()
+    assert int(_ops.LAST_SYNC[0][1023:1024].cpu()[0]) != 0
+    _ops.gru_poll_status()
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.AsrHipError):
+        _ops.gru_poll_status()
+    torch.cuda.synchronize()
+    y, *_ = _ops.gru_fwd(gi, whh, bhh, T, B, H, ndir)                             # the word was reset: back to normal
+    torch.cuda.synchronize()
+    _ops.gru_check_sync()
+    assert torch.isfinite(y.float()).all()
