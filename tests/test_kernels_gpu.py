@@ -300,3 +300,43 @@ def test_gru_abort_word_is_sticky_and_reported(device):
     torch.cuda.synchronize()
     _ops.gru_check_sync()
     assert torch.isfinite(y.float()).all()
+
+
+def test_gru_full_size_forms_agree(device):
+    """BASELINE size (T=1000, B=32, H=512, bidirectional): the persistent kernels (XCD-local hand-off, placement-free
+    hand-off, forged split placement) against the one-launch-per-step kernels -- same arithmetic, so the states agree to
+    bf16 rounding of the exchanged h, and the saved f32 states / gates to 1e-3."""
+    from asr import _ops
+    T, B, H, ndir = 1000, 32, 512, 2
+    g = torch.Generator().manual_seed(1)
+    gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device)
+    whh = (torch.randn(ndir, 3 * H, H, generator=g) / H ** 0.5).to(device)
+    whh16 = whh.to(torch.bfloat16).contiguous()
+    whhT16 = whh.transpose(1, 2).contiguous().to(torch.bfloat16)
+    bhh = (torch.randn(ndir * 3 * H, generator=g) * 0.1).to(device)
+    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    res = {}
+    try:
+        for mode in (1, 2, 0, 7):
+            _ops.GRU_MODE[0] = mode
+            y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir)
+            dbi = torch.zeros(ndir * 3 * H, device=device)
+            dbh = torch.zeros(ndir * 3 * H, device=device)
+            dgi, dgh = _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh)
+            torch.cuda.synchronize()
+            _ops.gru_check_sync()
+            res[mode] = [t.float().clone() for t in (y, hseq, gates, dgi, dgh, dbi, dbh)]
+    finally:
+        _ops.GRU_MODE[0] = 0
+    ref = res[1]
+    for mode in (2, 0, 7):
+        for name, a, r, tol in zip(("y", "hseq", "gates", "dgi", "dgh", "db_ih", "db_hh"), res[mode], ref,
+                                   (2e-2, 2e-3, 2e-3, 2e-2, 2e-2, 1e-2, 1e-2)):
+            err = float((a - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+            assert err < tol, (mode, name, err)
+    # the three persistent forms run the same instruction sequence per workgroup: bit-identical among themselves
+    # (bias gradients excepted: their float atomics land in any order)
+    for a, b_ in zip(res[2][:5], res[0][:5]):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(res[2][:5], res[7][:5]):
+        assert torch.equal(a, b_)
