@@ -23,6 +23,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int NT_LDS_BYTES = 2 * (BM + BN) * BK * 2;   // 64 KiB, double buffered
 
+// Tile order.  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2), so id -> (row panel, column
+// tile) is chosen such that the XCD that first touches a row panel of A also computes all of that panel's column
+// tiles: panels go to XCDs in groups of 8 (panel % 8 = id % 8), the incomplete last group falls back to the plain order.
+// Only the L2 hit rate depends on the dispatch behaviour, never the result (the map is a bijection either way).
+// Used (tiles_n passed negative) when the whole B operand fits an L2 beside the panels in flight; otherwise plain order.
+__device__ __forceinline__ void tile_of(int bid, int tiles_m, int tiles_n_signed, int& tm, int& tn) {
+    const int tiles_n = tiles_n_signed < 0 ? -tiles_n_signed : tiles_n_signed;
+    if (tiles_n_signed > 0) {
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+        return;
+    }
+    const int full = (tiles_m >> 3) << 3;
+    if (bid < full * tiles_n) {
+        const int x = bid & 7, idx = bid >> 3;
+        tm = (idx / tiles_n) * 8 + x;
+        tn = idx - (idx / tiles_n) * tiles_n;
+    } else {
+        const int r = bid - full * tiles_n;
+        tm = full + r / tiles_n;
+        tn = r - (r / tiles_n) * tiles_n;
+    }
+}
+
 union Frag {
     bf16x8 v;
     uint4 u;
@@ -52,9 +76,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
                                                       int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                       int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // XCD-aware order: consecutive workgroup ids of one XCD walk along N first (they share the A panel in that L2)
-    const int bid = blockIdx.x;
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm, tn;
+    tile_of(blockIdx.x, (M + BM - 1) / BM, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -235,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt256_kernel(const uint16_t* __re
                                                             int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                             int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = blockIdx.x;
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    int tm, tn;
+    tile_of(blockIdx.x, (M + B2M - 1) / B2M, tiles_n, tm, tn);
     const int m0 = tm * B2M, n0 = tn * B2N;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -488,6 +511,7 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
+    const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;      // 2.5 MB of the 4 MB per XCD
     const bool aligned = (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
     if (aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024) {      // at least two rounds of 2 workgroups per CU
         static bool attr2 = false;
@@ -496,12 +520,12 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
             (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
             attr2 = true;
         }
-        const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N);
+        const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N) * (b_fits_l2 ? -1 : 1);
         if (out_bf16)
-            hipLaunchKernelGGL(gemm_nt256_kernel<uint16_t>, dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+            hipLaunchKernelGGL(gemm_nt256_kernel<uint16_t>, dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
                                (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, t2n);
         else
-            hipLaunchKernelGGL(gemm_nt256_kernel<float>, dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+            hipLaunchKernelGGL(gemm_nt256_kernel<float>, dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
                                (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, t2n);
         ASR_LAUNCH_CHECK();
         return ASR_OK;
@@ -509,7 +533,7 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     const bool glds = (K % BK) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
 #define ASR_NT(T, G, CT)                                                                                                  \
     hipLaunchKernelGGL((gemm_nt_kernel<T, G>), dim3(tiles_m * tiles_n), dim3(256), NT_LDS_BYTES, stream, (const uint16_t*)A, lda, \
-                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_n)
+                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, b_fits_l2 ? -tiles_n : tiles_n)
     if (out_bf16) { if (glds) ASR_NT(uint16_t, true, uint16_t); else ASR_NT(uint16_t, false, uint16_t); }
     else          { if (glds) ASR_NT(float, true, float); else ASR_NT(float, false, float); }
 #undef ASR_NT
