@@ -256,3 +256,31 @@ def test_extract_batch_features_with_warps(device):
         assert feats[i][0].shape[1] == lm.shape[0]
         np.testing.assert_allclose(feats[i][0].cpu().numpy(), lm.T, rtol=2e-3, atol=2e-3)
         np.testing.assert_allclose(feats[i][2].cpu().numpy(), dd.T, rtol=2e-3, atol=4e-3)
+
+
+def test_device_prefetcher(device):
+    """asr/data/prefetch.py: minibatches prepared on a side stream equal the ones prepared inline"""
+    from asr import vocab
+    from asr.data.loaders.base import Loader
+    from asr.data.prefetch import DevicePrefetcher
+    from asr.data.processing import Processor
+
+    class L(Loader):
+        def __init__(self):
+            super(L, self).__init__()
+            self.processor = Processor(device=device)
+            self.token_ids, _ = vocab.get_unigram_ids()
+            self.id_blank = 0
+    rs = np.random.RandomState(4)
+    raw = [[((rs.randn(9000 + 700 * j + 300 * i) * 1500).astype(np.int16), "アイウ"[: 1 + (i + j) % 3]) for j in range(3)] for i in range(4)]
+    want = []
+    inline = L()
+    for b in raw:
+        f, s, mf, ms = inline.extract_batch_features(b)
+        want.append(inline.features_to_minibatch(f, s, mf, ms))
+    torch.cuda.synchronize()
+    got = list(DevicePrefetcher(raw, L(), depth=2))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert torch.equal(a.cpu(), b.cpu())
