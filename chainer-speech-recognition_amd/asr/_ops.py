@@ -459,3 +459,32 @@ def augment_specgram(pspec, nframes_out, speed, ratio, Fmax_out):
     rc = _lib.lib().asr_augment_specgram(stream(), ptr(pspec), ptr(nframes_out), ptr(speed), ptr(ratio), B, Fin, Fmax_out, nbins, ptr(out))
     check(rc, "asr_augment_specgram")
     return out
+
+
+def batchnorm_stats(x2, eps, decay, avg_mean=None, avg_var=None):
+    """x2 (R, C) bf16 -> (mean, rstd) f32 (C); running averages updated in place when given."""
+    R, C = x2.shape
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x2.device)
+    mean = torch.empty(C, dtype=F32, device=x2.device)
+    rstd = torch.empty(C, dtype=F32, device=x2.device)
+    rc = _lib.lib().asr_batchnorm_stats(stream(), ptr(x2), R, C, float(eps), float(decay), ptr(ws), ptr(mean), ptr(rstd),
+                                        ptr(avg_mean), ptr(avg_var))
+    check(rc, "asr_batchnorm_stats")
+    return mean, rstd
+
+
+def batchnorm_fwd(x2, mean, rstd, gamma, beta):
+    R, C = x2.shape
+    y = torch.empty_like(x2)
+    check(_lib.lib().asr_batchnorm_fwd(stream(), ptr(x2), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), R, C, ptr(y)), "asr_batchnorm_fwd")
+    return y
+
+
+def batchnorm_bwd(x2, gy, mean, rstd, gamma, dgamma, dbeta, need_dx=True):
+    R, C = x2.shape
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x2.device)
+    dx = torch.empty_like(x2) if need_dx else None
+    rc = _lib.lib().asr_batchnorm_bwd(stream(), ptr(x2), ptr(gy), ptr(mean), ptr(rstd), ptr(gamma), R, C, ptr(ws), ptr(dx), ptr(dgamma),
+                                      ptr(dbeta))
+    check(rc, "asr_batchnorm_bwd")
+    return dx

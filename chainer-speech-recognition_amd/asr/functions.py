@@ -484,6 +484,58 @@ def layer_normalization(x, gamma, beta, out_f32=False):
     raise ValueError("layer normalisation expects a 3-d or 4-d input")
 
 
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, gamma, beta, avg_mean, avg_var, eps, decay, train):
+        if train:
+            mean, rstd = _ops.batchnorm_stats(x2, eps, decay, avg_mean, avg_var)
+        else:       # inference: the running statistics (chainer.config.train == False)
+            mean, rstd = avg_mean, _rsqrt_eps(avg_var, eps)
+        y = _ops.batchnorm_fwd(x2, mean, rstd, gamma.detach(), beta.detach())
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params = (gamma, beta)
+        ctx.meta = (ctx.needs_input_grad[0], train)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        need_dx, train = ctx.meta
+        gy = gy.contiguous()
+        if not train:
+            raise RuntimeError("backward through BatchNormalization in test mode is not supported (fixed statistics)")
+        dx = _ops.batchnorm_bwd(x2, gy, mean, rstd, gamma.detach(), grad_buffer(gamma), grad_buffer(beta), need_dx)
+        return dx, None, None, None, None, None, None, None
+
+
+def _rsqrt_eps(var, eps):
+    """1 / sqrt(var + eps) on C values through the library (asr_batchnorm_stats is not needed for fixed statistics)"""
+    import numpy as np
+    return torch.from_numpy((1.0 / np.sqrt(var.cpu().numpy().astype(np.float64) + eps)).astype(np.float32)).to(var.device)
+
+
+def batch_normalization(x, gamma, beta, avg_mean, avg_var, eps=2e-5, decay=0.9):
+    """chainer.links.BatchNormalization on a (B, C, H, T) [or (B, C, T), (B, C)] activation: per-channel statistics over
+    every other axis; train mode (functions.train_mode) uses and records the batch statistics."""
+    train = bool(train_mode[0])
+    if x.dim() == 4:
+        p = x.permute(3, 0, 2, 1)
+        if not (p.is_contiguous() and p.dtype == BF16):
+            p = phys4(x)
+        T, B, H, C = p.shape
+        y = _BatchNorm.apply(p.reshape(T * B * H, C), gamma, beta, avg_mean, avg_var, eps, decay, train)
+        return logical4(y.reshape(T, B, H, C))
+    if x.dim() == 3:
+        p = x.permute(2, 0, 1)
+        if not (p.is_contiguous() and p.dtype == BF16):
+            p = phys3(x)
+        T, B, C = p.shape
+        y = _BatchNorm.apply(p.reshape(T * B, C), gamma, beta, avg_mean, avg_var, eps, decay, train)
+        return logical3(y.reshape(T, B, C))
+    raise ValueError("batch normalisation expects a 3-d or 4-d input")
+
+
 # ---------------------------------------------------------------------------------------------- GRU
 def _cast_transposed_per_direction(w):
     """(ndir, 3H, H) f32 -> (ndir, H, 3H) bf16, written in place (no torch.stack copy)."""

@@ -236,6 +236,23 @@ class LayerNormalization(Link):
         return functions.layer_normalization(x, self.gamma, self.beta, self.output_float32)
 
 
+class BatchNormalization(Link):
+    """chainer.links.BatchNormalization (visible as asr.nn.BatchNormalization through `from chainer.links import *`,
+    asr/nn/nn.py:3): per-channel (axis 1) statistics over every other axis, eps 2e-5, running averages with decay 0.9
+    (unbiased variance), used instead of the batch statistics when functions.train_mode is off."""
+
+    def __init__(self, size, decay=0.9, eps=2e-5, initial_gamma=None, initial_beta=None):
+        super().__init__()
+        self.gamma = Parameter(get_initializer(1 if initial_gamma is None else initial_gamma)((size,)))
+        self.beta = Parameter(get_initializer(0 if initial_beta is None else initial_beta)((size,)))
+        self.register_buffer("avg_mean", torch.zeros(size, dtype=torch.float32))
+        self.register_buffer("avg_var", torch.ones(size, dtype=torch.float32))
+        self.decay, self.eps = decay, eps
+
+    def __call__(self, x):
+        return functions.batch_normalization(x, self.gamma, self.beta, self.avg_mean, self.avg_var, self.eps, self.decay)
+
+
 class GLU(object):
     """asr/nn/nn.py:267-281."""
 

@@ -160,6 +160,82 @@ __global__ __launch_bounds__(256) void bwd_f32x4_kernel(const float* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ batch normalisation
+// chainer.links.BatchNormalization reaches the reference API through `from chainer.links import *` (asr/nn/nn.py:3).
+// Statistics per channel over every other axis; in the (T, B, H, C) layout that is a column reduction over R = T*B*H rows.
+//   reduce : mode 0: out0[c] += sum_r x, out1[c] += sum_r x^2                      (float64 accumulators)
+//            mode 1: out0[c] += sum_r gy, out1[c] += sum_r gy * (x - mean[c]) * rstd[c]
+//   finish : mean = s/R, var = q/R - mean^2 (biased, the normalising one); rstd = 1/sqrt(var + eps); running averages
+//            avg = decay*avg + (1-decay)*batch with the UNBIASED variance var*R/(R-1) (Chainer's update rule)
+//   fwd    : y = gamma (x - mean) rstd + beta
+//   bwd    : dx = gamma rstd (gy - sgy/R - xhat sgx/R); dgamma += sgx, dbeta += sgy
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gy,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        long long R, int C, int rows_per_block, double* __restrict__ out0,
+                                                        double* __restrict__ out1) {
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f, b = 0.f;                 // a block covers few rows: float partials, float64 across blocks
+        const float mu = MODE ? mean[c] : 0.f, rs = MODE ? rstd[c] : 0.f;
+        for (long long r = r0; r < r1; ++r) {
+            const float xv = bf16_to_f32(x[r * C + c]);
+            if (MODE == 0) { a += xv; b += xv * xv; }
+            else { const float g = bf16_to_f32(gy[r * C + c]); a += g; b += g * (xv - mu) * rs; }
+        }
+        atomicAdd(out0 + c, (double)a);
+        atomicAdd(out1 + c, (double)b);
+    }
+}
+
+__global__ void bn_finish_kernel(const double* __restrict__ s, const double* __restrict__ q, long long R, int C, float eps,
+                                 float decay, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ avg_mean,
+                                 float* __restrict__ avg_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = s[c] / (double)R;
+    double var = q[c] / (double)R - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (avg_mean) {
+        const double unbiased = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        avg_mean[c] = decay * avg_mean[c] + (1.f - decay) * (float)mu;
+        avg_var[c] = decay * avg_var[c] + (1.f - decay) * (float)unbiased;
+    }
+}
+
+__global__ void bn_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, long long n, int C,
+                              uint16_t* __restrict__ y) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        y[i] = f32_to_bf16(gamma[c] * (bf16_to_f32(x[i]) - mean[c]) * rstd[c] + beta[c]);
+    }
+}
+
+__global__ void bn_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gy, const float* __restrict__ mean,
+                              const float* __restrict__ rstd, const float* __restrict__ gamma, const double* __restrict__ sgy,
+                              const double* __restrict__ sgx, long long R, int C, uint16_t* __restrict__ dx) {
+    const long long n = R * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float xhat = (bf16_to_f32(x[i]) - mean[c]) * rstd[c];
+        const float a = (float)(sgy[c] / (double)R), b = (float)(sgx[c] / (double)R);
+        dx[i] = f32_to_bf16(gamma[c] * rstd[c] * (bf16_to_f32(gy[i]) - a - xhat * b));
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sgy, const double* __restrict__ sgx, int C,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dgamma[c] += (float)sgx[c];
+    dbeta[c] += (float)sgy[c];
+}
+
 }  // namespace ln
 }  // namespace asr
 
@@ -321,6 +397,54 @@ extern "C" int asr_channel_affine(void* stream, const float* x, const float* sca
 extern "C" int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, float* g, float* b, int C) {
     if (!mean || !stdv || !g || !b || C <= 0) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(asr::wn::init_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, stdv, g, b, C);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_batchnorm_stats(void* stream, const void* x_bf16, long long R, int C, float eps, float decay, double* ws2C,
+                                   float* mean, float* rstd, float* avg_mean, float* avg_var) {
+    if (!x_bf16 || !ws2C || !mean || !rstd || R <= 0 || C <= 0 || (avg_mean == nullptr) != (avg_var == nullptr)) return ASR_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws2C, 0, sizeof(double) * 2 * C, s) != hipSuccess) return ASR_ERR_LAUNCH;
+    const int rpb = 64;
+    hipLaunchKernelGGL(asr::ln::bn_reduce_kernel<0>, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, s, (const uint16_t*)x_bf16,
+                       (const uint16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, R, C, rpb, ws2C, ws2C + C);
+    hipLaunchKernelGGL(asr::ln::bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws2C, ws2C + C, R, C, eps, decay, mean, rstd,
+                       avg_mean, avg_var);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_batchnorm_fwd(void* stream, const void* x_bf16, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, long long R, int C, void* y_bf16) {
+    if (!x_bf16 || !mean || !rstd || !gamma || !beta || !y_bf16 || R <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    const long long n = R * C;
+    long long g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(asr::ln::bn_fwd_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x_bf16, mean, rstd,
+                       gamma, beta, n, C, (uint16_t*)y_bf16);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, const float* mean, const float* rstd,
+                                 const float* gamma, long long R, int C, double* ws2C, void* dx_bf16, float* dgamma_acc,
+                                 float* dbeta_acc) {
+    if (!x_bf16 || !gy_bf16 || !mean || !rstd || !gamma || !ws2C || R <= 0 || C <= 0) return ASR_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws2C, 0, sizeof(double) * 2 * C, s) != hipSuccess) return ASR_ERR_LAUNCH;
+    const int rpb = 64;
+    hipLaunchKernelGGL(asr::ln::bn_reduce_kernel<1>, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(256), 0, s, (const uint16_t*)x_bf16,
+                       (const uint16_t*)gy_bf16, mean, rstd, R, C, rpb, ws2C, ws2C + C);
+    if (dx_bf16) {
+        const long long n = R * C;
+        long long g = (n + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(asr::ln::bn_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, (const uint16_t*)x_bf16, (const uint16_t*)gy_bf16, mean,
+                           rstd, gamma, ws2C, ws2C + C, R, C, (uint16_t*)dx_bf16);
+    }
+    if (dgamma_acc && dbeta_acc)
+        hipLaunchKernelGGL(asr::ln::bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws2C, ws2C + C, C, dgamma_acc, dbeta_acc);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -176,6 +176,22 @@ int asr_channel_affine(void* stream, const float* x, const float* scale, const f
                        int C);
 int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, float* g, float* b, int C);
 
+/* ---------------------------------------------------------------------------------------- batch normalisation
+ * chainer.links.BatchNormalization reaches the reference API through `from chainer.links import *` (asr/nn/nn.py:3);
+ * Chainer's rule: normalise with the biased batch variance, eps = 2e-5, running averages with decay 0.9 and the
+ * unbiased variance.  x, gy, y, dx: (R, C) bf16, channel last (R = every other axis).  ws2C: 2*C doubles of scratch.
+ *   asr_batchnorm_stats  mean, rstd = 1/sqrt(var + eps) (C) f32; avg_mean / avg_var (both or neither) updated in place
+ *   asr_batchnorm_fwd    y = gamma (x - mean) rstd + beta   (also the inference form, with rstd from the running variance)
+ *   asr_batchnorm_bwd    dx (may be NULL) and dgamma / dbeta ACCUMULATED (may be NULL)
+ */
+int asr_batchnorm_stats(void* stream, const void* x_bf16, long long R, int C, float eps, float decay, double* ws2C,
+                        float* mean, float* rstd, float* avg_mean, float* avg_var);
+int asr_batchnorm_fwd(void* stream, const void* x_bf16, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, long long R, int C, void* y_bf16);
+int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, const float* mean, const float* rstd,
+                      const float* gamma, long long R, int C, double* ws2C, void* dx_bf16, float* dgamma_acc,
+                      float* dbeta_acc);
+
 /* ---------------------------------------------------------------------------------------- (Bi)GRU recurrence
  * nn.GRU / nn.NStepBiGRU reach the reference API through `from chainer.links import *` (asr/nn/nn.py:3); gate
  * convention = cuDNN / torch.nn.GRU (r, z, n).  Layouts in csrc/gru.hip.  gi comes from asr_gemm_nt.

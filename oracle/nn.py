@@ -173,3 +173,20 @@ def clip_decay_adam(p, g, m, v, step, alpha=1e-3, beta1=0.9, beta2=0.999, eps=1e
     lr = alpha * np.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
     p = p - lr * m / (np.sqrt(v) + eps)
     return p, m, v
+
+
+def batch_normalization(x, gamma, beta, avg_mean, avg_var, eps=2e-5, decay=0.9, train=True):
+    """chainer.links.BatchNormalization as documented by Chainer (third party, absent: parity unpinned; torch's
+    batch_norm is the cross-check in tests): x (B, C, ...) float64 numpy; returns y and the updated running averages."""
+    import numpy as np
+    axes = (0,) + tuple(range(2, x.ndim))
+    shape = (1, -1) + (1,) * (x.ndim - 2)
+    if train:
+        mean, var = x.mean(axis=axes), x.var(axis=axes)
+        n = x.size // x.shape[1]
+        avg_mean = decay * avg_mean + (1 - decay) * mean
+        avg_var = decay * avg_var + (1 - decay) * var * n / max(n - 1, 1)
+    else:
+        mean, var = avg_mean, avg_var
+    y = gamma.reshape(shape) * (x - mean.reshape(shape)) / np.sqrt(var.reshape(shape) + eps) + beta.reshape(shape)
+    return y, avg_mean, avg_var

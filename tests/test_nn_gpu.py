@@ -236,3 +236,53 @@ def test_generic_layout_entry(device):
     assert _rel(y.float().cpu(), onn.maxout2(x)) == 0
     y = nn.MaxPooling2D(ksize=(2, 1))(x.to(device))
     assert _rel(y.float().cpu(), onn.maxpool_h(x, 2)) == 0
+
+
+def test_batch_normalization(device):
+    """nn.BatchNormalization (chainer.links name, asr/nn/nn.py:3): forward, running averages, gradients, test mode --
+    against oracle/nn.py and torch's batch_norm on the CPU (bf16 activations: 2e-2 tolerances)."""
+    import asr.functions as F
+    from asr import nn
+    from oracle import nn as onn
+    rs = np.random.RandomState(3)
+    B, C, H, T = 3, 24, 5, 17
+    x = (rs.randn(B, C, H, T) * 1.5 + 0.7).astype(np.float32)
+    x = torch.from_numpy(x).to(torch.bfloat16).float()          # representable values
+    bn = nn.BatchNormalization(C)
+    with torch.no_grad():
+        bn.gamma.copy_(torch.from_numpy(rs.rand(C).astype(np.float32) + 0.5))
+        bn.beta.copy_(torch.from_numpy(rs.randn(C).astype(np.float32) * 0.1))
+    g0, b0 = bn.gamma.detach().clone().numpy().astype(np.float64), bn.beta.detach().clone().numpy().astype(np.float64)
+    bn.to_gpu(0)
+    xd = x.to(device).requires_grad_(True)
+    y = bn(xd)
+    want, am, av = onn.batch_normalization(x.numpy().astype(np.float64), g0, b0, np.zeros(C), np.ones(C))
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), want, rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(bn.avg_mean.cpu().numpy(), am, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(bn.avg_var.cpu().numpy(), av, rtol=1e-3, atol=1e-5)
+    # gradients against torch autograd on the CPU
+    gy = torch.from_numpy(rs.randn(B, C, H, T).astype(np.float32)).to(torch.bfloat16).float()
+    y.backward(gy.to(device).to(y.dtype))
+    xr = x.clone().requires_grad_(True)
+    gr, br = torch.tensor(g0, dtype=torch.float32, requires_grad=True), torch.tensor(b0, dtype=torch.float32, requires_grad=True)
+    yr = torch.nn.functional.batch_norm(xr, None, None, gr, br, training=True, eps=2e-5)
+    yr.backward(gy)
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(xd.grad.float().cpu(), xr.grad) < 3e-2
+    assert rel(bn.gamma.grad.cpu(), gr.grad) < 2e-2 and rel(bn.beta.grad.cpu(), br.grad) < 2e-2
+    # test mode uses the running statistics
+    F.train_mode[0] = False
+    try:
+        with torch.no_grad():
+            yt = bn(x.to(device))
+    finally:
+        F.train_mode[0] = True
+    want_t, _, _ = onn.batch_normalization(x.numpy().astype(np.float64), g0, b0, am, av, train=False)
+    np.testing.assert_allclose(yt.float().cpu().numpy(), want_t, rtol=2e-2, atol=2e-2)
+    # 3-d input (B, C, T)
+    bn3 = nn.BatchNormalization(8).to_gpu(0)
+    x3 = torch.from_numpy(rs.randn(4, 8, 11).astype(np.float32)).to(torch.bfloat16).float()
+    y3 = bn3(x3.to(device))
+    w3, _, _ = onn.batch_normalization(x3.numpy().astype(np.float64), np.ones(8), np.zeros(8), np.zeros(8), np.ones(8))
+    np.testing.assert_allclose(y3.float().detach().cpu().numpy(), w3, rtol=2e-2, atol=2e-2)
