@@ -78,11 +78,11 @@ class Optimizer(object):
                 clip = float(h.threshold)
             elif isinstance(h, WeightDecay):
                 decay = float(h.rate)
-        sq = None
-        if clip > 0:
-            sq = self._flat["sq"]
-            _ops.fill_(sq, 0.0)
-            _ops.sqnorm_acc(G, sq)
+        # the squared gradient norm is always taken: it drives the clipping and the device-side "skip a non-finite
+        # step" guard (the reference's NaN check, run/ctc/cnn/train.py:193-197, without a host synchronisation)
+        sq = self._flat["sq"]
+        _ops.fill_(sq, 0.0)
+        _ops.sqnorm_acc(G, sq)
         self._step(P, G, clip, decay, scale, sq)
         bump_weight_epoch()
 

@@ -25,10 +25,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float beta1, float beta2, float eps, float decay, float clip,
                                                    float grad_scale, const float* __restrict__ sqnorm) {
     float rate = grad_scale;
-    if (clip > 0.f && sqnorm) {
-        const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
-        const float r = clip / norm;
-        if (r < 1.f) rate *= r;
+    if (sqnorm) {
+        // the reference's loop drops a step whose loss is NaN (run/ctc/cnn/train.py:193-197) after reading the loss on the
+        // host; here the step is dropped on the device when the gradient norm is not finite (a NaN loss makes it so), so
+        // the train loop never has to synchronise for it
+        if (!isfinite(sqnorm[0])) return;
+        if (clip > 0.f) {
+            const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
+            const float r = clip / norm;
+            if (r < 1.f) rate *= r;
+        }
     }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float pi = p[i];
@@ -48,10 +54,16 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
                                                   long long n, int kind, float lr, float mu, float decay, float clip,
                                                   float grad_scale, const float* __restrict__ sqnorm) {
     float rate = grad_scale;
-    if (clip > 0.f && sqnorm) {
-        const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
-        const float r = clip / norm;
-        if (r < 1.f) rate *= r;
+    if (sqnorm) {
+        // the reference's loop drops a step whose loss is NaN (run/ctc/cnn/train.py:193-197) after reading the loss on the
+        // host; here the step is dropped on the device when the gradient norm is not finite (a NaN loss makes it so), so
+        // the train loop never has to synchronise for it
+        if (!isfinite(sqnorm[0])) return;
+        if (clip > 0.f) {
+            const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
+            const float r = clip / norm;
+            if (r < 1.f) rate *= r;
+        }
     }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float pi = p[i];

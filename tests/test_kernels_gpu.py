@@ -340,3 +340,22 @@ def test_gru_full_size_forms_agree(device):
         assert torch.equal(a, b_)
     for a, b_ in zip(res[2][:5], res[7][:5]):
         assert torch.equal(a, b_)
+
+
+def test_non_finite_step_is_skipped(device):
+    """a NaN / Inf gradient norm leaves parameters and optimiser state untouched (run/ctc/cnn/train.py:193-197)"""
+    from asr import _ops
+    n = 4097
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g).to(device)
+    for bad in (float("nan"), float("inf")):
+        p, m, v = p0.clone(), torch.full((n,), 0.25, device=device), torch.full((n,), 0.5, device=device)
+        gr = torch.randn(n, generator=g).to(device)
+        gr[17] = bad
+        sq = torch.zeros(1, device=device)
+        _ops.sqnorm_acc(gr, sq)
+        _ops.clip_decay_adam(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-5, 1.0, 1.0, sq, 1)
+        assert torch.equal(p, p0) and bool((m == 0.25).all()) and bool((v == 0.5).all())
+        vel = torch.zeros(n, device=device)
+        _ops.clip_decay_sgd(p, gr, vel, 1, 1e-2, 0.9, 0.0, 0.0, 1.0, sq)
+        assert torch.equal(p, p0) and bool((vel == 0).all())
