@@ -164,6 +164,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # ASR_BENCH_BACKEND=gloo + ASR_BENCH_ONE_DEVICE=1: rehearse the multi-rank control flow with several processes on
+    # ONE GPU (no RCCL between ranks of one device); the numbers of such a run mean nothing
+    if os.environ.get("ASR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -177,7 +181,7 @@ def main():
     comm = None
     if world > 1 or os.environ.get("ASR_BENCH_FORCE_COMM") == "1":      # the latter: exercise the RCCL path on one GPU
         from asr.parallel import Communicator
-        comm = Communicator("nccl")
+        comm = Communicator(os.environ.get("ASR_BENCH_BACKEND", "nccl"))
 
     B, T, V = args.batch, args.frames, args.vocab
     cfg = ds2.configure()
@@ -236,6 +240,8 @@ def main():
     log("%.2f ms/step, %.1f utt/s" % (ms_per_step, value))
     if not args.no_census:
         log("kernel census")
+        if comm is not None:
+            opt.set_communicator(None)      # the other ranks have left: the census steps must not wait for them
         from asr import functions as asr_functions
         census = Census()
         census.wrap(_ops)
