@@ -244,16 +244,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
 // ------------------------------------------------------------------------------------------------ NT, 256 x 128 tile
 // At 128 x 128 x 64 every MFMA cycle needs 64 B/clk of operand fill per CU -- the whole L1-miss path -- so the K = 512
 // projections of the model ran at ~450 TFLOP/s.  256 x 128 halves the fill per flop: 4 waves as 2 (M) x 2 (N), each
-// 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers); BK = 32, two LDS stages of 24 KB filled by LDS-DMA, so two or
-// three workgroups share a CU and one's prologue / epilogue hides behind another's main loop.
+// 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers); BK = 32, two LDS stages of 24 KB filled by LDS-DMA and 168 VGPRs,
+// so THREE workgroups share a CU and one's loads / prologue / epilogue hide behind another's MFMAs.  Measured at
+// M=32000, N=3072, K=512 (f32 out): 3 stages x 2 workgroups per CU 480 TFLOP/s, 4 stages x 1 workgroup 301, 2 stages x 3
+// workgroups 542 (8192^3: 957 / 537 / 1010): occupancy hides the fill latency better than pipeline depth.
 // LDS image: rows of 64 B (32 k), 16-B chunk c of row r stored at position c ^ g[(r >> 2) & 3], g = {0, 2, 3, 1}: the
 // ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) then touch 16 distinct 16-B slots of the 256-B bank row.
 constexpr int B2M = 256, B2N = 128, B2K = 32;
-constexpr int NT2_STAGES = 3;
-constexpr int NT2_LDS_BYTES = NT2_STAGES * (B2M + B2N) * B2K * 2;      // 72 KiB: two workgroups per CU
+constexpr int NT2_STAGES = 2;
+constexpr int NT2_LDS_BYTES = NT2_STAGES * (B2M + B2N) * B2K * 2;      // stages x 24 KiB
 
 template <typename OutT>
-__global__ __launch_bounds__(256, 2) void gemm_nt256_kernel(const uint16_t* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __restrict__ A, int lda,
                                                             const uint16_t* __restrict__ B, int ldb, OutT* __restrict__ C,
                                                             int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                             int tiles_n) {
@@ -311,17 +313,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt256_kernel(const uint16_t* __re
             boff[j] = row * 64 + ((q ^ g4(row)) << 4);
         }
     }
-    // three stages, two tiles in flight: by Little's law 48 B/clk of fill at ~2000 cycles of latency is ~96 KB per CU.
-    // Tile kt + 2 is issued while tile kt is computed; before the barrier each wave waits until only its newest 6
-    // DMAs are outstanding (tile kt + 1 has landed).  Raw s_barrier: __syncthreads() would drain the DMAs in flight.
+    // NT2_STAGES stages, NT2_STAGES - 1 tiles in flight: by Little's law 48 B/clk of fill at ~2000 cycles of latency is
+    // ~96 KB per CU.  Tile kt + S - 1 is issued while tile kt is computed; before the barrier each wave waits until only
+    // the DMAs of the tiles behind kt + 1 are outstanding (6 per tile and wave).  Raw s_barrier: __syncthreads() would
+    // drain the DMAs in flight.
+    constexpr int S = NT2_STAGES;
+    auto wait_tiles_in_flight = [](int tiles) {          // vmcnt needs an immediate
+        if (tiles >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (tiles == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     const int nk = K / B2K;
-    issue_tile(0, 0);
-    if (nk > 1) issue_tile(1, 1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < S - 1 && t < nk; ++t) issue_tile(t, t);
+    wait_tiles_in_flight(min(S - 2, nk - 1));
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 2 < nk) issue_tile(kt + 2, buf >= 1 ? buf - 1 : 2);
+        if (kt + S - 1 < nk) issue_tile(kt + S - 1, buf == 0 ? S - 1 : buf - 1);
         const char* Ab = As + buf * A_STAGE;
         const char* Bb = Bs + buf * B_STAGE;
         Frag b[4];
@@ -334,9 +343,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt256_kernel(const uint16_t* __re
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
         }
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_tiles_in_flight(min(S - 2, nk - 2 - kt));          // tiles kt + 2 .. may stay in flight, tile kt + 1 has landed
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == S - 1 ? 0 : buf + 1;
     }
 
     // epilogue: 64 rows at a time through LDS (f32, row pitch 132 floats = 33 KB) and whole rows out
