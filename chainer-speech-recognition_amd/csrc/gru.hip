@@ -652,7 +652,8 @@ __device__ __forceinline__ void set_flag(unsigned* flag, unsigned v, bool local)
 // bypass the L1 and are served by the L2).  Control words: sync[960 + r] XCC id, [976 + r] mismatch, [992 + r] arrivals.
 __device__ __forceinline__ int decide_local(unsigned* sync, int rec, int nwg, unsigned* abort_word, int forge) {
     unsigned xcc = (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u) + 1u;      // HW_REG_XCC_ID[3:0]
-    if (forge) xcc = 1u + (blockIdx.x >> 3 & 1u);                              // test hook: pretend a split placement
+    if (forge == 1) xcc = 1u + (blockIdx.x >> 3 & 1u);                         // test hook: pretend a split placement
+    else if (forge > 1) xcc = (unsigned)forge;                                 // (wide kernels pass 2 + slot parity)
     unsigned expect = 0u;
     if (!__hip_atomic_compare_exchange_strong(sync + 960 + rec, &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
         expect != xcc)
@@ -929,6 +930,237 @@ __global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_
         atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
     }
 #undef ASR_ST
+}
+
+// ---- wide form: 32 hidden units per workgroup, recurrences of 4 batch rows ------------------------------------------
+// The hand-off load phase scales with the payload bytes per CU (rows x K x 2 B, whatever the instruction form: section 5
+// of DESIGN.md).  Halving the rows per recurrence halves it; to stay within 256 workgroups each one then owns 32 units:
+// 8 compute waves (K split in 8, both 16-unit tiles per wave, 48 weight registers as before) + loader + storer = 640
+// threads.  The 16-row MFMA tile has 4 live rows, so the lanes of tile rows 4..15 fetch the next three K slices of the
+// same rows (one load instruction = 4 slices = whole 128-B lines) and DPP row shifts bring them to rows 0..3.
+__device__ __forceinline__ uint4 shl_rows(uint4 v, int n4) {      // lane i of every 16-lane row <- lane i + 4 n4 (zero beyond)
+    uint4 r = v;
+    if (n4 == 1) {
+        r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x104, 0xF, 0xF, true); r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x104, 0xF, 0xF, true);
+        r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x104, 0xF, 0xF, true); r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x104, 0xF, 0xF, true);
+    } else if (n4 == 2) {
+        r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x108, 0xF, 0xF, true); r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x108, 0xF, 0xF, true);
+        r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x108, 0xF, 0xF, true); r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x108, 0xF, 0xF, true);
+    } else if (n4 == 3) {
+        r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x10C, 0xF, 0xF, true); r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x10C, 0xF, 0xF, true);
+        r.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.z, 0x10C, 0xF, 0xF, true); r.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.w, 0x10C, 0xF, 0xF, true);
+    }
+    return r;
+}
+
+template <int KS8, bool LOCAL>
+__global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
+                                                          const float* __restrict__ hseq, const uint16_t* __restrict__ whhT,
+                                                          uint16_t* __restrict__ dgi, uint16_t* dgh, float* __restrict__ db_ih,
+                                                          float* __restrict__ db_hh, unsigned* sync, int T, int B, int H, int ndir,
+                                                          int forge) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [8 waves][2 tiles][64]
+    char* opring = smem + 8 * 2 * 64 * 16;                                            // [BIO_GD][BIO_SLOT]: 5 x [4 rows][32 units] f32, dy bf16
+    unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);       // [2][3: ar az an][4 rows][16 pairs]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 4 * 16);
+    constexpr int rows = 4;
+    const int nwg = H / 32;
+    const int Gn = (B + rows - 1) / rows, nrec = Gn * ndir, nrec_pad = (nrec + 7) & ~7;
+    // LOCAL: 1-D grid of nrec_pad x H/32 workgroups; ids are dealt round-robin over the 8 XCDs, so recurrence id % nrec_pad
+    // sits on XCD id % 8 with all its workgroups (nrec_pad is a multiple of 8)
+    const int rec = LOCAL ? (int)(blockIdx.x % nrec_pad) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    const int slot = LOCAL ? (int)(blockIdx.x / nrec_pad) : (int)blockIdx.x;
+    if (LOCAL && rec >= nrec) return;
+    const int d = rec / Gn, g = rec % Gn;
+    const int j0 = slot * 32;
+    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_compute = w < 8, is_loader = w == 8, is_storer = w == 9;
+    const int nks = (3 * H) >> 5;
+    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
+    unsigned* shards = shard_base(sync, rec);
+    unsigned* my_shard = shards + (slot % NSH) * 32;
+    unsigned* abort_word = sync + 1023;
+    const __amdgpu_buffer_rsrc_t dghrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
+    const long long tstep = d == 0 ? -1 : 1;
+    const int tfirst = d == 0 ? T - 1 : 0;
+
+    // ---- loader (wave 8): lanes 0..31 fetch (row lane / 8, units 4 (lane % 8) ..) of each f32 array, lanes 0..15 dy
+    const int lrow = lane >> 3, lyrow = lane >> 2;
+    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4;
+    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
+                       (size_t)d * H + j0 + (lane & 7) * 4;
+    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
+    const long long lgs = tstep * (long long)B * ndir * 4 * H, lhs = tstep * (long long)B * (long long)hs, lys = tstep * (long long)B * H;
+    auto issue = [&](int sq) {
+        if (sq < T) {
+            char* sl = opring + (sq % BIO_GD) * BIO_SLOT;
+            if (lane < 32 && lrow < Bl) {
+#pragma unroll
+                for (int arr = 0; arr < 4; ++arr)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)arr * H), (lds_ptr_t)(sl + arr * 512), 16, 0, 0);
+                if (sq < T - 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)lhp, (lds_ptr_t)(sl + 4 * 512), 16, 0, 0);
+            }
+            if (lane < 16 && lyrow < Bl) __builtin_amdgcn_global_load_lds((glb_ptr_t)lyp, (lds_ptr_t)(sl + 5 * 512), 16, 0, 0);
+        }
+        lgp += lgs; lhp += lhs; lyp += lys;
+    };
+    // ---- storer (wave 9): dgi: 3 gates x 4 rows x 64 B = 48 pieces of 16 B
+    auto store_step = [&](int sp) {
+        const long long tq = tfirst + tstep * sp;
+        const unsigned* src = oring + (size_t)(sp & 1) * 3 * 4 * 16;
+        const int gsel = lane >> 4, row = (lane & 15) >> 2, c = lane & 3;
+        if (lane < 48 && row < Bl)
+            *reinterpret_cast<uint4*>(dgi + ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c * 8) =
+                *reinterpret_cast<const uint4*>(src + (gsel * 4 + row) * 16 + c * 4);
+    };
+    if (is_loader) {
+        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) issue(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // weights: wave w owns the K slices [w KS8, (w + 1) KS8) for both 16-unit tiles
+    Frag bb[KS8][2];
+    if (is_compute) {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int i = 0; i < KS8; ++i) {
+            const int ks = w * KS8 + i;
+            const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                bb[i][n].u = ks < nks ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + n * 16 + (lane & 15)) * (3 * H) + k)
+                                      : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // gate phase on waves 2 and 3: thread (row (tid - 128) / 32, unit tid % 32)
+    const int b = ((tid - 128) >> 5) & 3, u0 = tid & 31;
+    const int j = j0 + (u0 & ~1);
+    const bool gate_wave = tid >= 128 && tid < 256;
+    const bool act = gate_wave && b < Bl;
+    constexpr int kPoller = 128;
+    float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) {
+        *s_abort = 0;
+        s_abort[1] = 0;
+        if (LOCAL) {
+            const int v = decide_local(sync, rec, nwg, abort_word, forge ? 2 + (slot & 1) : 0);
+            if (v < 0) *s_abort = 1; else s_abort[1] = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ASR_RAW_BARRIER();
+    const bool local = LOCAL && s_abort[1] != 0;
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? t + 1 : t - 1;
+        float rcr = 0.f;
+        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f;
+        if (gate_wave) {
+            const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
+            const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
+            r = of[0]; z = of[128]; n = of[256]; qq = of[384];
+            hp = s < T - 1 ? of[512] : 0.f;
+            dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
+        }
+        if (s > 0) {
+            if (local) {
+                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
+            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
+                *s_abort = 1;
+            }
+            ASR_RAW_BARRIER();
+            if (*s_abort) break;
+            if (is_compute) {
+                f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+                constexpr int NL = (KS8 + 3) / 4;
+                Frag a[NL];
+                const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int i = 4 * l + sl4, ks = w * KS8 + i;
+                    a[l].u = make_uint4(0, 0, 0, 0);
+                    if (i < KS8 && ks < nks && row < Bl) {
+                        const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                        a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KS8; ++i) {
+                    Frag f;
+                    f.u = shl_rows(a[i >> 2].u, i & 3);
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, bb[i][nn].v, acc[nn], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) part[(w * 2 + nn) * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);
+            }
+            ASR_RAW_BARRIER();
+            if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
+                const float* pf = reinterpret_cast<const float*>(part) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) rcr += pf[ww * 2 * 256];
+            }
+        }
+        if (is_loader) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue(s + BIO_GD - 1);
+        } else if (is_storer) {
+            if (s > 0) store_step(s - 1);
+        } else if (gate_wave) {
+            const float dh = dyy + carry + rcr;
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (hp - n);
+            const float dan = dn * (1.0f - n * n);
+            const float daz = dz * z * (1.0f - z);
+            const float dq = dan * r;
+            const float dar = dan * qq * r * (1.0f - r);
+            carry = dh * z;
+            const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
+            if (act) { sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq); }
+            const unsigned m1 = (unsigned)ar | ((unsigned)az << 16), m2 = (unsigned)an | ((unsigned)aq << 16);
+            const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
+            const bool odd = u0 & 1;
+            const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;
+            const unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
+            const unsigned pn_ = (e2 & 0xffffu) | (d2 << 16), pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
+            const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
+            unsigned* od = oring + (size_t)(s & 1) * 3 * 4 * 16 + b * 16 + (u0 >> 1);
+            if (act && !odd) {
+                if (local) {
+                    __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
+                } else {
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
+                }
+                od[0] = pr_;
+            }
+            if (act && odd) {
+                if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
+                else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
+                od[4 * 16] = pz_; od[2 * 4 * 16] = pn_;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ASR_RAW_BARRIER();
+        if (tid == kPoller) {
+            if (local) set_flag(shards + slot, (unsigned)s + 1u, true);
+            else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT);
+        }
+    }
+    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASR_RAW_BARRIER();
+    if (is_storer && !*s_abort) store_step(T - 1);
+    if (act && db_ih && db_hh) {
+        float* bi = db_ih + (size_t)d * 3 * H + j0 + u0;
+        float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0;
+        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
+        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
+    }
 }
 
 // Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
@@ -1792,6 +2024,35 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         }
 #undef ASR_BWDG
         return ASR_OK;
+    }
+    // wide form (32 units x 4-row recurrences): mode 5 keeps the 16-unit x 8-row kernels for comparison
+    if (persist && mode != 3 && mode != 5 && db_ih && db_hh && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16) {
+        const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
+        const int ks8 = (3 * H / 32 + 7) / 8;
+        if (ks8 <= 6) {
+            if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
+            const bool local = mode == 0 || mode == 4 || mode == 7;
+            const int forge = mode == 7;
+            const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
+#define ASR_BWDW(K)                                                                                                       \
+    do {                                                                                                                  \
+        if (local) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)bwd_wide_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_wide_kernel<K, true>), wgrid, wblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
+                               (unsigned*)sync_ws, T, B, H, ndir, forge);                                                         \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)bwd_wide_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((bwd_wide_kernel<K, false>), wgrid, wblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
+                               (unsigned*)sync_ws, T, B, H, ndir, 0);                                                             \
+        }                                                                                                                 \
+    } while (0)
+            if (ks8 <= 2) ASR_BWDW(2); else if (ks8 <= 3) ASR_BWDW(3); else if (ks8 <= 4) ASR_BWDW(4); else if (ks8 <= 5) ASR_BWDW(5); else ASR_BWDW(6);
+#undef ASR_BWDW
+            ASR_LAUNCH_CHECK();
+            return ASR_OK;
+        }
     }
     if (persist && mode != 3 && db_ih && db_hh && H % 16 == 0) {
         // batch rows split into independent recurrences of 8 rows (half of one 16-row MFMA tile)

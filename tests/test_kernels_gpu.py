@@ -180,7 +180,7 @@ def test_layernorm(device, B, C, H, T):
 
 # 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
 # 4: persistent with the XCD-local hand-off where placement allows (= automatic), 7: 4 with a forged split placement
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("T,B,I,H,ndir", [(12, 4, 64, 64, 2), (9, 5, 96, 128, 1), (20, 32, 64, 512, 2), (7, 40, 32, 64, 2),
                                           (150, 32, 32, 256, 2), (40, 19, 48, 128, 2), (30, 7, 32, 384, 1)])
 def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
