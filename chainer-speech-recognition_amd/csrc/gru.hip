@@ -1402,6 +1402,196 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
     if (is_storer && !*s_abort) store_step(T - 1);
 }
 
+// Forward wide form (see bwd_wide_kernel): 32 units x 4-row recurrences, 8 compute waves (K = H split in 8, all 3 gates x 2
+// unit tiles per wave), loader, storer.
+template <int KS8, bool LOCAL>
+__global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+                                                          const float* __restrict__ bhh, float* __restrict__ hseq,
+                                                          uint16_t* hseq16, float* __restrict__ gates, unsigned* sync, int T,
+                                                          int B, int H, int ndir, int forge) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [8 waves][6 tiles: gate x unit half][64]
+    float* opring = reinterpret_cast<float*>(part + 8 * 6 * 64);                      // [BIO_GD][3 gates][4 rows][32 units]
+    float* oring = opring + BIO_GD * 3 * 128;                                         // [2][5: h r z n q][4 rows][32 units]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 128);
+    constexpr int rows = 4;
+    const int nwg = H / 32;
+    const int Gn = (B + rows - 1) / rows, nrec = Gn * ndir, nrec_pad = (nrec + 7) & ~7;
+    const int rec = LOCAL ? (int)(blockIdx.x % nrec_pad) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    const int slot = LOCAL ? (int)(blockIdx.x / nrec_pad) : (int)blockIdx.x;
+    if (LOCAL && rec >= nrec) return;
+    const int d = rec / Gn, g = rec % Gn;
+    const int j0 = slot * 32;
+    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_compute = w < 8, is_loader = w == 8, is_storer = w == 9;
+    const int nks = H >> 5;
+    const size_t hs = (size_t)ndir * H;
+    unsigned* shards = shard_base(sync, rec);
+    unsigned* my_shard = shards + (slot % NSH) * 32;
+    unsigned* abort_word = sync + 1023;
+    const __amdgpu_buffer_rsrc_t h16rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
+    const long long tstep = d == 0 ? 1 : -1;
+    const int tfirst = d == 0 ? 0 : T - 1;
+
+    // loader (wave 8): lanes 0..31 fetch (row lane / 8, units 4 (lane % 8) ..) of the three gi gate arrays
+    const int lrow = lane >> 3;
+    const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 7) * 4;
+    const long long lstride = tstep * (long long)B * 3 * (long long)hs;
+    auto issue = [&](int sq) {
+        if (sq < T && lane < 32 && lrow < Bl) {
+            char* sl = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)gg * H), (lds_ptr_t)(sl + gg * 512), 16, 0, 0);
+        }
+        lgp += lstride;
+    };
+    // storer (wave 9): 5 arrays x 4 rows x 128 B = 160 pieces: piece p = lane + 64 i: array p / 32, row (p % 32) / 8
+    auto store_step = [&](int sp) {
+        const long long tq = tfirst + tstep * sp;
+        const float* src = oring + (size_t)(sp & 1) * 5 * 128;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int pp = lane + 64 * i, arr = pp >> 5, row = (pp & 31) >> 3, c4 = (pp & 7) * 4;
+            if (pp < 160 && row < Bl) {
+                const size_t rowi = (size_t)tq * B + b0 + row;
+                float* dst = arr == 0 ? hseq + rowi * hs + (size_t)d * H + j0 + c4
+                                      : gates + (rowi * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c4;
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src + pp * 4);
+            }
+        }
+    };
+    if (is_loader) {
+        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) issue(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // weights: wave w owns K slices [w KS8, (w + 1) KS8) of all six 16-column tiles (gate gg, unit half n: tile 2 gg + n)
+    Frag bb[KS8][6];
+    if (is_compute) {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int i = 0; i < KS8; ++i) {
+            const int ks = w * KS8 + i;
+            const int k = ks * 32 + 8 * (lane >> 4);
+#pragma unroll
+            for (int tl = 0; tl < 6; ++tl)
+                bb[i][tl].u = ks < nks ? *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + (tl >> 1)) * H + j0 + (tl & 1) * 16 + (lane & 15)) * H + k)
+                                       : make_uint4(0, 0, 0, 0);
+        }
+    }
+    const int b = ((tid - 128) >> 5) & 3, u = tid & 31;
+    const bool gate_wave = tid >= 128 && tid < 256;
+    const bool act = gate_wave && b < Bl;
+    constexpr int kPoller = 128;
+    float bh[3] = {0.f, 0.f, 0.f};
+    if (gate_wave) {
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg) bh[gg] = bhh[(d * 3 + gg) * H + j0 + u];
+    }
+    float hprev = 0.f;
+    if (tid == 0) {
+        *s_abort = 0;
+        s_abort[1] = 0;
+        if (LOCAL) {
+            const int v = decide_local(sync, rec, nwg, abort_word, forge ? 2 + (slot & 1) : 0);
+            if (v < 0) *s_abort = 1; else s_abort[1] = v;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ASR_RAW_BARRIER();
+    const bool local = LOCAL && s_abort[1] != 0;
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        float gh[3] = {bh[0], bh[1], bh[2]};
+        float gr = 0.f, gz = 0.f, gn = 0.f;
+        if (gate_wave) {
+            const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 128 + b * 32 + u;
+            gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
+        }
+        if (s > 0) {
+            if (local) {
+                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
+            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
+                *s_abort = 1;
+            }
+            ASR_RAW_BARRIER();
+            if (*s_abort) break;
+            if (is_compute) {
+                f32x4 acc[6];
+#pragma unroll
+                for (int tl = 0; tl < 6; ++tl) acc[tl] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                constexpr int NL = (KS8 + 3) / 4;
+                Frag a[NL];
+                const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int i = 4 * l + sl4, ks = w * KS8 + i;
+                    a[l].u = make_uint4(0, 0, 0, 0);
+                    if (i < KS8 && ks < nks && row < Bl) {
+                        const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + ks * 32 + 8 * (lane >> 4)) * 2);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                        a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < KS8; ++i) {
+                    Frag f;
+                    f.u = shl_rows(a[i >> 2].u, i & 3);
+#pragma unroll
+                    for (int tl = 0; tl < 6; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, bb[i][tl].v, acc[tl], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tl = 0; tl < 6; ++tl) part[(w * 6 + tl) * 64 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);
+            }
+            ASR_RAW_BARRIER();
+            if (act) {
+                const float* pf = reinterpret_cast<const float*>(part) + ((u >> 4) * 64 + (u & 15)) * 4 + b;
+#pragma unroll
+                for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+                    for (int ww = 0; ww < 8; ++ww) gh[gg] += pf[(ww * 6 + gg * 2) * 256];
+            }
+        }
+        if (is_loader) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            issue(s + BIO_GD - 1);
+        } else if (is_storer) {
+            if (s > 0) store_step(s - 1);
+        } else if (gate_wave) {
+            const float r = sigmoidf_(gr + gh[0]);
+            const float z = sigmoidf_(gz + gh[1]);
+            const float n = tanhf_(gn + r * gh[2]);
+            const float h = (1.0f - z) * n + z * hprev;
+            hprev = h;
+            const unsigned mine = (unsigned)f32_to_bf16(h);
+            const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+            if (act) {
+                if (!(u & 1)) {
+                    const unsigned packed = mine | (other << 16);
+                    const size_t o = ((size_t)t * B + b0 + b) * hs + (size_t)d * H + j0 + u;
+                    if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
+                    else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);
+                }
+                float* od = oring + (size_t)(s & 1) * 5 * 128 + b * 32 + u;
+                od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        ASR_RAW_BARRIER();
+        if (tid == kPoller) {
+            if (local) set_flag(shards + slot, (unsigned)s + 1u, true);
+            else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT);
+        }
+    }
+    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASR_RAW_BARRIER();
+    if (is_storer && !*s_abort) store_step(T - 1);
+}
+
 // ================================================================================================ grouped persistent form
 // The recurrence is independent across utterances, so the batch is cut into groups of RG = 8 rows and a group's
 // workgroups only ever talk to each other: 8 workgroups (64 hidden units each, 512 threads) hold the whole W_hh of one
@@ -1923,7 +2113,31 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
     const int Gio = (B + 7) / 8;
-    if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
+    if (persist && mode == 2 && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
+        // wide form (32 units x 4-row recurrences).  Measured at T=1000, B=32, H=512: with the XCD-local hand-off it ties
+        // the 16-unit x 8-row kernel (2.11 vs 2.12 us: the smaller payload is paid back in the 8-wave reduction), with the
+        // placement-free hand-off it wins (2.47 vs 2.72 us) -- so it serves mode 2 only; the backward pass is wide in both.
+        const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
+        const int ks8 = (H / 32 + 7) / 8;
+        if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
+        const bool local = mode == 0 || mode == 4 || mode == 7;
+        const int forge = mode == 7;
+        const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
+#define ASR_FWDW(K)                                                                                                       \
+    do {                                                                                                                  \
+        if (local) {                                                                                                      \
+            (void)hipFuncSetAttribute((const void*)fwd_wide_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((fwd_wide_kernel<K, true>), wgrid, wblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,  \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, forge);                        \
+        } else {                                                                                                          \
+            (void)hipFuncSetAttribute((const void*)fwd_wide_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+            hipLaunchKernelGGL((fwd_wide_kernel<K, false>), wgrid, wblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, 0);                            \
+        }                                                                                                                 \
+    } while (0)
+        if (ks8 <= 1) ASR_FWDW(1); else if (ks8 <= 2) ASR_FWDW(2); else ASR_FWDW(4);
+#undef ASR_FWDW
+    } else if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
         const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
         const int forge = mode == 7;

@@ -202,7 +202,8 @@ int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, con
  * 1 = one launch per time step, 2 = persistent with the placement-free hand-off only (sc1 write-through + agent-scope
  * counter), 3 = the 32-unit grouped kernels, 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
  * find themselves on one XCD (what mode 0 selects; decided inside the launch, falls back to the mode-2 protocol
- * otherwise), 7 = mode 4 with a forged split placement (test hook for that fall-back).  Modes >= 2 return
+ * otherwise), 5 = mode 4 with the 16-unit x 8-row backward kernel instead of the wide one (comparison),
+ * 7 = mode 4 with a forged split placement (test hook for that fall-back).  Modes >= 2 return
  * ASR_ERR_UNSUPPORTED instead of falling back to mode 1.
  * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).  That word
  * is sticky: the calls zero every other control word but never this one, so a caller that reuses one sync_ws (zeroed

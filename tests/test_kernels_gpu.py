@@ -334,13 +334,11 @@ def test_gru_full_size_forms_agree(device):
                                    (2e-2, 2e-3, 2e-3, 2e-2, 2e-2, 1e-2, 1e-2)):
             err = float((a - r).abs().max()) / (float(r.abs().max()) + 1e-12)
             assert err < tol, (mode, name, err)
-    # the three persistent forms run the same instruction sequence per workgroup: bit-identical among themselves
-    # (bias gradients excepted: their float atomics land in any order)
-    for a, b_ in zip(res[2][:5], res[0][:5]):
+    # the XCD-local form and its forged-placement fall-back run the same instruction sequence per workgroup (only the
+    # hand-off differs): bit-identical (bias gradients excepted: their float atomics land in any order).  Mode 2 runs the
+    # wide forward kernel (another K split), so it agrees to rounding only.
+    for a, b_ in zip(res[0][:5], res[7][:5]):
         assert torch.equal(a, b_)
-    for a, b_ in zip(res[2][:5], res[7][:5]):
-        assert torch.equal(a, b_)
-
 
 def test_non_finite_step_is_skipped(device):
     """a NaN / Inf gradient norm leaves parameters and optimiser state untouched (run/ctc/cnn/train.py:193-197)"""
