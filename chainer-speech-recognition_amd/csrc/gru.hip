@@ -2139,7 +2139,7 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
 #undef ASR_FWDW
     } else if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-        const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
+        const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
         const int forge = mode == 7;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
 #define ASR_FWDIO(K)                                                                                                      \
@@ -2275,7 +2275,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         const int G = (B + rows - 1) / rows;
         if (ndir * G <= 16) {
             if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-            const bool local = (mode == 0 || mode == 4 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
+            const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
             const int forge = mode == 7;
             const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
 #define ASR_BWDIO(K)                                                                                                      \
