@@ -225,7 +225,7 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
     return dx
 
 
-GRU_MODE = [0]      # 0 automatic, 1 one launch per time step, 2 persistent only, 3 persistent + grouped backward
+GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 = 0, 5 narrow backward, 7 forged placement
 
 
 _SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky
