@@ -850,7 +850,7 @@ __global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_
 #pragma unroll
                     for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
                 }
-                part[w * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (lane < 32) part[w * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);      // live rows 0..7 only
             }
             ASR_ST(2)
             ASR_RAW_BARRIER();
@@ -1096,7 +1096,8 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                     for (int nn = 0; nn < 2; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, bb[i][nn].v, acc[nn], 0, 0, 0);
                 }
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) part[(w * 2 + nn) * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);
+                for (int nn = 0; nn < 2; ++nn)
+                    if (lane < 16) part[(w * 2 + nn) * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
             if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
@@ -1342,7 +1343,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 }
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
-                    part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
+                    if (lane < 32) part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);   // live rows 0..7 only
             }
             ASR_ST(3)
             ASR_RAW_BARRIER();
@@ -1545,7 +1546,8 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                     for (int tl = 0; tl < 6; ++tl) acc[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.v, bb[i][tl].v, acc[tl], 0, 0, 0);
                 }
 #pragma unroll
-                for (int tl = 0; tl < 6; ++tl) part[(w * 6 + tl) * 64 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);
+                for (int tl = 0; tl < 6; ++tl)
+                    if (lane < 16) part[(w * 6 + tl) * 64 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
             if (act) {
