@@ -237,6 +237,13 @@ def main():
                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
                       "final_loss": loss_value}}
 
+    # which hand-off the persistent GRU kernels of the last launch agreed on (decided inside the launch: DESIGN.md section 5)
+    if _ops.LAST_SYNC[0] is not None:
+        words = _ops.LAST_SYNC[0][960:1008].cpu().tolist()
+        nrec = sum(1 for v in words[32:48] if v > 0)
+        out["config"]["gru_handoff"] = {"recurrences": nrec, "xcd_of_recurrence": [v - 1 for v in words[0:16] if v > 0],
+                                        "split_placements": int(sum(words[16:32])),
+                                        "form": "xcd-local" if nrec and sum(words[16:32]) == 0 else "placement-free"}
     log("%.2f ms/step, %.1f utt/s" % (ms_per_step, value))
     if not args.no_census:
         log("kernel census")
@@ -276,11 +283,11 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc_path):
             ks = json.load(open(pmc_path))["kernels"]
-            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_persistent_io_kernel" in k]
+            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k]
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
                 traffic_src = "profiles/r01_pmc_traffic.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_persistent_io_kernel (one launch per layer)",
+        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_wide_kernel (one launch per layer)",
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                            "ms_per_launch": per_launch_s * 1e3, "launches_per_step": launches,
