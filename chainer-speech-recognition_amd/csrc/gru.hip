@@ -640,6 +640,24 @@ __device__ __forceinline__ bool wait_flags(unsigned* flags, int nwg, unsigned ta
         }
     }
 }
+// the same for a subset of the producers (bit i of mask = workgroup i): a compute wave waits only for the workgroups whose
+// units its K slices cover, and starts its loads without a workgroup barrier
+__device__ __forceinline__ bool wait_flags_mask(unsigned* flags, int nflags, unsigned long long mask, unsigned target,
+                                                unsigned* abort_word, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = lane < nflags ? __hip_atomic_load(flags + lane, ASR_RLX_AGENT) : 0xffffffffu;
+        if ((__ballot(v >= target) & mask) == mask) return true;
+        ++spins;
+        if ((spins & 63u) == 0u) {
+            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
+            if (spins > kSpinLimit) {
+                if (lane == 0) __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
+                return false;
+            }
+        }
+    }
+}
 __device__ __forceinline__ void set_flag(unsigned* flag, unsigned v, bool local) {
     if (local) asm volatile("global_store_dword %0, %1, off" :: "v"(flag), "v"(v) : "memory");
     else __hip_atomic_store(flag, v, ASR_RLX_AGENT);
@@ -1041,6 +1059,13 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
     const bool act = gate_wave && b < Bl;
     constexpr int kPoller = 128;
     float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    // producers (workgroups of 32 units) behind this wave's K slices: slice ks = columns [32 ks, 32 ks + 32) of (gate, unit)
+    unsigned long long my_producers = 0ull;
+#pragma unroll
+    for (int i = 0; i < KS8; ++i) {
+        const int ks = w * KS8 + i;
+        if (ks < nks) my_producers |= 1ull << (((32 * ks) % H) >> 5);
+    }
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
@@ -1066,13 +1091,12 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
         }
         if (s > 0) {
-            if (local) {
-                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
-            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
-                *s_abort = 1;
+            if (local) {        // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
+                if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
+            } else {
+                if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) *s_abort = 1;
+                ASR_RAW_BARRIER();
             }
-            ASR_RAW_BARRIER();
-            if (*s_abort) break;
             if (is_compute) {
                 f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
                 constexpr int NL = (KS8 + 3) / 4;
@@ -1100,6 +1124,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                     if (lane < 16) part[(w * 2 + nn) * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
+            if (*s_abort) break;
             if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
                 const float* pf = reinterpret_cast<const float*>(part) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
 #pragma unroll
@@ -1253,6 +1278,17 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
         for (int gg = 0; gg < 3; ++gg) bh[gg] = bhh[(d * 3 + gg) * H + j0 + u];
     }
     float hprev = 0.f;
+    // producers (workgroups of 16 units) behind this wave's K slices
+    unsigned long long my_producers = 0ull;
+    if (PAIRED) {
+#pragma unroll
+        for (int i2 = 0; i2 < KSW / 2; ++i2) {
+            const int p2 = i2 * 4 + w;                          // slices 2 p2, 2 p2 + 1 = units [64 p2, 64 p2 + 64)
+            for (int q = 0; q < 4; ++q) if (4 * p2 + q < nwg) my_producers |= 1ull << (4 * p2 + q);
+        }
+    } else {
+        my_producers = nwg >= 64 ? ~0ull : ((1ull << nwg) - 1ull);
+    }
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
@@ -1282,15 +1318,14 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
         }
         if (s > 0) {
-            if (local) {        // one line of per-producer flags, polled by the whole wave 2 with a single load
-                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
-            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
-                *s_abort = 1;   // placement-free form: sharded agent-scope counters (flag stores to one line were slower there)
+            if (local) {        // one line of per-producer flags; every compute wave polls it for ITS producers and goes on
+                if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
+            } else {
+                if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word))
+                    *s_abort = 1;   // placement-free form: sharded agent-scope counters (flag stores to one line were slower there)
+                ASR_RAW_BARRIER();
             }
-            ASR_ST(0)
-            ASR_RAW_BARRIER();
             ASR_ST(1)
-            if (*s_abort) break;
             if (is_compute) {
                 f32x4 acc[3];
 #pragma unroll
@@ -1348,6 +1383,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             ASR_ST(3)
             ASR_RAW_BARRIER();
             ASR_ST(4)
+            if (*s_abort) break;
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
                 // nest of divergent branches around narrow reads (measured 0.95 us per step)
