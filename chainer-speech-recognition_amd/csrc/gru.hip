@@ -1528,6 +1528,12 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
         for (int gg = 0; gg < 3; ++gg) bh[gg] = bhh[(d * 3 + gg) * H + j0 + u];
     }
     float hprev = 0.f;
+    unsigned long long my_producers = 0ull;       // workgroups (32 units each) behind this wave's K slices
+#pragma unroll
+    for (int i = 0; i < KS8; ++i) {
+        const int ks = w * KS8 + i;
+        if (ks < nks) my_producers |= 1ull << ks;
+    }
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
@@ -1550,13 +1556,12 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
             gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
         }
         if (s > 0) {
-            if (local) {
-                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
-            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
-                *s_abort = 1;
+            if (local) {        // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
+                if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
+            } else {
+                if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) *s_abort = 1;
+                ASR_RAW_BARRIER();
             }
-            ASR_RAW_BARRIER();
-            if (*s_abort) break;
             if (is_compute) {
                 f32x4 acc[6];
 #pragma unroll
@@ -1586,6 +1591,7 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                     if (lane < 16) part[(w * 6 + tl) * 64 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
+            if (*s_abort) break;
             if (act) {
                 const float* pf = reinterpret_cast<const float*>(part) + ((u >> 4) * 64 + (u & 15)) * 4 + b;
 #pragma unroll
