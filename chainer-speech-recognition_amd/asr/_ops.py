@@ -488,3 +488,28 @@ def batchnorm_bwd(x2, gy, mean, rstd, gamma, dgamma, dbeta, need_dx=True):
                                       ptr(dbeta))
     check(rc, "asr_batchnorm_bwd")
     return dx
+
+
+def conv_implicit_ok(Cs, KH, KW):
+    """the implicit-GEMM convolution wants whole 16-B chunks per tap and whole 32-wide K tiles"""
+    return Cs % 8 == 0 and (KH * KW * Cs) % 32 == 0
+
+
+def conv_nt(x, W2, bias, out_dtype, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
+    """x (Ts, B, Hs, Cs) bf16 contiguous; W2 (N, KH*KW*Cs) bf16 -> (Tr*B*Hr, N): asr_hip.h asr_conv_nt."""
+    Ts, B, Hs, Cs = x.shape
+    N = W2.shape[0]
+    assert x.dtype == BF16 and x.is_contiguous() and W2.dtype == BF16 and W2.is_contiguous() and W2.shape[1] == KH * KW * Cs
+    out = torch.empty((Tr * B * Hr, N), dtype=out_dtype, device=x.device)
+    rc = _lib.lib().asr_conv_nt(stream(), ptr(x), ptr(W2), ptr(out), _is_bf16(out), ptr(bias), Ts, B, Hs, Cs, KH, KW, pad_h, pad_t,
+                                int(sgn), Tr, Hr, N)
+    check(rc, "asr_conv_nt")
+    return out
+
+
+def conv_weight_pack_bwd(W):
+    """(Co, Ci, kh, kw) f32 -> bf16 (Ci, kh*kw*Co), k = (kh, kw, co)."""
+    Co, Ci, KH, KW = W.shape
+    dst = torch.empty((Ci, KH * KW * Co), dtype=BF16, device=W.device)
+    check(_lib.lib().asr_conv_weight_pack_bwd(stream(), ptr(W), ptr(dst), Co, Ci, KH, KW), "asr_conv_weight_pack_bwd")
+    return dst

@@ -136,13 +136,24 @@ class _Conv2D(torch.autograd.Function):
     Output physical (Tout, B, Hout, Co) bf16 (or f32)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, w16, w16t, pad_h, pad_t, causal, out_f32):
+    def forward(ctx, x, W, b, w16, w16t, wbwd, pad_h, pad_t, causal, out_f32):
         B, Ci, Hin, T = x.shape
         Co, _, KH, KW = W.shape
         Tout = T if causal else T + 2 * pad_t - KW + 1
         Hout = Hin + 2 * pad_h - KH + 1
         pointwise = KH == 1 and KW == 1 and pad_h == 0 and pad_t == 0
         xp = None
+        # implicit GEMM (asr_conv_nt): no column matrix when the input is already physical bf16 and every 16-B chunk of a
+        # virtual im2col row stays inside one tap
+        xphys = x.permute(3, 0, 2, 1)
+        if (not pointwise and xphys.dtype == BF16 and xphys.is_contiguous() and _ops.conv_implicit_ok(Ci, KH, KW)
+                and w16.shape[1] == KH * KW * Ci):
+            y = _ops.conv_nt(xphys, w16, b.detach() if b is not None else None, F32 if out_f32 else BF16, KH, KW, pad_h, pad_t,
+                             +1, Tout, Hout)
+            ctx.save_for_backward(xphys, w16t, wbwd)
+            ctx.params = (W, b)
+            ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, ctx.needs_input_grad[0], True)
+            return y.reshape(Tout, B, Hout, Co)
         if pointwise:
             xp = x.permute(3, 0, 2, 1)
             if not (xp.dtype == BF16 and xp.is_contiguous()):
@@ -154,30 +165,31 @@ class _Conv2D(torch.autograd.Function):
             col = _ops.im2col(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, KH, KW, pad_h,
                               pad_t, Tout)
         y = _ops.gemm_nt(col, w16, b.detach() if b is not None else None, F32 if out_f32 else BF16)
-        ctx.save_for_backward(col, w16t)
+        ctx.save_for_backward(col, w16t, wbwd)
         ctx.params = (W, b)
-        ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, x.dtype, ctx.needs_input_grad[0])
+        ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, x.dtype, ctx.needs_input_grad[0], False)
         return y.reshape(Tout, B, Hout, Co)
 
     @staticmethod
     def backward(ctx, gy):
-        col, w16t = ctx.saved_tensors
+        col, w16t, wbwd = ctx.saved_tensors
         W, b = ctx.params
-        B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx = ctx.meta
+        B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx, implicit = ctx.meta
         gy = gy.contiguous()
         if gy.dtype != BF16:
             gy = _ops.cast_bf16(gy.reshape(-1, Co))
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
-        Kp = col.shape[1]
+        xphys = col if implicit else None        # the implicit forward saved the input, not a column matrix
+        Kp = (Kreal + 7) // 8 * 8 if implicit else col.shape[1]
         w_is_param = isinstance(W, torch.nn.Parameter)
         gx = None
         if need_dx:         # activation gradient first: it is what the rest of the backward pass waits for
-            dcol = _ops.gemm_nt(g2, w16t, None, BF16)
-            if pointwise:
-                gp = dcol.reshape(T, B, Hin, Ci)
+            if wbwd is not None and not pointwise:      # implicit backward-data: no dcol matrix, no col2im pass
+                gp = _ops.conv_nt(g2.reshape(Tout, B, Hout, Co), wbwd, None, BF16, KH, KW, pad_h, pad_t, -1, T, Hin).reshape(T, B, Hin, Ci)
             else:
-                gp = _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, pad_h, pad_t, Tout)
+                dcol = _ops.gemm_nt(g2, w16t, None, BF16)
+                gp = dcol.reshape(T, B, Hin, Ci) if pointwise else _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, pad_h, pad_t, Tout)
             gx = gp.permute(1, 3, 2, 0)
             if xdtype == F32:
                 gx = _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
@@ -189,6 +201,10 @@ class _Conv2D(torch.autograd.Function):
         gb = grad_buffer(b) if b is not None else None
 
         def weight_grads():
+            nonlocal col
+            if implicit:    # the column matrix is only needed here, off the critical path
+                col = _ops.im2col(xphys, (xphys.stride(0), xphys.stride(1), xphys.stride(2), xphys.stride(3)), T, B, Hin, Ci, KH, KW,
+                                  pad_h, pad_t, Tout)
             if Kp == Kreal and KH == 1 and KW == 1:
                 _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
             else:
@@ -204,7 +220,7 @@ class _Conv2D(torch.autograd.Function):
                 weight_grads()
         else:
             weight_grads()
-        return gx, (None if w_is_param else gW), None, None, None, None, None, None, None
+        return gx, (None if w_is_param else gW), None, None, None, None, None, None, None, None
 
 
 def conv_weight_matrix(W):
@@ -217,14 +233,20 @@ def conv_weight_matrix_t(W):
     return _ops.conv_weight_pack(W.contiguous(), transpose=True)
 
 
+def conv_weight_matrix_bwd(W):
+    """bf16 (Ci, kh*kw*Co): the operand of the implicit backward-data convolution."""
+    return _ops.conv_weight_pack_bwd(W.contiguous())
+
+
 def convolution_2d(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
     """Cross-correlation over (height, time), stride 1 (asr/nn/nn.py:235-238 forces stride=1)."""
     pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
     w16 = link.compute_copy("w16", W, conv_weight_matrix)
     w16t = link.compute_copy("w16t", W, conv_weight_matrix_t)
+    wbwd = link.compute_copy("wbwd", W, conv_weight_matrix_bwd) if _ops.conv_implicit_ok(W.shape[0], W.shape[2], W.shape[3]) else None
     if x.dtype not in (F32, BF16):
         raise TypeError("convolution input must be float32 or bfloat16")
-    y = _Conv2D.apply(x, W, b, w16, w16t, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
     return logical4(y)
 
 
@@ -235,7 +257,8 @@ def convolution_2d_given_weight(x, W, b, link, pad=(0, 0), causal=False, out_f32
     with torch.no_grad():
         w16 = conv_weight_matrix(W.detach())
         w16t = conv_weight_matrix_t(W.detach())
-    y = _Conv2D.apply(x, W, b, w16, w16t, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+        wbwd = conv_weight_matrix_bwd(W.detach()) if _ops.conv_implicit_ok(W.shape[0], W.shape[2], W.shape[3]) else None
+    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
     return logical4(y)
 
 

@@ -352,6 +352,19 @@ __global__ void conv_weight_pack_kernel(const float* __restrict__ W, uint16_t* _
         if (transpose) dst[(long long)k * Co + co] = f32_to_bf16(v); else dst[i] = f32_to_bf16(v);
     }
 }
+// backward-data operand of the implicit-GEMM convolution: dst[ci][(kh*KW + kw)*Co + co] = W[co][ci][kh][kw]
+__global__ void conv_weight_pack_bwd_kernel(const float* __restrict__ W, uint16_t* __restrict__ dst, int Co, int Ci, int KH,
+                                            int KW) {
+    const long long n = (long long)Co * Ci * KH * KW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int co = (int)(r % Co); r /= Co;
+        const int kw = (int)(r % KW); r /= KW;
+        const int kh = (int)(r % KH);
+        const int ci = (int)(r / KH);
+        dst[i] = f32_to_bf16(W[(((long long)co * Ci + ci) * KH + kh) * KW + kw]);
+    }
+}
 // unpack: gW[co][ci][kh][kw] += scratch[co][(kh*KW + kw)*Ci + ci]
 __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch, float* __restrict__ gW, int Co, int Ci,
                                                int KH, int KW, int Kp) {
@@ -754,6 +767,13 @@ extern "C" int asr_conv_weight_pack(void* stream, const float* W, void* dst, int
     if (!W || !dst || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Kp < KH * KW * Ci) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid_for((long long)Co * Kp)), dim3(kThreads), 0, (hipStream_t)stream,
                        W, (uint16_t*)dst, Co, Ci, KH, KW, Kp, transpose);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst, int Co, int Ci, int KH, int KW) {
+    if (!W || !dst || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(conv_weight_pack_bwd_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(kThreads), 0, (hipStream_t)stream,
+                       W, (uint16_t*)dst, Co, Ci, KH, KW);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -251,60 +251,95 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
 // LDS image: rows of 64 B (32 k), 16-B chunk c of row r stored at position c ^ g[(r >> 2) & 3], g = {0, 2, 3, 1}: the
 // ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) then touch 16 distinct 16-B slots of the 256-B bank row.
 constexpr int B2M = 256, B2N = 128, B2K = 32;
+
+// Implicit-GEMM convolution (CONV = true): operand A is not a matrix but the activation tensor (Ts, B, Hs, Cs) bf16, and
+// row r = (t, b, h) / column k = (kh, kw, c) of the virtual im2col matrix is gathered on the fly:
+//   A[r][k] = x[t + sgn (kw - pt)][b][h + sgn (kh - ph)][c]      (zero outside the tensor)
+// sgn = +1 with rows over the OUTPUT positions is the forward convolution (col . W^T); sgn = -1 with rows over the INPUT
+// positions and x = the output gradient is the backward-data convolution.  Cs % 8 == 0 keeps every 16-B chunk inside one
+// tap, so the LDS-DMA loader only changes its per-lane source address; out-of-range chunks read a page of zeros.
+struct ConvDesc {
+    int B, Hs, Cs, Ts, KH, KW, ph, pt, sgn, Hr;       // Hr: height of the row space
+};
+__device__ uint4 g_zero_page[2];
 constexpr int NT2_STAGES = 2;
 constexpr int NT2_LDS_BYTES = NT2_STAGES * (B2M + B2N) * B2K * 2;      // stages x 24 KiB
 
-template <typename OutT>
-__global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __restrict__ A, int lda,
+// WN = waves along N: 2 -> tile 256 x 128 (waves 2 x 2, 128 x 64 each); 1 -> tile 256 x 64 (waves 4 x 1, 64 x 64 each) for N <= 64
+template <typename OutT, bool CONV, int WN>
+__global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uint16_t* __restrict__ A, int lda,
                                                             const uint16_t* __restrict__ B, int ldb, OutT* __restrict__ C,
                                                             int ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                            int tiles_n) {
+                                                            int tiles_n, ConvDesc cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     tile_of(blockIdx.x, (M + B2M - 1) / B2M, tiles_n, tm, tn);
-    const int m0 = tm * B2M, n0 = tn * B2N;
+    constexpr int TN = 64 * WN, MI = 4 * WN;        // tile columns, 16-row MFMA tiles per wave along M
+    const int m0 = tm * B2M, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = B2N * B2K * 2;
+    const int wm = WN == 2 ? wid >> 1 : wid, wn = WN == 2 ? wid & 1 : 0;
+    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = TN * B2K * 2;
     char* As = smem;                           // [3][256 rows][64 B]
     char* Bs = smem + NT2_STAGES * A_STAGE;    // [3][128 rows][64 B]
     auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
 
-    f32x4 acc[8][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // LDS-DMA sources: slot s of an image = (row s / 4, position s % 4) holds chunk (s % 4) ^ g(row); a wave-instruction
     // fills 64 consecutive slots.  A: 1024 slots = 4 per thread, B: 512 = 2 per thread.
     const uint16_t* ga[4];
-    const uint16_t* gb[2];
+    const uint16_t* gb[WN];
+    int cth[4];                            // CONV: (t << 8) | h of the slot's row; rows beyond M get a t far below zero
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int sl = i * 256 + tid, row = sl >> 2, c = (sl & 3) ^ g4(row);
-        ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        if (CONV) {
+            const int r = m0 + row;
+            const int rr = r < M ? r : 0;
+            const int h = rr % cd.Hr, tb = rr / cd.Hr, b = tb % cd.B, t = r < M ? tb / cd.B : -(1 << 20);
+            cth[i] = t * 256 + h;
+            ga[i] = A + ((size_t)b * cd.Hs) * cd.Cs;                 // + ((ti * B) * Hs + hi) * Cs + ci per tile
+        } else {
+            ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WN; ++i) {
         const int sl = i * 256 + tid, row = sl >> 2, c = (sl & 3) ^ g4(row);
         gb[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
     }
     auto issue_tile = [&](int kt, int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga[i] + kt * B2K), (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const uint16_t* src;
+            if (CONV) {
+                const int sl = i * 256 + tid, row = sl >> 2;
+                const int k = kt * B2K + ((sl & 3) ^ g4(row)) * 8;
+                const int tap = k / cd.Cs, ci = k - tap * cd.Cs;
+                const int kh = tap / cd.KW, kw = tap - kh * cd.KW;
+                const int ti = (cth[i] >> 8) + cd.sgn * (kw - cd.pt), hi = (cth[i] & 255) + cd.sgn * (kh - cd.ph);
+                const bool ok = ti >= 0 && ti < cd.Ts && hi >= 0 && hi < cd.Hs;
+                src = ok ? ga[i] + ((size_t)ti * cd.B * cd.Hs + hi) * cd.Cs + ci : reinterpret_cast<const uint16_t*>(g_zero_page);
+            } else {
+                src = ga[i] + kt * B2K;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WN; ++i)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[i] + kt * B2K), (lds_ptr_t)(Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
     };
     // fragment addresses (bytes inside a stage) are loop invariant
-    int aoff[8], boff[4];
+    int aoff[MI], boff[4];
     {
         const int q = lane >> 4, r = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = wm * 128 + i * 16 + r;
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * (16 * MI) + i * 16 + r;
             aoff[i] = row * 64 + ((q ^ g4(row)) << 4);
         }
 #pragma unroll
@@ -318,10 +353,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __re
     // the DMAs of the tiles behind kt + 1 are outstanding (6 per tile and wave).  Raw s_barrier: __syncthreads() would
     // drain the DMAs in flight.
     constexpr int S = NT2_STAGES;
-    auto wait_tiles_in_flight = [](int tiles) {          // vmcnt needs an immediate
-        if (tiles >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (tiles == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    auto wait_tiles_in_flight = [](int tiles) {          // vmcnt needs an immediate: 4 + WN DMAs per tile and thread
+        if (tiles >= 3) { if (WN == 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
+        else if (tiles == 2) { if (WN == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else if (tiles == 1) { if (WN == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const int nk = K / B2K;
@@ -337,7 +372,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const uint4*>(Bb + boff[j]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MI; ++i) {
             Frag a;
             a.u = *reinterpret_cast<const uint4*>(Ab + aoff[i]);
 #pragma unroll
@@ -350,10 +385,10 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __re
 
     // epilogue: 64 rows at a time through LDS (f32, row pitch 132 floats = 33 KB) and whole rows out
     float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int CP = B2N + 4;
+    constexpr int CP = TN + 4;
 #pragma unroll
     for (int chunk = 0; chunk < 4; ++chunk) {
-        if (wm == (chunk >> 1)) {
+        if (wm == (WN == 2 ? chunk >> 1 : chunk)) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
@@ -362,12 +397,12 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256_kernel(const uint16_t* __re
                     for (int r = 0; r < 4; ++r) {
                         const int row = ii * 16 + (lane >> 4) * 4 + r;
                         const int col = wn * 64 + j * 16 + (lane & 15);
-                        Cs[row * CP + col] = acc[(chunk & 1) * 4 + ii][j][r];
+                        Cs[row * CP + col] = acc[(WN == 2 ? (chunk & 1) * 4 : 0) + ii][j][r];
                     }
         }
         __syncthreads();
-        for (int id = tid; id < 64 * (B2N / 4); id += 256) {
-            const int row = id / (B2N / 4), c4 = (id - row * (B2N / 4)) * 4;
+        for (int id = tid; id < 64 * (TN / 4); id += 256) {
+            const int row = id / (TN / 4), c4 = (id - row * (TN / 4)) * 4;
             const int gm = m0 + chunk * 64 + row, gn = n0 + c4;
             if (gm >= M || gn >= N) continue;
             float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
@@ -525,17 +560,17 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     if (aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024) {      // at least two rounds of 2 workgroups per CU
         static bool attr2 = false;
         if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<float, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
             attr2 = true;
         }
         const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N) * (b_fits_l2 ? -1 : 1);
         if (out_bf16)
-            hipLaunchKernelGGL(gemm_nt256_kernel<uint16_t>, dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
-                               (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, t2n);
+            hipLaunchKernelGGL((gemm_nt256_kernel<uint16_t, false, 2>), dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, t2n, ConvDesc{});
         else
-            hipLaunchKernelGGL(gemm_nt256_kernel<float>, dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
-                               (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, t2n);
+            hipLaunchKernelGGL((gemm_nt256_kernel<float, false, 2>), dim3(t2m * cdiv(N, B2N)), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, t2n, ConvDesc{});
         ASR_LAUNCH_CHECK();
         return ASR_OK;
     }
@@ -565,6 +600,38 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     splits = cdiv(K, k_per_split);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
                        (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, void* out, int out_bf16, const float* bias, int Ts,
+                           int B, int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
+    if (!x || !W || !out || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0 || N <= 0 ||
+        (sgn != 1 && sgn != -1))
+        return ASR_ERR_BAD_ARG;
+    const long long M = (long long)Tr * B * Hr;
+    const int K = KH * KW * Cs;
+    if ((Cs & 7) || (K % B2K) || M > 0x7fffffffLL || ((((uintptr_t)x) | ((uintptr_t)W)) & 15)) return ASR_ERR_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<float, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<float, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<uint16_t, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+        attr = true;
+    }
+    const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, sgn, Hr};
+    const bool narrow = N <= 64;                 // 256 x 64 tiles: no MFMA work on columns that do not exist
+    const int t2m = cdiv((int)M, B2M), t2n = cdiv(N, narrow ? 64 : B2N);
+    const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;
+    const int tn_arg = b_fits_l2 ? -t2n : t2n;
+#define ASR_CONV(T, W_, CT)                                                                                               \
+    hipLaunchKernelGGL((gemm_nt256_kernel<T, true, W_>), dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)x, 0, \
+                       (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, tn_arg, cd)
+    if (out_bf16) { if (narrow) ASR_CONV(uint16_t, 1, uint16_t); else ASR_CONV(uint16_t, 2, uint16_t); }
+    else          { if (narrow) ASR_CONV(float, 1, float); else ASR_CONV(float, 2, float); }
+#undef ASR_CONV
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -357,3 +357,33 @@ def test_non_finite_step_is_skipped(device):
         vel = torch.zeros(n, device=device)
         _ops.clip_decay_sgd(p, gr, vel, 1, 1e-2, 0.9, 0.0, 0.0, 1.0, sq)
         assert torch.equal(p, p0) and bool((vel == 0).all())
+
+
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
+                                                          (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True)])
+def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
+    """asr_conv_nt (no column matrix) against the im2col + GEMM path it replaces, forward and backward-data: the same
+    products in the same bf16 operands, so they agree to accumulation order"""
+    from asr import _ops
+    rs = np.random.RandomState(T + Ci)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(torch.bfloat16)
+    W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.1).astype(np.float32)).to(device)
+    bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
+    w16 = _ops.conv_weight_pack(W)
+    col = _ops.im2col(x, (x.stride(0), x.stride(1), x.stride(2), x.stride(3)), T, B, Hin, Ci, KH, KW, ph, pt, Tout)
+    ref = _ops.gemm_nt(col, w16, bias, torch.float32)
+    got = _ops.conv_nt(x, w16, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got.cpu(), ref.cpu()) < 1e-5
+    got16 = _ops.conv_nt(x, w16, bias, torch.bfloat16, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got16.float().cpu(), ref.cpu()) < 1e-2
+    # backward-data: dx = col2im(gy . W)
+    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(torch.bfloat16)
+    w16t = _ops.conv_weight_pack(W, transpose=True)
+    dcol = _ops.gemm_nt(gy.reshape(-1, Co), w16t, None, torch.float32)
+    ref_dx = _ops.col2im(dcol.to(torch.bfloat16), T, B, Hin, Ci, KH, KW, ph, pt, Tout).float()
+    wb = _ops.conv_weight_pack_bwd(W)
+    got_dx = _ops.conv_nt(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin).reshape(T, B, Hin, Ci)
+    assert _rel(got_dx.cpu(), ref_dx.cpu()) < 2e-2      # the reference path rounds dcol to bf16 before the gather
