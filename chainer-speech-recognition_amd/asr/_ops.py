@@ -94,11 +94,11 @@ def col2im(dcol, T, B, Hin, Cin, KH, KW, pad_h, pad_t=None, Tout=None):
     return dx
 
 
-def conv_weight_pack(W, transpose=False):
-    """(Co, Ci, kh, kw) f32 -> bf16 (Co, Kp) [or (Kp, Co)], k = (kh, kw, ci), Kp = K rounded up to 8."""
+def conv_weight_pack(W, transpose=False, Kp=None):
+    """(Co, Ci, kh, kw) f32 -> bf16 (Co, Kp) [or (Kp, Co)], k = (kh, kw, ci), Kp = K rounded up to 8 (or as given), zero padded."""
     assert W.dtype == F32 and W.is_contiguous() and W.dim() == 4
     Co, Ci, KH, KW = W.shape
-    Kp = (KH * KW * Ci + 7) // 8 * 8
+    Kp = (KH * KW * Ci + 7) // 8 * 8 if Kp is None else int(Kp)
     dst = torch.empty((Kp, Co) if transpose else (Co, Kp), dtype=BF16, device=W.device)
     check(_lib.lib().asr_conv_weight_pack(stream(), ptr(W), ptr(dst), Co, Ci, KH, KW, Kp, int(transpose)), "asr_conv_weight_pack")
     return dst
@@ -499,10 +499,10 @@ def conv_nt(x, W2, bias, out_dtype, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     """x (Ts, B, Hs, Cs) bf16 contiguous; W2 (N, KH*KW*Cs) bf16 -> (Tr*B*Hr, N): asr_hip.h asr_conv_nt."""
     Ts, B, Hs, Cs = x.shape
     N = W2.shape[0]
-    assert x.dtype == BF16 and x.is_contiguous() and W2.dtype == BF16 and W2.is_contiguous() and W2.shape[1] == KH * KW * Cs
+    assert x.dtype == BF16 and x.is_contiguous() and W2.dtype == BF16 and W2.is_contiguous() and W2.shape[1] >= KH * KW * Cs
     out = torch.empty((Tr * B * Hr, N), dtype=out_dtype, device=x.device)
-    rc = _lib.lib().asr_conv_nt(stream(), ptr(x), ptr(W2), ptr(out), _is_bf16(out), ptr(bias), Ts, B, Hs, Cs, KH, KW, pad_h, pad_t,
-                                int(sgn), Tr, Hr, N)
+    rc = _lib.lib().asr_conv_nt(stream(), ptr(x), ptr(W2), W2.shape[1], ptr(out), _is_bf16(out), ptr(bias), Ts, B, Hs, Cs, KH, KW,
+                                pad_h, pad_t, int(sgn), Tr, Hr, N)
     check(rc, "asr_conv_nt")
     return out
 
@@ -513,3 +513,11 @@ def conv_weight_pack_bwd(W):
     dst = torch.empty((Ci, KH * KW * Co), dtype=BF16, device=W.device)
     check(_lib.lib().asr_conv_weight_pack_bwd(stream(), ptr(W), ptr(dst), Co, Ci, KH, KW), "asr_conv_weight_pack_bwd")
     return dst
+
+
+def pack_input_pad(x, strides_tbhc, T, B, H, C, Cpad):
+    """any strided (T, B, H, C) view of x -> dense (T, B, H, Cpad) bf16 with zero channels behind C."""
+    out = torch.empty((T, B, H, Cpad), dtype=BF16, device=x.device)
+    rc = _lib.lib().asr_pack_input_pad(stream(), x.data_ptr(), _is_bf16(x), *strides_tbhc, T, B, H, C, Cpad, ptr(out))
+    check(rc, "asr_pack_input_pad")
+    return out

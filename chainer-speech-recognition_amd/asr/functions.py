@@ -136,13 +136,23 @@ class _Conv2D(torch.autograd.Function):
     Output physical (Tout, B, Hout, Co) bf16 (or f32)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, w16, w16t, wbwd, pad_h, pad_t, causal, out_f32):
+    def forward(ctx, x, W, b, w16, w16t, wbwd, w16p, pad_h, pad_t, causal, out_f32):
         B, Ci, Hin, T = x.shape
         Co, _, KH, KW = W.shape
         Tout = T if causal else T + 2 * pad_t - KW + 1
         Hout = Hin + 2 * pad_h - KH + 1
         pointwise = KH == 1 and KW == 1 and pad_h == 0 and pad_t == 0
         xp = None
+        # first layer (Cin < 8, e.g. the loader's (B, 3, 40, T) float32 minibatch, no input gradient wanted): bring the input
+        # to (T, B, H, 8) bf16 with zero channels and run the implicit GEMM with K padded by one empty tap to a multiple of 32
+        if not pointwise and Ci < 8 and not ctx.needs_input_grad[0] and w16p is not None:
+            xpad = _ops.pack_input_pad(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, 8)
+            y = _ops.conv_nt(xpad, w16p, b.detach() if b is not None else None, F32 if out_f32 else BF16, KH, KW, pad_h, pad_t,
+                             +1, Tout, Hout)
+            ctx.save_for_backward(x, w16t, wbwd)
+            ctx.params = (W, b)
+            ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, False, 2)
+            return y.reshape(Tout, B, Hout, Co)
         # implicit GEMM (asr_conv_nt): no column matrix when the input is already physical bf16 and every 16-B chunk of a
         # virtual im2col row stays inside one tap
         xphys = x.permute(3, 0, 2, 1)
@@ -202,7 +212,10 @@ class _Conv2D(torch.autograd.Function):
 
         def weight_grads():
             nonlocal col
-            if implicit:    # the column matrix is only needed here, off the critical path
+            if implicit == 2:       # first layer: the saved tensor is the logical (B, C, H, T) input
+                col = _ops.im2col(xphys, (xphys.stride(3), xphys.stride(0), xphys.stride(2), xphys.stride(1)), T, B, Hin, Ci, KH, KW,
+                                  pad_h, pad_t, Tout)
+            elif implicit:          # the column matrix is only needed here, off the critical path
                 col = _ops.im2col(xphys, (xphys.stride(0), xphys.stride(1), xphys.stride(2), xphys.stride(3)), T, B, Hin, Ci, KH, KW,
                                   pad_h, pad_t, Tout)
             if Kp == Kreal and KH == 1 and KW == 1:
@@ -220,7 +233,7 @@ class _Conv2D(torch.autograd.Function):
                 weight_grads()
         else:
             weight_grads()
-        return gx, (None if w_is_param else gW), None, None, None, None, None, None, None, None
+        return gx, (None if w_is_param else gW), None, None, None, None, None, None, None, None, None
 
 
 def conv_weight_matrix(W):
@@ -238,6 +251,15 @@ def conv_weight_matrix_bwd(W):
     return _ops.conv_weight_pack_bwd(W.contiguous())
 
 
+def conv_weight_matrix_pad8(W):
+    """first-layer operand of the implicit convolution: channels zero-padded to 8, k = (kh, kw, c8), rows padded with empty
+    (zero) taps to a multiple of 32"""
+    Co, Ci, KH, KW = W.shape
+    Wp = torch.zeros((Co, 8, KH, KW), dtype=W.dtype, device=W.device)
+    Wp[:, :Ci] = W
+    return _ops.conv_weight_pack(Wp, Kp=(KH * KW * 8 + 31) // 32 * 32)
+
+
 def convolution_2d(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
     """Cross-correlation over (height, time), stride 1 (asr/nn/nn.py:235-238 forces stride=1)."""
     pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
@@ -246,7 +268,8 @@ def convolution_2d(x, W, b, link, pad=(0, 0), causal=False, out_f32=False):
     wbwd = link.compute_copy("wbwd", W, conv_weight_matrix_bwd) if _ops.conv_implicit_ok(W.shape[0], W.shape[2], W.shape[3]) else None
     if x.dtype not in (F32, BF16):
         raise TypeError("convolution input must be float32 or bfloat16")
-    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+    w16p = link.compute_copy("w16p", W, conv_weight_matrix_pad8) if W.shape[1] < 8 else None
+    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, w16p, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
     return logical4(y)
 
 
@@ -258,7 +281,8 @@ def convolution_2d_given_weight(x, W, b, link, pad=(0, 0), causal=False, out_f32
         w16 = conv_weight_matrix(W.detach())
         w16t = conv_weight_matrix_t(W.detach())
         wbwd = conv_weight_matrix_bwd(W.detach()) if _ops.conv_implicit_ok(W.shape[0], W.shape[2], W.shape[3]) else None
-    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
+        w16p = conv_weight_matrix_pad8(W.detach()) if W.shape[1] < 8 else None
+    y = _Conv2D.apply(x, W, b, w16, w16t, wbwd, w16p, int(pad_h), int(pad_t), bool(causal), bool(out_f32))
     return logical4(y)
 
 

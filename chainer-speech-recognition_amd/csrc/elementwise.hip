@@ -75,6 +75,26 @@ __global__ void permute4_kernel(const SrcT* __restrict__ src, DstT* __restrict__
     }
 }
 
+// dense (T, B, H, Cpad) bf16 from any strided (T, B, H, C) source, zero channels behind C
+template <typename SrcT>
+__global__ void pack_input_pad_kernel(const SrcT* __restrict__ x, long long sT, long long sB, long long sH, long long sC, int T,
+                                      int B, int H, int C, int Cpad, uint16_t* __restrict__ out) {
+    const long long n = (long long)T * B * H * Cpad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        long long r = i;
+        const int c = (int)(r % Cpad); r /= Cpad;
+        const int h = (int)(r % H); r /= H;
+        const int b = (int)(r % B);
+        const int t = (int)(r / B);
+        uint16_t v = 0;
+        if (c < C) {
+            const SrcT s = x[t * sT + b * sB + h * sH + c * sC];
+            if (sizeof(SrcT) == 2) v = (uint16_t)s; else v = f32_to_bf16((float)s);
+        }
+        out[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ im2col / col2im
 // col[(t, b, ho)][(kh, kw, ci)] = x[t + kw - pt, b, ho + kh - ph, ci]   (zero outside), row pitch Kp >= KH*KW*Cin,
 // t in [0, Tout).  pt = KW-1, Tout = T is the causal convolution; Tout = T + KW-1 the reference's padded output.
@@ -782,6 +802,20 @@ extern "C" int asr_conv_weight_grad_unpack(void* stream, const float* scratch, f
     if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Kp < KH * KW * Ci) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(conv_weight_grad_unpack_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(kThreads), 0,
                        (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC,
+                                  int T, int B, int H, int C, int Cpad, void* out_bf16) {
+    if (!x || !out_bf16 || T <= 0 || B <= 0 || H <= 0 || C <= 0 || Cpad < C) return ASR_ERR_BAD_ARG;
+    const long long n = (long long)T * B * H * Cpad;
+    if (x_bf16)
+        hipLaunchKernelGGL(pack_input_pad_kernel<uint16_t>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                           sT, sB, sH, sC, T, B, H, C, Cpad, (uint16_t*)out_bf16);
+    else
+        hipLaunchKernelGGL(pack_input_pad_kernel<float>, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const float*)x, sT,
+                           sB, sH, sC, T, B, H, C, Cpad, (uint16_t*)out_bf16);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
                 const int tap = k / cd.Cs, ci = k - tap * cd.Cs;
                 const int kh = tap / cd.KW, kw = tap - kh * cd.KW;
                 const int ti = (cth[i] >> 8) + cd.sgn * (kw - cd.pt), hi = (cth[i] & 255) + cd.sgn * (kh - cd.ph);
-                const bool ok = ti >= 0 && ti < cd.Ts && hi >= 0 && hi < cd.Hs;
+                const bool ok = ti >= 0 && ti < cd.Ts && hi >= 0 && hi < cd.Hs && kh < cd.KH;      // (K may be padded with empty taps)
                 src = ok ? ga[i] + ((size_t)ti * cd.B * cd.Hs + hi) * cd.Cs + ci : reinterpret_cast<const uint16_t*>(g_zero_page);
             } else {
                 src = ga[i] + kt * B2K;
@@ -604,14 +604,15 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     return ASR_OK;
 }
 
-extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, void* out, int out_bf16, const float* bias, int Ts,
-                           int B, int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
+extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias,
+                           int Ts, int B, int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
     if (!x || !W || !out || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0 || N <= 0 ||
         (sgn != 1 && sgn != -1))
         return ASR_ERR_BAD_ARG;
     const long long M = (long long)Tr * B * Hr;
-    const int K = KH * KW * Cs;
-    if ((Cs & 7) || (K % B2K) || M > 0x7fffffffLL || ((((uintptr_t)x) | ((uintptr_t)W)) & 15)) return ASR_ERR_UNSUPPORTED;
+    const int K = ldw;                  // row pitch of W = K of the GEMM: KH*KW*Cs, or more with empty (zero) taps behind
+    if (ldw < KH * KW * Cs) return ASR_ERR_BAD_ARG;
+    if ((Cs & 7) || (K % B2K) || (K % Cs) || M > 0x7fffffffLL || ((((uintptr_t)x) | ((uintptr_t)W)) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     static bool attr = false;
     if (!attr) {

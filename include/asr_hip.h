@@ -139,14 +139,19 @@ int asr_col2im(void* stream, const void* dcol, int T, int B, int Hin, int Cin, i
 /* Convolution2D weights (Co, Ci, kh, kw) f32 <-> the GEMM's (Co, Kp) matrix with k = (kh, kw, ci) */
 int asr_conv_weight_pack(void* stream, const float* W, void* dst_bf16, int Co, int Ci, int KH, int KW, int Kp,
                          int transpose);
-/* implicit-GEMM convolution (no column matrix): x (Ts, B, Hs, Cs) bf16 with Cs % 8 == 0 and KH*KW*Cs % 32 == 0;
+/* implicit-GEMM convolution (no column matrix): x (Ts, B, Hs, Cs) bf16 with Cs % 8 == 0; W rows of pitch ldw >= KH*KW*Cs,
+ * ldw % 32 == 0 and ldw % Cs == 0 (columns behind KH*KW*Cs are empty taps and must hold zeros);
  * out[(t, b, h)][n] = sum_{kh,kw,c} x[t + sgn (kw - pad_t)][b][h + sgn (kh - pad_h)][c] * W[n][(kh*KW + kw)*Cs + c]  (+ bias)
  * over rows t < Tr, h < Hr (zero outside x).  sgn = +1, rows = output positions, W = asr_conv_weight_pack(.., 0): the
  * forward convolution of nn.Convolution2D (asr/nn/nn.py:235-238); sgn = -1, x = output gradient, rows = input positions,
  * W = asr_conv_weight_pack_bwd: its backward-data.  out (Tr*B*Hr, N) bf16 or f32.
  * asr_conv_weight_pack_bwd: dst[ci][(kh*KW + kw)*Co + co] = W[co][ci][kh][kw] as bf16. */
-int asr_conv_nt(void* stream, const void* x, const void* W, void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
-                int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+int asr_conv_nt(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B,
+                int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+/* any strided (T, B, H, C) f32 / bf16 tensor -> dense (T, B, H, Cpad) bf16, channels C..Cpad-1 zero: brings the loader's
+ * (B, 3, 40, T) float32 minibatch into the layout of asr_conv_nt (first layer: C = 3 -> Cpad = 8) */
+int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,
+                       int B, int H, int C, int Cpad, void* out_bf16);
 int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst, int Co, int Ci, int KH, int KW);
 int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp);
 int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);

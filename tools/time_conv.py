@@ -26,3 +26,18 @@ print("bwd  gemm(dcol)    %.3f ms" % t(lambda: _ops.gemm_nt(gy.reshape(-1, Co), 
 dcol = _ops.gemm_nt(gy.reshape(-1, Co), w16t, None, torch.bfloat16)
 print("bwd  col2im        %.3f ms" % t(lambda: _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, 0)))
 print("bwd  implicit      %.3f ms" % t(lambda: _ops.conv_nt(gy, wb, None, torch.bfloat16, KH, KW, 0, KW - 1, -1, T, Hin)))
+# first layer: (B, 3, 40, T) float32 -> 128 channels, k 3x5
+B, Ci, Hin, T, Co = 32, 3, 40, 1000, 128
+x = torch.randn(B, Ci, Hin, T, device=dev)
+W = (torch.randn(Co, Ci, KH, KW, device=dev) * 0.05)
+w16 = _ops.conv_weight_pack(W)
+Wp = torch.zeros((Co, 8, KH, KW), device=dev); Wp[:, :Ci] = W
+w16p = _ops.conv_weight_pack(Wp, Kp=128)
+st = (x.stride(3), x.stride(0), x.stride(2), x.stride(1))
+Hout = Hin - KH + 1
+print("conv1 im2col       %.3f ms" % t(lambda: _ops.im2col(x, st, T, B, Hin, Ci, KH, KW, 0)))
+col = _ops.im2col(x, st, T, B, Hin, Ci, KH, KW, 0)
+print("conv1 gemm(col)    %.3f ms" % t(lambda: _ops.gemm_nt(col, w16, None, torch.bfloat16)))
+print("conv1 pack_pad8    %.3f ms" % t(lambda: _ops.pack_input_pad(x, st, T, B, Hin, Ci, 8)))
+xp = _ops.pack_input_pad(x, st, T, B, Hin, Ci, 8)
+print("conv1 implicit     %.3f ms" % t(lambda: _ops.conv_nt(xp, w16p, None, torch.bfloat16, KH, KW, 0, KW - 1, +1, T, Hout)))
