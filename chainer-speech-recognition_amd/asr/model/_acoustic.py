@@ -57,3 +57,23 @@ def load_if_exists(module, filename):
         module.load_state_dict(torch.load(filename, map_location="cpu"))
         return True
     return False
+
+
+class AcousticCall(object):
+    """mix-in giving a layer container (nn.Stream or nn.Module) the acoustic-model call of the reference
+    (asr/model/cnn.py:33-49, asr/model/sru.py:29-45): run the stack on x (B, C, H, T), check that the time axis survived,
+    hand the logits over per time step (tuple of T (B, V) views) or as one (B, T, V) view; plus save / load."""
+
+    def __call__(self, x, split_into_variables=True):
+        n_utt, n_frames = x.shape[0], x.shape[3]
+        mark_logit_layers(self.layers)
+        logits = super(AcousticCall, self).__call__(x)
+        if logits.shape[3] != n_frames:
+            raise AssertionError("the model changed the number of frames: %d -> %d" % (n_frames, logits.shape[3]))
+        return split_output(logits, n_utt, n_frames, split_into_variables)
+
+    def save(self, filename):
+        save_atomic(self, filename)
+
+    def load(self, filename):
+        return load_if_exists(self, filename)

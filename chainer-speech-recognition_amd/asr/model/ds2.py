@@ -9,27 +9,13 @@ forward (the template drops it, run/ctc/sru/model.py:120-124).  SURVEY.md sectio
   Conv1D(dense->V), LayerNormalization.
 """
 from .. import functions, nn
-from . import base
+from .base import NeedsVocabulary
 from ._acoustic import load_if_exists, save_atomic, split_output
 
 
-class Configuration(base.Configuration):
-    def __init__(self):
-        super().__init__()
-        self.vocab_size = -1
-        self.ndim_audio_features = 3
-        self.ndim_conv = 64
-        self.ndim_rnn = 512
-        self.ndim_dense = 320
-        self.num_conv_layers = 2
-        self.num_rnn_layers = 4
-        self.bidirectional = True
-        self.kernel_size = (3, 5)
-        self.dropout = 0
-
-    def save(self, filename):
-        assert self.vocab_size > 0
-        super().save(filename)
+class Configuration(NeedsVocabulary):
+    FIELDS = dict(ndim_audio_features=3, ndim_conv=64, ndim_rnn=512, ndim_dense=320, num_conv_layers=2, num_rnn_layers=4,
+                  bidirectional=True, kernel_size=(3, 5), dropout=0)
 
 
 def configure():

@@ -1,41 +1,17 @@
-"""nn.Module based acoustic model -- asr/model/sru.py:9-59."""
+"""Conv + recurrent acoustic model container built from named sub-modules (reference: asr/model/sru.py:9-59)."""
 from .. import nn
-from . import base
-from ._acoustic import load_if_exists, mark_logit_layers, save_atomic, split_output
+from .base import NeedsVocabulary
+from ._acoustic import AcousticCall
 
 
-class Configuration(base.Configuration):
-    def __init__(self):
-        super().__init__()
-        self.vocab_size = -1
-        self.ndim_audio_features = 40
-        self.ndim_conv = 64
-        self.ndim_h = 128
-        self.ndim_dense = 256
-        self.num_rnn_layers = 2
-        self.kernel_size = (3, 5)
-        self.dropout = 0
-
-    def save(self, filename):
-        assert self.vocab_size > 0
-        super().save(filename)
+class Configuration(NeedsVocabulary):
+    FIELDS = dict(ndim_audio_features=40, ndim_conv=64, ndim_h=128, ndim_dense=256, num_rnn_layers=2, kernel_size=(3, 5),
+                  dropout=0)
 
 
 def configure():
     return Configuration()
 
 
-class AcousticModel(nn.Module):
-    def __call__(self, x, split_into_variables=True):
-        batchsize = x.shape[0]
-        seq_length = x.shape[3]
-        mark_logit_layers(self.layers)
-        out_data = super(AcousticModel, self).__call__(x)
-        assert out_data.shape[3] == seq_length
-        return split_output(out_data, batchsize, seq_length, split_into_variables)
-
-    def save(self, filename):
-        save_atomic(self, filename)
-
-    def load(self, filename):
-        return load_if_exists(self, filename)
+class AcousticModel(AcousticCall, nn.Module):
+    pass

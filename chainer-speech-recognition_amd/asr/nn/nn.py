@@ -19,162 +19,81 @@ from .layernorm import normalize_layer  # noqa: F401
 from .sru import SRU  # noqa: F401
 
 
-# Standard functions (asr/nn/nn.py:11-73)
-
-class ClippedReLU():
-    def __init__(self, z=20):
-        self.z = z
-
-    def __call__(self, x):
-        return functions.clipped_relu(x, self.z)
+# ---------------------------------------------------------------------------------------------------------------------
+# Function layers (asr/nn/nn.py:11-218): stateless callables that remember a few arguments.  They are generated from one
+# table -- (layer name, function applied, ((argument, default), ...)) -- instead of one hand-written class each; an
+# argument without default is required, arguments may be given by position or keyword, and every argument is kept as an
+# attribute of the same name (the recipes read e.g. ``layer.ratio``).
+_REQUIRED = object()
 
 
-class ELU():
-    def __init__(self, alpha=1):
-        self.alpha = alpha
+def _function_layer(name, fn, signature, doc=None):
+    names = tuple(n for n, _ in signature)
 
-    def __call__(self, x):
-        return functions.elu(x, self.alpha)
-
-
-def HardSigmoid():
-    return functions.hard_sigmoid
-
-
-class LeakyReLU():
-    def __init__(self, slope=1):
-        self.slope = slope
+    def __init__(self, *args, **kwargs):
+        if len(args) > len(names):
+            raise TypeError("%s() takes at most %d arguments" % (name, len(names)))
+        given = dict(zip(names, args))
+        for key, value in kwargs.items():
+            if key not in names or key in given:
+                raise TypeError("%s() got an unexpected or repeated argument %r" % (name, key))
+            given[key] = value
+        for key, default in signature:
+            if key not in given and default is _REQUIRED:
+                raise TypeError("%s() missing argument %r" % (name, key))
+            setattr(self, key, given.get(key, default))
 
     def __call__(self, x):
-        return functions.leaky_relu(x, self.slope)
+        return fn(x, *(getattr(self, key) for key in names))
+
+    return type(name, (object,), {"__init__": __init__, "__call__": __call__, "__doc__": doc or "functions.%s" % fn.__name__})
 
 
-class Maxout():
-    """asr/nn/nn.py:45-50 (the reference's default pool_size=0.5 is unusable; every call site passes 2)."""
-
-    def __init__(self, pool_size=0.5):
-        self.pool_size = pool_size
-
-    def __call__(self, x):
-        return functions.maxout(x, self.pool_size)
+def _plain(fn):
+    """layers without arguments are factories returning the function itself (asr/nn/nn.py:25-27,52-56,71-73,159-161)"""
+    def factory():
+        return fn
+    factory.__name__ = fn.__name__
+    return factory
 
 
-def ReLU():
-    return functions.relu
+def _max_pool(x, ksize, stride, pad, cover_all):
+    # the reference forwards only ksize / stride / pad, so Chainer's default cover_all=True always applies (:102-103)
+    return functions.max_pooling_2d(x, ksize, stride, pad)
 
 
-def Sigmoid():
-    return functions.sigmoid
+def _dropout(x, ratio):
+    return x if ratio == 0 else functions.dropout(x, ratio)
 
 
-class Softplus():
-    def __init__(self, beta=1):
-        self.beta = beta
+for _name, _fn, _sig, _doc in (
+        # activations (asr/nn/nn.py:11-73)
+        ("ClippedReLU", functions.clipped_relu, (("z", 20),), None),
+        ("ELU", functions.elu, (("alpha", 1),), None),
+        ("LeakyReLU", functions.leaky_relu, (("slope", 1),), None),
+        ("Maxout", functions.maxout, (("pool_size", 0.5),),
+         "asr/nn/nn.py:45-50 (the reference's default pool_size=0.5 is unusable; every call site passes 2)"),
+        ("Softplus", functions.softplus, (("beta", 1),), None),
+        # pooling (:95-103)
+        ("MaxPooling2D", _max_pool, (("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("cover_all", True)), "asr/nn/nn.py:95-103"),
+        # array manipulation (:148-207): views of the physical buffer
+        ("BroadcastTo", functions.broadcast_to, (("shape", _REQUIRED),), None),
+        ("ExpandDims", functions.expand_dims, (("axis", _REQUIRED),), None),
+        ("Reshape", functions.reshape, (("shape", _REQUIRED),), None),
+        ("RollAxis", functions.rollaxis, (("axis", _REQUIRED), ("start", 0)), None),
+        ("Squeeze", functions.squeeze, (("axis", _REQUIRED),), None),
+        ("SwapAxes", functions.swapaxes, (("axis1", _REQUIRED), ("axis2", _REQUIRED)), None),
+        ("Tile", functions.tile, (("reps", _REQUIRED),), None),
+        ("Transpose", functions.transpose, (("axes", _REQUIRED),), None),
+        # noise (:211-218): identity when the ratio is 0
+        ("Dropout", _dropout, (("ratio", 0.5),), "asr/nn/nn.py:211-218")):
+    globals()[_name] = _function_layer(_name, _fn, _sig, _doc)
 
-    def __call__(self, x):
-        return functions.softplus(x, self.beta)
-
-
-def Tanh():
-    return functions.tanh
-
-
-# Pooling (asr/nn/nn.py:95-103)
-
-class MaxPooling2D():
-    def __init__(self, ksize, stride=None, pad=0, cover_all=True):
-        self.ksize = ksize
-        self.stride = stride
-        self.pad = pad
-        self.cover_all = cover_all
-
-    def __call__(self, x):
-        # the reference forwards only ksize/stride/pad, so Chainer's default cover_all=True applies (asr/nn/nn.py:102-103)
-        return functions.max_pooling_2d(x, self.ksize, self.stride, self.pad)
-
-
-# Array manipulations (asr/nn/nn.py:148-207) -- views
-
-class BroadcastTo():
-    def __init__(self, shape):
-        self.shape = shape
-
-    def __call__(self, x):
-        return functions.broadcast_to(x, self.shape)
-
-
-class ExpandDims():
-    def __init__(self, axis):
-        self.axis = axis
-
-    def __call__(self, x):
-        return functions.expand_dims(x, self.axis)
-
-
-def Flatten():
-    return functions.flatten
-
-
-class Reshape():
-    def __init__(self, shape):
-        self.shape = shape
-
-    def __call__(self, x):
-        return functions.reshape(x, self.shape)
-
-
-class RollAxis():
-    def __init__(self, axis, start=0):
-        self.axis = axis
-        self.start = start
-
-    def __call__(self, x):
-        return functions.rollaxis(x, self.axis, self.start)
-
-
-class Squeeze():
-    def __init__(self, axis):
-        self.axis = axis
-
-    def __call__(self, x):
-        return functions.squeeze(x, self.axis)
-
-
-class SwapAxes():
-    def __init__(self, axis1, axis2):
-        self.axis1 = axis1
-        self.axis2 = axis2
-
-    def __call__(self, x):
-        return functions.swapaxes(x, self.axis1, self.axis2)
-
-
-class Tile():
-    def __init__(self, reps):
-        self.reps = reps
-
-    def __call__(self, x):
-        return functions.tile(x, self.reps)
-
-
-class Transpose():
-    def __init__(self, axes):
-        self.axes = axes
-
-    def __call__(self, x):
-        return functions.transpose(x, self.axes)
-
-
-# Noise injection (asr/nn/nn.py:211-218)
-
-class Dropout():
-    def __init__(self, ratio=0.5):
-        self.ratio = ratio
-
-    def __call__(self, x):
-        if self.ratio == 0:
-            return x
-        return functions.dropout(x, self.ratio)
+HardSigmoid = _plain(functions.hard_sigmoid)
+ReLU = _plain(functions.relu)
+Sigmoid = _plain(functions.sigmoid)
+Tanh = _plain(functions.tanh)
+Flatten = _plain(functions.flatten)
 
 
 # Links
@@ -292,28 +211,32 @@ def _apply_layers(layers, x):
     return x
 
 
-# Chains (asr/nn/nn.py:296-414)
+# Chains (asr/nn/nn.py:296-414).  Both containers register the parameterised layers they are given as attributes named
+# <prefix><index> (and <prefix><index>_<inner index> for the layers inside a Residual), which is what fixes the parameter
+# names of a saved model: "layer_" for Stream (:304-320), "_sequential_" for Module (:341-353).
+
+def _register_layers(owner, prefix, first_index, layers, glu_weight=False):
+    for offset, layer in enumerate(layers):
+        tag = "%s%d" % (prefix, first_index + offset)
+        if isinstance(layer, Link):
+            setattr(owner, tag, layer)
+        elif glu_weight and isinstance(layer, GLU):
+            setattr(owner, tag, layer.W)
+        elif isinstance(layer, Residual):
+            for inner, sub in enumerate(layer.layers):
+                if isinstance(sub, Link):
+                    setattr(owner, "%s_%d" % (tag, inner), sub)
+
 
 class Stream(Chain):
     def __init__(self, *layers):
         super(Stream, self).__init__()
-        assert not hasattr(self, "layers")
         self.layers = []
-        if len(layers) > 0:
+        if layers:
             self.layer(*layers)
 
     def layer(self, *layers):
-        with self.init_scope():
-            for i, layer in enumerate(layers):
-                index = i + len(self.layers)
-                if isinstance(layer, Link):
-                    setattr(self, "layer_%d" % index, layer)
-                if isinstance(layer, GLU):
-                    setattr(self, "layer_%d" % index, layer.W)
-                if isinstance(layer, Residual):
-                    for _index, _layer in enumerate(layer.layers):
-                        if isinstance(_layer, Link):
-                            setattr(self, "layer_{}_{}".format(index, _index), _layer)
+        _register_layers(self, "layer_", len(self.layers), layers, glu_weight=True)
         self.layers += layers
 
     def __call__(self, x):
@@ -323,24 +246,14 @@ class Stream(Chain):
 class Module(Chain):
     def __init__(self, *layers):
         super(Module, self).__init__()
-        self.layers = []
-        self.blocks = []
-        self._links = []
-        self._submodules = []
+        self.layers, self.blocks = [], []
+        self._links, self._submodules = [], []
         self._locked = False
-        if len(layers) > 0:
+        if layers:
             self.add(*layers)
 
     def add(self, *layers):
-        with self.init_scope():
-            for i, layer in enumerate(layers):
-                index = i + len(self.layers)
-                if isinstance(layer, Link):
-                    setattr(self, "_sequential_%d" % index, layer)
-                if isinstance(layer, Residual):
-                    for _index, _layer in enumerate(layer.layers):
-                        if isinstance(_layer, Link):
-                            setattr(self, "_sequential_{}_{}".format(index, _index), _layer)
+        _register_layers(self, "_sequential_", len(self.layers), layers)
         self.layers += layers
         self.blocks.append(layers)
 
