@@ -270,6 +270,37 @@ def g_minibatch(vocab):
         json.dump(dict(sentences=sents, token_ids=ids), f, ensure_ascii=False, indent=1)
 
 
+def g_buckets():
+    """asr/data/readers/buckets.py:26-209 on the synthetic corpus of bucket_fixture.py: the seeded train / dev split, the
+    iteration counts and a few sampled minibatches (identified by signal length and sentence)."""
+    import json
+    import tempfile
+    sys.path.insert(0, OUT)
+    import bucket_fixture
+    sys.modules["refasr.data.readers"] = types.ModuleType("refasr.data.readers")
+    sys.modules["refasr.data.readers"].__path__ = [os.path.join(REF, "asr/data/readers")]
+    spec = importlib.util.spec_from_file_location("refasr.data.readers.buckets", os.path.join(REF, "asr/data/readers/buckets.py"))
+    rb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rb)
+    with tempfile.TemporaryDirectory() as root:
+        bucket_fixture.build(root)
+        reader = rb.Reader(root, buckets_limit=None, buckets_cache_size=2, dev_split=0.25, seed=3)
+        out = dict(train=[[list(map(int, ix)) for ix in pieces] for pieces in reader.buckets_indices_train],
+                   dev=[[list(map(int, ix)) for ix in pieces] for pieces in reader.buckets_indices_dev],
+                   distribution=[float(v) for v in reader.bucket_distribution],
+                   train_iterations=reader.calculate_total_training_iterations_with_batchsizes([3, 4, 2]),
+                   dev_iterations=reader.calculate_total_dev_iterations_with_batchsizes([3, 4, 2]))
+        np.random.seed(5)
+        samples = []
+        for _ in range(6):
+            batch, b, p = reader.sample_minibatch([3, 4, 2])
+            samples.append(dict(bucket=int(b), piece=int(p), items=[[int(len(sig)), sent] for sig, sent in batch]))
+        out["samples"] = samples
+        out["statistics"] = reader.get_statistics()
+    with open(os.path.join(OUT, "buckets.json"), "w") as f:
+        json.dump(out, f, ensure_ascii=False, indent=1)
+
+
 def g_stats():
     """asr/data/loaders/base.py:64-80,39-41 -- executed from the reference file with its package imports stubbed."""
     for n in ("asr", "asr.data", "asr.data.readers", "asr.data.readers.buckets", "asr.data.processing", "asr.utils",
@@ -321,6 +352,7 @@ def main():
     sys.modules["refasr.data"].__path__ = [os.path.join(REF, "asr/data")]
     sys.modules["refasr.fft"] = fft
     g_minibatch(vocab)
+    g_buckets()
     g_stats()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

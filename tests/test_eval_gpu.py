@@ -284,3 +284,32 @@ def test_device_prefetcher(device):
     for g, w in zip(got, want):
         for a, b in zip(g, w):
             assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_bucket_loader_end_to_end(device, tmp_path):
+    """asr/data/loaders/buckets.py: disk -> Reader -> Processor (GPU) -> minibatch tensors; the dev iterator yields every
+    development utterance exactly once, in chunks of batchsizes[bucket]"""
+    import sys
+    sys.path.insert(0, GOLD)
+    import bucket_fixture
+    from asr import vocab
+    from asr.data.loaders.buckets import Loader
+    root = bucket_fixture.build(str(tmp_path))
+    ids, _ = vocab.get_unigram_ids()
+    ld = Loader(root, batchsizes_train=[3, 4, 2], batchsizes_dev=[2, 2, 2], vocab_token_to_id=ids, dev_split=0.25, seed=3)
+    assert ld.get_num_buckets() == 3 and ld.get_total_training_iterations() == 14 and ld.get_total_dev_iterations() == 6
+    np.random.seed(5)
+    x, xl, t, tl, bg, bucket = ld.sample_minibatch()
+    assert x.is_cuda and x.dtype == torch.float32 and x.shape[1:3] == (3, 40) and x.shape[0] == len(xl) == t.shape[0] == 3
+    assert bucket == 0 and int(xl.max()) == x.shape[3] and (tl > 0).all()
+    seen = 0
+    for x, xl, t, tl, bg, bucket in ld.get_development_batch_iterator([2, 2, 2]):
+        assert x.shape[0] <= 2 and x.shape[0] == t.shape[0]
+        seen += x.shape[0]
+    assert seen == sum(len(ix) for pieces in ld.reader.buckets_indices_dev for ix in pieces) == 8
+    it = ld.get_training_batch_iterator([3, 4, 2])
+    assert it.get_total_iterations() == 14 and len(next(it)) == 6
+    # statistics switch on once initialised: the minibatch is then normalised by the running mean / std
+    ld._update_stats_batch(x, [int(v) for v in xl])
+    x2, *_ = ld.sample_minibatch()
+    assert ld.stats_total > 0 and torch.isfinite(x2).all()

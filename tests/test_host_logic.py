@@ -169,3 +169,34 @@ def test_build_model_architectures(arch):
     cfg.architecture = "unknown"
     with pytest.raises(NotImplementedError):
         build_model(cfg)
+
+
+def test_bucket_reader_matches_reference(tmp_path):
+    """asr/data/readers/buckets.py: the seeded train / dev split, iteration counts and sampled minibatches equal the
+    reference Reader's on the same synthetic corpus (tests/golden/buckets.json, made by make_golden.py)."""
+    import json
+    import os
+    import sys
+    import numpy as np
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold_dir)
+    import bucket_fixture
+    from asr.data.readers.buckets import Reader
+    with open(os.path.join(gold_dir, "buckets.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    root = bucket_fixture.build(str(tmp_path))
+    reader = Reader(root, buckets_limit=None, buckets_cache_size=2, dev_split=0.25, seed=3)
+    assert [[list(map(int, ix)) for ix in pieces] for pieces in reader.buckets_indices_train] == g["train"]
+    assert [[list(map(int, ix)) for ix in pieces] for pieces in reader.buckets_indices_dev] == g["dev"]
+    np.testing.assert_allclose(reader.bucket_distribution, g["distribution"])
+    assert reader.calculate_total_training_iterations_with_batchsizes([3, 4, 2]) == g["train_iterations"]
+    assert reader.calculate_total_dev_iterations_with_batchsizes([3, 4, 2]) == g["dev_iterations"]
+    assert reader.get_num_buckets() == 3 and reader.buckets_num_data == [[7, 4], [12], [5, 9, 3]]
+    np.random.seed(5)
+    for want in g["samples"]:
+        batch, b, p = reader.sample_minibatch([3, 4, 2])
+        assert (int(b), int(p)) == (want["bucket"], want["piece"])
+        assert [[int(len(sig)), sent] for sig, sent in batch] == want["items"]
+    assert reader.get_statistics() == g["statistics"]
+    limited = Reader(root, buckets_limit=2, dev_split=0.25, seed=3)
+    assert limited.get_num_buckets() == 2
