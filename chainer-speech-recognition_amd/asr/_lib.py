@@ -44,6 +44,7 @@ SIGNATURES = {
     "asr_conv_weight_pack_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    "asr_cast_bf16_many": (c_int, [c_void_p, c_void_p, c_int, c_longlong]),
     "asr_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong]),
     "asr_permute4": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 4 + [c_longlong] * 4),
     "asr_im2col": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 10 + [c_void_p]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "asr_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_int]),
     "asr_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 3 + [c_void_p, c_int, c_void_p, c_void_p,
                                   c_longlong, c_int, c_int]),
+    "asr_layernorm_bwd_rows_ws_bytes": (c_longlong, [c_longlong, c_int]),
+    "asr_layernorm_bwd_rows": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_longlong]),
     "asr_weightnorm_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int]),
     "asr_weightnorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int]),
     "asr_channel_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),

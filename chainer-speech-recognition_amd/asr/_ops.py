@@ -215,12 +215,23 @@ def layernorm_fwd(x, gamma, beta, C, out_dtype):
 
 
 def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None, need_dx=True):
+    """dx (of dx_dtype) and dgamma += / dbeta +=.  float32 x and dy (the logits path) take the one-sweep kernel
+    (asr_layernorm_bwd_rows: dx and the column sums in one pass), everything else asr_layernorm_bwd."""
     rows, D = x.shape
     dy = dy.contiguous()
     dx = torch.empty((rows, D), dtype=dx_dtype, device=x.device) if need_dx else None
-    rc = _lib.lib().asr_layernorm_bwd(stream(), ptr(x), _is_bf16(x), ptr(dy), _is_bf16(dy), ptr(gamma), ptr(mean),
-                                      ptr(rstd), ptr(dx), _is_bf16(dx) if need_dx else 0, ptr(dgamma), ptr(dbeta),
-                                      rows, D, C)
+    lib = _lib.lib()
+    if x.dtype == F32 and dy.dtype == F32 and C % 4 == 0:
+        nbytes = lib.asr_layernorm_bwd_rows_ws_bytes(rows, D)
+        if nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if dgamma is not None else None
+            rc = lib.asr_layernorm_bwd_rows(stream(), ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                            _is_bf16(dx) if need_dx else 0, ptr(dgamma), ptr(dbeta), rows, D, C, ptr(ws), nbytes)
+            check(rc, "asr_layernorm_bwd_rows")
+            return dx
+    rc = lib.asr_layernorm_bwd(stream(), ptr(x), _is_bf16(x), ptr(dy), _is_bf16(dy), ptr(gamma), ptr(mean),
+                               ptr(rstd), ptr(dx), _is_bf16(dx) if need_dx else 0, ptr(dgamma), ptr(dbeta),
+                               rows, D, C)
     check(rc, "asr_layernorm_bwd")
     return dx
 

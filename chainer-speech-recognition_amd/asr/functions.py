@@ -65,6 +65,75 @@ class _OnSide(object):
         return False
 
 
+# ---------------------------------------------------------------------------------------------- bf16 gradient hand-over
+# A layer that writes float32 output (the logit projection) wants its incoming gradient in bf16, but autograd insists
+# on a float32 gradient for a float32 tensor -- a 384 MB write plus a cast pass on the logits.  Such a producer hangs a
+# mailbox on its graph node; a consumer that finds it (through pure view nodes) posts its bf16 gradient there and hands
+# autograd an all-zero stride-0 token instead.  The producer adds mailbox + whatever autograd delivered, so the result is
+# right with any number of consumers; with the usual single consumer the token is recognised and nothing is added.
+class _GradMailbox(object):
+    __slots__ = ("ptr", "numel", "value")
+
+    def __init__(self, y):
+        self.ptr, self.numel, self.value = y.data_ptr(), y.numel(), None
+
+    def post(self, g):
+        self.value = g if self.value is None else _ops.add_bf16(self.value, g.reshape(self.value.shape))
+
+    def take(self):
+        v, self.value = self.value, None
+        return v
+
+
+_ZERO = {}
+_VIEW_NODES = ("ViewBackward", "ReshapeAliasBackward", "UnsafeViewBackward", "PermuteBackward", "TransposeBackward",
+               "SqueezeBackward", "UnsqueezeBackward", "AliasBackward")
+
+
+def _zero_token(shape, device):
+    z = _ZERO.get(device)
+    if z is None:
+        z = _ZERO[device] = torch.zeros(1, dtype=F32, device=device)
+    return z.reshape((1,) * len(shape)).expand(shape)
+
+
+def _is_zero_token(t):
+    z = _ZERO.get(t.device)
+    return z is not None and t.data_ptr() == z.data_ptr()
+
+
+def _producer_mailbox(x2):
+    """the mailbox of the node that produced the buffer `x2` is a contiguous re-view of, or None"""
+    if x2.dtype != F32 or not x2.is_contiguous():
+        return None
+    node = x2.grad_fn
+    for _ in range(8):
+        if node is None:
+            return None
+        box = getattr(node, "_asr_mailbox", None)
+        if box is not None:
+            return box if (box.ptr == x2.data_ptr() and box.numel == x2.numel()) else None
+        if not type(node).__name__.startswith(_VIEW_NODES) or len(node.next_functions) != 1:
+            return None
+        node = node.next_functions[0][0]
+    return None
+
+
+def _incoming_bf16(ctx, gy, width):
+    """the gradient of a producer's output as contiguous bf16 rows (-1, width): autograd's part + the mailbox's"""
+    box = getattr(ctx, "_asr_mailbox", None)
+    extra = box.take() if box is not None else None
+    if extra is not None and _is_zero_token(gy):
+        return extra.reshape(-1, width)
+    gy = gy.contiguous()
+    if gy.dtype != BF16:
+        gy = _ops.cast_bf16(gy.reshape(-1, width))
+    gy = gy.reshape(-1, width)
+    if extra is not None:
+        gy = _ops.add_bf16(gy, extra.reshape(-1, width))
+    return gy
+
+
 # ---------------------------------------------------------------------------------------------- layout helpers
 class _ToPhys(torch.autograd.Function):
     """any strided f32/bf16 tensor (logical order given by `perm`) -> contiguous bf16 in physical order."""
@@ -152,6 +221,8 @@ class _Conv2D(torch.autograd.Function):
             ctx.save_for_backward(x, w16t, wbwd)
             ctx.params = (W, b)
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, False, 2)
+            if out_f32:
+                ctx._asr_mailbox = _GradMailbox(y)
             return y.reshape(Tout, B, Hout, Co)
         # implicit GEMM (asr_conv_nt): no column matrix when the input is already physical bf16 and every 16-B chunk of a
         # virtual im2col row stays inside one tap
@@ -163,6 +234,8 @@ class _Conv2D(torch.autograd.Function):
             ctx.save_for_backward(xphys, w16t, wbwd)
             ctx.params = (W, b)
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, ctx.needs_input_grad[0], True)
+            if out_f32:
+                ctx._asr_mailbox = _GradMailbox(y)
             return y.reshape(Tout, B, Hout, Co)
         if pointwise:
             xp = x.permute(3, 0, 2, 1)
@@ -178,6 +251,8 @@ class _Conv2D(torch.autograd.Function):
         ctx.save_for_backward(col, w16t, wbwd)
         ctx.params = (W, b)
         ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, x.dtype, ctx.needs_input_grad[0], False)
+        if out_f32:
+            ctx._asr_mailbox = _GradMailbox(y)
         return y.reshape(Tout, B, Hout, Co)
 
     @staticmethod
@@ -185,9 +260,7 @@ class _Conv2D(torch.autograd.Function):
         col, w16t, wbwd = ctx.saved_tensors
         W, b = ctx.params
         B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx, implicit = ctx.meta
-        gy = gy.contiguous()
-        if gy.dtype != BF16:
-            gy = _ops.cast_bf16(gy.reshape(-1, Co))
+        gy = _incoming_bf16(ctx, gy, Co)
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
         xphys = col if implicit else None        # the implicit forward saved the input, not a column matrix
@@ -296,15 +369,15 @@ class _Dense(torch.autograd.Function):
         ctx.save_for_backward(x2, w16t)
         ctx.params = (W, b)
         ctx.need_dx = ctx.needs_input_grad[0]
+        if out_f32:
+            ctx._asr_mailbox = _GradMailbox(y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x2, w16t = ctx.saved_tensors
         W, b = ctx.params
-        gy = gy.contiguous()
-        if gy.dtype != BF16:
-            gy = _ops.cast_bf16(gy)
+        gy = _incoming_bf16(ctx, gy, W.shape[0])
         gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         gW = grad_buffer(W).reshape(W.shape[0], -1)
         gb = grad_buffer(b) if b is not None else None
@@ -316,8 +389,8 @@ class _Dense(torch.autograd.Function):
 
 
 def dense(x2, W, b, link, out_f32=False):
-    w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1)))
-    w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1), transpose=True))
+    w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1)), "plain")
+    w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w.reshape(w.shape[0], -1), transpose=True), "t_first")
     return _Dense.apply(x2, W, b, w16, w16t, bool(out_f32))
 
 
@@ -493,21 +566,25 @@ def add(a, b):
 # ---------------------------------------------------------------------------------------------- layer normalisation
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, gamma, beta, C, out_f32):
+    def forward(ctx, x2, gamma, beta, C, out_f32, mailbox):
         y, mean, rstd = _ops.layernorm_fwd(x2, gamma.detach(), beta.detach(), C, F32 if out_f32 else BF16)
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params = (gamma, beta)
-        ctx.meta = (C, ctx.needs_input_grad[0])
+        ctx.meta = (C, ctx.needs_input_grad[0], mailbox)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
-        C, need_dx = ctx.meta
-        dx = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, x2.dtype, grad_buffer(gamma),
-                                grad_buffer(beta), need_dx)
-        return dx, None, None, None, None
+        C, need_dx, mailbox = ctx.meta
+        handover = mailbox is not None and need_dx      # the producer of x2 takes its gradient in bf16
+        dx = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, BF16 if handover else x2.dtype,
+                                grad_buffer(gamma), grad_buffer(beta), need_dx)
+        if handover:
+            mailbox.post(dx)
+            dx = _zero_token(x2.shape, x2.device)
+        return dx, None, None, None, None, None
 
 
 def layer_normalization(x, gamma, beta, out_f32=False):
@@ -517,7 +594,8 @@ def layer_normalization(x, gamma, beta, out_f32=False):
         if not (p.is_contiguous() and p.dtype in (BF16, F32)):
             p = phys4(x)
         T, B, H, C = p.shape
-        y = _LayerNorm.apply(p.reshape(T * B, H * C), gamma, beta, C, bool(out_f32))
+        x2 = p.reshape(T * B, H * C)
+        y = _LayerNorm.apply(x2, gamma, beta, C, bool(out_f32), _producer_mailbox(x2))
         return logical4(y.reshape(T, B, H, C))
     if x.dim() == 3:
         # (B, V, T): the reference normalises over V AND T jointly (axes 1, 2).  Physical rows are (t, b); joint
@@ -526,7 +604,7 @@ def layer_normalization(x, gamma, beta, out_f32=False):
         rows = x.permute(0, 2, 1)                # (B, T, V)
         if not (rows.is_contiguous() and rows.dtype in (BF16, F32)):
             rows = _ToPhys.apply(x, (0, 2, 1))
-        y = _LayerNorm.apply(rows.reshape(Bn, T * V), gamma, beta, V, bool(out_f32))
+        y = _LayerNorm.apply(rows.reshape(Bn, T * V), gamma, beta, V, bool(out_f32), None)
         return y.reshape(Bn, T, V).permute(0, 2, 1)
     raise ValueError("layer normalisation expects a 3-d or 4-d input")
 
@@ -636,10 +714,10 @@ def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
     T, B, I = p.shape
     H = w_hh.shape[2]
     copies = (
-        link.compute_copy("wih16", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]))),
-        link.compute_copy("wih16t", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]), transpose=True)),
-        link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape)),
-        link.compute_copy("whh16t", w_hh, _cast_transposed_per_direction),
+        link.compute_copy("wih16", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])), "plain"),
+        link.compute_copy("wih16t", w_ih, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1]), transpose=True), "t_last"),
+        link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape), "plain"),
+        link.compute_copy("whh16t", w_hh, _cast_transposed_per_direction, "t_each"),
     )
     y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir)
     return logical3(y.reshape(T, B, H))

@@ -33,6 +33,7 @@ class Link(torch.nn.Module):
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_compute_cache", {})
+        object.__setattr__(self, "_cast_registry", {})
 
     @contextlib.contextmanager
     def init_scope(self):
@@ -65,8 +66,13 @@ class Link(torch.nn.Module):
                 p.grad = None
 
     # -- compute copies ------------------------------------------------------------------------------
-    def compute_copy(self, key, param, maker):
-        """bf16 (possibly re-laid-out) copy of a parameter, rebuilt only when the parameter changed."""
+    def compute_copy(self, key, param, maker, layout=None):
+        """bf16 (possibly re-laid-out) copy of a parameter, rebuilt only when the parameter changed.
+
+        ``layout`` declares what ``maker`` does when that is a pure cast, so that ``refresh_compute_copies`` can redo
+        every such copy of a model in one launch after an optimiser step: "plain" (same element order), "t_first" /
+        "t_last" (the parameter seen as (shape[0], rest) / (rest, shape[-1]), transposed) or "t_each" (a stack of
+        matrices, each transposed)."""
         stamp = (_WEIGHT_EPOCH[0], param._version, param.data_ptr())
         hit = self._compute_cache.get(key)
         if hit is not None and hit[0] == stamp:
@@ -74,7 +80,58 @@ class Link(torch.nn.Module):
         with torch.no_grad():
             value = maker(param.detach())
         self._compute_cache[key] = (stamp, value)
+        if layout is not None and value.is_cuda:
+            self._cast_registry[key] = (param, value, _cast_jobs(param, layout))
         return value
+
+
+def _cast_jobs(param, layout):
+    """(source offset, destination offset, rows, cols, transpose) in elements, one per matrix"""
+    n, shape = param.numel(), tuple(param.shape)
+    if layout == "plain":
+        return ((0, 0, n // shape[-1], shape[-1], 0),)
+    if layout == "t_first":
+        return ((0, 0, shape[0], n // shape[0], 1),)
+    if layout == "t_last":
+        return ((0, 0, n // shape[-1], shape[-1], 1),)
+    if layout == "t_each":
+        each = shape[-2] * shape[-1]
+        return tuple((i * each, i * each, shape[-2], shape[-1], 1) for i in range(n // each))
+    raise ValueError(layout)
+
+
+def refresh_compute_copies(model):
+    """Redo, in place and with ONE launch, the registered bf16 copies of every parameter of ``model`` (the optimisers call
+    this right after their update kernel; without it each copy is rebuilt by its own small launch in front of the GEMM
+    that needs it).  Copies whose parameter moved since they were made are left to the lazy path."""
+    from . import _lib
+    todo, sig = [], []
+    for m in model.modules():
+        reg = getattr(m, "_cast_registry", None)
+        if not reg:
+            continue
+        for key, (param, out, jobs) in reg.items():
+            hit = m._compute_cache.get(key)
+            if hit is None or hit[1] is not out or hit[0][2] != param.data_ptr() or not param.is_cuda:
+                continue
+            todo.append((m, key, param, out))
+            sig.append((param.data_ptr(), out.data_ptr(), jobs))
+    if not todo:
+        return 0
+    cached = getattr(model, "_cast_table", None)
+    if cached is None or cached[0] != sig:
+        rows, tile = [], 0
+        for src, dst, jobs in sig:
+            for so, do, r, c, t in jobs:
+                rows.append([src + 4 * so, dst + 2 * do, r, c, t, tile])
+                tile += ((r + 63) // 64) * ((c + 63) // 64)
+        table = torch.tensor(rows, dtype=torch.int64).to(todo[0][2].device)
+        cached = (sig, table, len(rows), tile)
+        object.__setattr__(model, "_cast_table", cached)
+    _lib.check(_lib.lib().asr_cast_bf16_many(_lib.stream(), _lib.ptr(cached[1]), cached[2], cached[3]), "asr_cast_bf16_many")
+    for m, key, param, out in todo:
+        m._compute_cache[key] = ((_WEIGHT_EPOCH[0], param._version, param.data_ptr()), out)
+    return cached[2]
 
 
 class Chain(Link):

@@ -23,10 +23,14 @@ def _as_tbv(xs):
         return xs
     if not isinstance(xs, (list, tuple)) or len(xs) == 0:
         raise TypeError("xs must be a list of Variables")       # asr/loss/gram_ctc.py:301-302
+    whole = getattr(xs, "buffer", None)         # asr.model TimeSteps: the views' (T, B, V) buffer
+    if whole is not None and whole.dim() == 3 and whole.shape[0] == len(xs):
+        return whole
     base = getattr(xs[0], "_base", None)
-    if base is not None and base.dim() == 3 and base.shape[0] == len(xs) and base.shape[1:] == xs[0].shape \
-            and xs[0].data_ptr() == base.data_ptr() and xs[-1].data_ptr() == base[-1].data_ptr():
-        return base
+    if base is not None and base.is_contiguous() and base.numel() == len(xs) * xs[0].numel() and xs[0].is_contiguous() \
+            and xs[0].data_ptr() == base.data_ptr() \
+            and xs[-1].data_ptr() == base.data_ptr() + (len(xs) - 1) * xs[0].numel() * base.element_size():
+        return base.view((len(xs),) + tuple(xs[0].shape))
     return torch.stack(list(xs), dim=0)
 
 

@@ -30,6 +30,16 @@ def mark_logit_layers(layers):
             prev = layer
 
 
+class TimeSteps(tuple):
+    """the reference's tuple of T (B, V) Variables, as views of ONE (T, B, V) buffer that the losses pick up without a
+    copy (``.buffer``); indexing, len() and iteration behave like the plain tuple"""
+
+    def __new__(cls, tbv):
+        self = super(TimeSteps, cls).__new__(cls, tbv.unbind(0))
+        self.buffer = tbv
+        return self
+
+
 def split_output(out_data, batchsize, seq_length, split_into_variables):
     """out_data logical (B, V, 1, T) [or (B, V, T)] backed by a (T, B, 1, V) / (T, B, V) buffer."""
     if out_data.dim() == 4:
@@ -39,7 +49,7 @@ def split_output(out_data, batchsize, seq_length, split_into_variables):
         assert out_data.shape[2] == seq_length
         tbv = out_data.permute(2, 0, 1)
     if split_into_variables:
-        return tuple(tbv.unbind(0))                           # T views (B, V): swapaxes/reshape/split_axis of the reference
+        return TimeSteps(tbv)                                 # T views (B, V): swapaxes/reshape/split_axis of the reference
     return tbv.permute(1, 0, 2)                               # (B, T, V)
 
 

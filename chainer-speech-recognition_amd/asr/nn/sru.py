@@ -50,8 +50,8 @@ def sru(x, W, B, initial_ct, use_tanh=True, mask_x=None, link=None):
     """x (B, D, T) -> (H (B, D, T), C (B, D, T), c_T (B, D))   (asr/nn/sru.py:435-439)."""
     link = link if link is not None else _DEFAULT_LINK
     p = functions.phys3(x)
-    w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w))
-    w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w, transpose=True))
+    w16 = link.compute_copy("w16", W, lambda w: _ops.cast_bf16(w), "plain")
+    w16t = link.compute_copy("w16t", W, lambda w: _ops.cast_bf16(w, transpose=True), "t_first")
     H, C, cT = SRUFunction.apply(p, W, B, initial_ct, mask_x, w16, w16t, bool(use_tanh))
     return functions.logical3(H), functions.logical3(C), cT
 

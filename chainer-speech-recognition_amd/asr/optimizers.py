@@ -11,7 +11,7 @@ RCCL calls over contiguous slices.
 import torch
 
 from . import _ops
-from .link import bump_weight_epoch
+from .link import bump_weight_epoch, refresh_compute_copies
 
 F32 = torch.float32
 
@@ -85,6 +85,7 @@ class Optimizer(object):
         _ops.sqnorm_acc(G, sq)
         self._step(P, G, clip, decay, scale, sq)
         bump_weight_epoch()
+        refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
 
     # -- flat buffers ------------------------------------------------------------------------------
     def _params(self):

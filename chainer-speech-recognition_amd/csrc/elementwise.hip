@@ -52,6 +52,62 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* _
         if (c < cols && r < rows) dst[(size_t)c * rows + r] = f32_to_bf16(tile[tx][i]);
     }
 }
+// All bf16 weight copies of a model in ONE launch (they are rebuilt after every optimiser step: 27 launches of ~6 us
+// each in front of the GEMMs otherwise).  jobs: njobs x 6 long long {src, dst, rows, cols, transpose, first_tile},
+// first_tile ascending; a tile is 64 x 64 elements of src.
+__global__ void __launch_bounds__(256) cast_many_kernel(const long long* __restrict__ jobs, int njobs) {
+    __shared__ float tile[64][65];
+    int j = 0;
+    while (j + 1 < njobs && (long long)blockIdx.x >= jobs[(j + 1) * 6 + 5]) ++j;
+    const float* __restrict__ src = (const float*)jobs[j * 6 + 0];
+    uint16_t* __restrict__ dst = (uint16_t*)jobs[j * 6 + 1];
+    const int rows = (int)jobs[j * 6 + 2], cols = (int)jobs[j * 6 + 3];
+    const bool transpose = jobs[j * 6 + 4] != 0;
+    const int local = (int)((long long)blockIdx.x - jobs[j * 6 + 5]);
+    const int tiles_c = (cols + 63) / 64;
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 x 16 threads, 4 columns each, 4 row passes
+    const bool vec = (cols & 3) == 0;
+    if (!transpose) {
+        for (int i = ty; i < 64; i += 16) {
+            const int r = r0 + i, c = c0 + tx * 4;
+            if (r >= rows || c >= cols) continue;
+            if (vec) {
+                const float4 v = *(const float4*)(src + (size_t)r * cols + c);
+                uint2 o;
+                o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+                o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+                *(uint2*)(dst + (size_t)r * cols + c) = o;
+            } else {
+                for (int k = 0; k < 4 && c + k < cols; ++k) dst[(size_t)r * cols + c + k] = f32_to_bf16(src[(size_t)r * cols + c + k]);
+            }
+        }
+        return;
+    }
+    for (int i = ty; i < 64; i += 16) {
+        const int r = r0 + i, c = c0 + tx * 4;
+        if (vec && r < rows && c < cols) {
+            const float4 v = *(const float4*)(src + (size_t)r * cols + c);
+            tile[i][tx * 4 + 0] = v.x; tile[i][tx * 4 + 1] = v.y; tile[i][tx * 4 + 2] = v.z; tile[i][tx * 4 + 3] = v.w;
+        } else {
+            for (int k = 0; k < 4; ++k) tile[i][tx * 4 + k] = (r < rows && c + k < cols) ? src[(size_t)r * cols + c + k] : 0.f;
+        }
+    }
+    __syncthreads();
+    const bool vecr = (rows & 3) == 0;
+    for (int i = ty; i < 64; i += 16) {       // dst row = source column c0 + i; 4 consecutive source rows per thread
+        const int c = c0 + i, r = r0 + tx * 4;
+        if (c >= cols || r >= rows) continue;
+        if (vecr) {
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16(tile[tx * 4 + 0][i]) | ((unsigned)f32_to_bf16(tile[tx * 4 + 1][i]) << 16);
+            o.y = (unsigned)f32_to_bf16(tile[tx * 4 + 2][i]) | ((unsigned)f32_to_bf16(tile[tx * 4 + 3][i]) << 16);
+            *(uint2*)(dst + (size_t)c * rows + r) = o;
+        } else {
+            for (int k = 0; k < 4 && r + k < rows; ++k) dst[(size_t)c * rows + r + k] = f32_to_bf16(tile[tx * 4 + k][i]);
+        }
+    }
+}
 __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = bf16_to_f32(src[i]);
@@ -573,6 +629,13 @@ extern "C" int asr_cast_bf16(void* stream, const float* src, void* dst, int rows
         hipLaunchKernelGGL(transpose_cast_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, src,
                            (uint16_t*)dst, rows, cols);
     }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_cast_bf16_many(void* stream, const long long* jobs_dev, int njobs, long long total_tiles) {
+    if (!jobs_dev || njobs <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cast_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

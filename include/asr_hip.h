@@ -117,6 +117,9 @@ int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb
 /* ---------------------------------------------------------------------------------------- layout / activations
  * Internal activations are (T, B, H, C) bf16 (time-major, channel-last); see DESIGN.md "Data layout in HBM".
  *   asr_cast_bf16     f32 (rows, cols) -> bf16, optionally transposed to (cols, rows)    [weight copies]
+ *   asr_cast_bf16_many  the same for a table of matrices in one launch: jobs_dev = njobs x 6 long long in device
+ *                     memory {src, dst, rows, cols, transpose, first_tile}; a tile is 64x64 elements of src, tiles are
+ *                     numbered job after job, total_tiles = their sum  [all weight copies after an optimiser step]
  *   asr_permute4      dense dst (d0,d1,d2,d3) <- strided src (element strides s0..s3), f32/bf16 either side
  *   asr_im2col        col[(t,b,ho)][(kh,kw,ci)] (row pitch Kp, zero padded) from x with element strides
  *                     (sT,sB,sH,sC); reads x[t+kw-pad_t, b, ho+kh-pad_h, ci] for t in [0, Tout).  pad_t = KW-1 with
@@ -129,6 +132,7 @@ int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb
  *   asr_colsum_acc    out[c] += sum_r x[r][c]   (bias gradients)
  */
 int asr_cast_bf16(void* stream, const float* src, void* dst, int rows, int cols, int transpose);
+int asr_cast_bf16_many(void* stream, const long long* jobs_dev, int njobs, long long total_tiles);
 int asr_bf16_to_f32(void* stream, const void* src, float* dst, long long n);
 int asr_permute4(void* stream, const void* src, int src_bf16, void* dst, int dst_bf16, int d0, int d1, int d2, int d3,
                  long long s0, long long s1, long long s2, long long s3);
@@ -178,6 +182,14 @@ int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* y, int y_bf
 int asr_layernorm_bwd(void* stream, const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma,
                       const float* mean, const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta,
                       long long rows, int D, int C);
+/* one-sweep backward of the float32 logits normalisation (x and dy float32, D % 4 == 0, C % 4 == 0, D <= 4096; other
+ * shapes: ASR_ERR_UNSUPPORTED, use asr_layernorm_bwd): dx (bf16 or f32, may be NULL) and dgamma += / dbeta += (both or
+ * neither) in one pass over x and dy; ws: asr_layernorm_bwd_rows_ws_bytes(rows, D) bytes of scratch for the per-workgroup
+ * column sums (0 = shape not supported).  Same formulas as asr_layernorm_bwd (asr/nn/layernorm.py:50-61). */
+long long asr_layernorm_bwd_rows_ws_bytes(long long rows, int D);
+int asr_layernorm_bwd_rows(void* stream, const float* x, const float* dy, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta, long long rows, int D,
+                           int C, void* ws, long long ws_bytes);
 
 /* weight normalisation of asr/nn/convolution_2d.py: W = g V / (||V|| + 1e-9) per output channel (:21-25,62-64), its
  * gradient (:92-93, accumulated into gV / gg), and the data-dependent initialisation g = 1/std_t, b = -mean_t/std_t

@@ -113,6 +113,23 @@ def test_views_cost_nothing_and_keep_reference_semantics():
     assert merged.shape == (2, 12, 5) and merged.data_ptr() == phys.data_ptr()       # no copy
 
 
+def test_logit_time_steps_reach_the_loss_without_a_copy():
+    """asr/model/cnn.py:41-49 hands T Variables (B, V) to the loss; here they are views of one buffer and the loss must
+    find that buffer again (a torch.stack of 1000 views costs 0.4 ms per train step)"""
+    from asr.model._acoustic import split_output, TimeSteps
+    from asr.loss.ctc import _as_tbv
+    phys = torch.randn(7, 2, 1, 5, requires_grad=True) * 1.0          # (T, B, 1, V) buffer of the last layer
+    steps = split_output(phys.permute(1, 3, 2, 0), 2, 7, True)         # logical (B, V, 1, T)
+    assert isinstance(steps, (tuple, TimeSteps)) and len(steps) == 7 and steps[3].shape == (2, 5)
+    assert torch.equal(steps[3], phys[3, :, 0])
+    assert _as_tbv(steps).data_ptr() == phys.data_ptr() and _as_tbv(steps).shape == (7, 2, 5)
+    plain = tuple(steps)                                               # a user re-wrapping the tuple: still no copy
+    assert _as_tbv(plain).data_ptr() == phys.data_ptr()
+    foreign = [torch.randn(2, 5) for _ in range(7)]                    # the reference's own list of arrays: stacked
+    assert _as_tbv(foreign).shape == (7, 2, 5)
+    assert torch.equal(_as_tbv(foreign)[4], foreign[4])
+
+
 def test_ctc_argument_checks_match_reference():
     """asr/loss/gram_ctc.py:224-227,301-308"""
     from asr.loss import connectionist_temporal_classification, gram_ctc

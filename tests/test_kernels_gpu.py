@@ -178,6 +178,42 @@ def test_layernorm(device, B, C, H, T):
     np.testing.assert_allclose(dbeta.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("rows,D,C", [(20000, 120, 120), (700, 3000, 3000), (33, 4096, 1024), (257, 1028, 4), (1, 8, 8)])
+def test_layernorm_one_sweep_backward(device, rows, D, C):
+    """asr_layernorm_bwd_rows (dx + column sums in one pass, many rows per workgroup) against the float64 oracle and,
+    for the bf16 output, against the rounded float32 output; also dx only / parameter gradients only"""
+    from asr import _ops, _lib
+    assert _lib.lib().asr_layernorm_bwd_rows_ws_bytes(rows, D) > 0
+    rs = np.random.RandomState(rows + D)
+    H = D // C
+    x = rs.uniform(-10, 10, (rows, H, C)).astype(np.float32)
+    gy = rs.uniform(-1, 1, (rows, H, C)).astype(np.float32)
+    gamma = rs.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rs.uniform(-1, 1, C).astype(np.float32)
+    # oracle layout: (B, C, H, T) with B = rows, T = 1
+    x_o, gy_o = x.transpose(0, 2, 1)[..., None].astype(np.float64), gy.transpose(0, 2, 1)[..., None].astype(np.float64)
+    _, cache = onn.layer_normalization(x_o, gamma.astype(np.float64), beta.astype(np.float64))
+    dx_ref, dg_ref, db_ref = onn.layer_normalization_bwd(gy_o, gamma.astype(np.float64), cache)
+    dx_ref = dx_ref[..., 0].transpose(0, 2, 1).reshape(rows, D)
+    xd, gyd = torch.tensor(x).reshape(rows, D).to(device), torch.tensor(gy).reshape(rows, D).to(device)
+    gd, bd = torch.tensor(gamma).to(device), torch.tensor(beta).to(device)
+    _, mean, rstd = _ops.layernorm_fwd(xd, gd, bd, C, F32)
+    dgamma, dbeta = torch.zeros(C, device=device), torch.zeros(C, device=device)
+    dx = _ops.layernorm_bwd(xd, gyd, gd, mean, rstd, C, F32, dgamma, dbeta)
+    np.testing.assert_allclose(dx.cpu().numpy(), dx_ref, rtol=1e-4, atol=1e-5)
+    scale = max(1.0, float(np.sqrt(rows * H)))
+    np.testing.assert_allclose(dgamma.cpu().numpy(), dg_ref, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-5 * scale)
+    dx16 = _ops.layernorm_bwd(xd, gyd, gd, mean, rstd, C, BF16, None, None)        # dx only, bf16
+    # (the two instantiations contract their multiply-adds differently: equal up to one bf16 rounding step)
+    assert dx16.dtype == BF16
+    torch.testing.assert_close(dx16.float(), dx, rtol=2.0 ** -7, atol=1e-6)
+    dg2, db2 = torch.ones(C, device=device), torch.ones(C, device=device)          # parameter gradients only, accumulated
+    assert _ops.layernorm_bwd(xd, gyd, gd, mean, rstd, C, F32, dg2, db2, need_dx=False) is None
+    np.testing.assert_allclose(dg2.cpu().numpy() - 1.0, dgamma.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(db2.cpu().numpy() - 1.0, dbeta.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+
+
 # 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
 # 4: persistent with the XCD-local hand-off where placement allows (= automatic), 7: 4 with a forged split placement
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7])

@@ -156,3 +156,62 @@ def test_cnn_recipes_train_step(device, arch):
         opt.update(lossfun=lambda: loss)
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_weight_copies_refreshed_in_one_launch(device):
+    """after optimizer.update every registered bf16 weight copy (plain / transposed / per-direction transposed) equals
+    the cast of the NEW master weights, is the same tensor as before (refreshed in place by asr_cast_bf16_many) and is
+    found current by the next forward pass (no per-layer cast launches)"""
+    from asr import link as L
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import get_optimizer, GradientClipping
+    cfg, model = _build(device, V=29)
+    x, labels, x_len, l_len = omodel.synthetic_batch(3, 40, 29, Lmin=3, Lmax=8, seed=5)
+    args = (labels.to(device), 0, x_len.to(device), l_len.to(device))
+    opt = get_optimizer("adam", 1e-2, 0.9)
+    model(x.to(device))
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    # 1st update: the optimiser moves the parameters into its flat buffer (copies made before that are dropped);
+    # 2nd update: copies made lazily from the flat buffer and registered
+    for _ in range(2):
+        opt.update(lossfun=lambda: connectionist_temporal_classification(model(x.to(device)), *args))
+    before = {(id(m), k): v[1] for m in model.modules() for k, v in getattr(m, "_cast_registry", {}).items()}
+    assert len(before) >= 6
+    masters = {(id(m), k): v[0].detach().clone() for m in model.modules() for k, v in getattr(m, "_cast_registry", {}).items()}
+    opt.update(lossfun=lambda: connectionist_temporal_classification(model(x.to(device)), *args))
+    assert getattr(model, "_cast_table", None) is not None and model._cast_table[2] >= len(before)
+    seen = 0
+    for m in model.modules():
+        for key, (param, out, jobs) in getattr(m, "_cast_registry", {}).items():
+            assert out is before[(id(m), key)]                         # refreshed in place
+            assert not torch.equal(param.detach(), masters[(id(m), key)])    # the step did move the weights
+            stamp, cached = m._compute_cache[key]
+            assert cached is out and stamp[0] == L._WEIGHT_EPOCH[0]    # current for the next forward pass
+            w = param.detach()
+            for so, do, r, c, t in jobs:
+                src = w.reshape(-1)[so:so + r * c].reshape(r, c)
+                want = (src.t() if t else src).contiguous().to(torch.bfloat16)
+                got = out.reshape(-1)[do:do + r * c].reshape(want.shape)
+                assert torch.equal(got, want), (key, r, c, t)
+                seen += 1
+    assert seen >= len(before)
+
+
+def test_cast_many_ragged_shapes(device):
+    """asr_cast_bf16_many on shapes that are not multiples of the 64x64 tile or of 4"""
+    from asr import _lib
+    torch.manual_seed(3)
+    shapes = [(1, 1, 0), (5, 7, 1), (64, 64, 1), (65, 130, 0), (130, 65, 1), (3, 257, 1), (200, 4, 1), (96, 1536, 0), (7, 12, 1)]
+    srcs = [torch.randn(r, c, device=device) for r, c, _ in shapes]
+    dsts = [torch.full((c, r) if t else (r, c), 7.0, dtype=torch.bfloat16, device=device) for r, c, t in shapes]
+    rows, tile = [], 0
+    for (r, c, t), s, d in zip(shapes, srcs, dsts):
+        rows.append([s.data_ptr(), d.data_ptr(), r, c, t, tile])
+        tile += ((r + 63) // 64) * ((c + 63) // 64)
+    table = torch.tensor(rows, dtype=torch.int64).to(device)
+    _lib.check(_lib.lib().asr_cast_bf16_many(_lib.stream(), _lib.ptr(table), len(rows), tile), "asr_cast_bf16_many")
+    torch.cuda.synchronize()
+    for (r, c, t), s, d in zip(shapes, srcs, dsts):
+        want = (s.t() if t else s).contiguous().to(torch.bfloat16)
+        assert torch.equal(d, want), (r, c, t)

@@ -286,3 +286,54 @@ def test_batch_normalization(device):
     y3 = bn3(x3.to(device))
     w3, _, _ = onn.batch_normalization(x3.numpy().astype(np.float64), np.ones(8), np.zeros(8), np.zeros(8), np.ones(8))
     np.testing.assert_allclose(y3.float().detach().cpu().numpy(), w3, rtol=2e-2, atol=2e-2)
+
+
+def test_bf16_gradient_handover_from_layernorm_to_projection(device):
+    """the float32 logit projection takes the LayerNormalization gradient in bf16 through its mailbox (no float32 dx, no
+    cast pass); the gradients must equal those of the plain float32 route, also when the projection's output has a
+    second consumer (autograd's part + the mailbox's part)"""
+    from asr import functions as F, nn
+    torch.manual_seed(11)
+    B, C, T, V = 3, 32, 9, 24
+    x = torch.randn(B, C, 1, T).to(device)
+    gy = torch.randn(B, V, 1, T).to(device)
+
+    def run(handover, second_consumer):
+        torch.manual_seed(5)
+        proj = nn.Convolution2D(C, V, (1, 1)).to_gpu()
+        norm = nn.LayerNormalization(V).to_gpu()
+        proj.output_float32 = True
+        norm.output_float32 = True
+        saved = F._producer_mailbox
+        posted = []
+        if not handover:
+            F._producer_mailbox = lambda x2: None
+        else:
+            def spy(x2):
+                box = saved(x2)
+                posted.append(box)
+                return box
+            F._producer_mailbox = spy
+        try:
+            xin = x.clone().requires_grad_(True)
+            h = proj(xin)
+            assert h.dtype == torch.float32
+            y = norm(h)
+            loss = (y * gy).sum()
+            if second_consumer:
+                loss = loss + (h * 0.5).sum()
+            loss.backward()
+        finally:
+            F._producer_mailbox = saved
+        if handover:
+            assert len(posted) == 1 and posted[0] is not None and posted[0].value is None     # found, used and emptied
+        return [xin.grad.float().cpu()] + [p.grad.float().cpu().clone() for p in list(proj.parameters()) + list(norm.parameters())]
+
+    for second in (False, True):
+        a, b = run(True, second), run(False, second)
+        for u, v in zip(a, b):
+            assert u.shape == v.shape
+            # both routes round dx to bf16 once (the f32 and bf16 kernels may differ in the last f32 bit before that);
+            # with a second consumer the sum is rounded once more
+            scale = float(v.abs().max()) + 1e-6
+            torch.testing.assert_close(u, v, rtol=2e-2, atol=(2e-2 if second else 4e-3) * scale)
