@@ -55,7 +55,8 @@ SIGNATURES = {
     "asr_glu_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int]),
     "asr_dropout": (c_int, [c_void_p] * 3 + [c_longlong, c_float, ctypes.c_uint]),
     "asr_conv_weight_pack": (c_int, [c_void_p] * 3 + [c_int] * 6),
-    "asr_conv_weight_grad_unpack": (c_int, [c_void_p] * 3 + [c_int] * 5),
+    "asr_conv_weight_grad_unpack": (c_int, [c_void_p] * 3 + [c_int] * 6),
+    "asr_conv_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
     "asr_maxout2_fwd": (c_int, [c_void_p] * 3 + [c_longlong]),
     "asr_maxout2_bwd": (c_int, [c_void_p] * 4 + [c_longlong]),
     "asr_maxpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),

@@ -104,11 +104,24 @@ def conv_weight_pack(W, transpose=False, Kp=None):
     return dst
 
 
-def conv_weight_grad_unpack(scratch, gW):
+def conv_weight_grad_unpack(scratch, gW, channel_pitch=0):
+    """gW (Co, Ci, KH, KW) += scratch (Co, Kp) with k = (kh, kw, c), c < channel_pitch (0: Ci)"""
     Co, Ci, KH, KW = gW.shape
     assert scratch.dtype == F32 and scratch.is_contiguous() and gW.is_contiguous()
-    check(_lib.lib().asr_conv_weight_grad_unpack(stream(), ptr(scratch), ptr(gW), Co, Ci, KH, KW, scratch.shape[1]),
-          "asr_conv_weight_grad_unpack")
+    check(_lib.lib().asr_conv_weight_grad_unpack(stream(), ptr(scratch), ptr(gW), Co, Ci, KH, KW, scratch.shape[1],
+                                                 int(channel_pitch)), "asr_conv_weight_grad_unpack")
+
+
+def conv_tn_acc(g2, x, scratch, KH, KW, pad_h, pad_t, Tr, Hr):
+    """scratch (Co, KH*KW*Cs) f32 += weight gradient of the convolution that maps x (Ts, B, Hs, Cs) bf16 to (Tr, B, Hr, Co),
+    g2 (Tr*B*Hr, Co) bf16 its output gradient: the implicit form of gemm_tn_acc(g2, im2col(x), scratch)"""
+    Ts, B, Hs, Cs = x.shape
+    Co = g2.shape[1]
+    assert x.dtype == BF16 and g2.dtype == BF16 and scratch.dtype == F32 and g2.shape[0] == Tr * B * Hr
+    assert scratch.shape == (Co, KH * KW * Cs) and scratch.is_contiguous()
+    rc = _lib.lib().asr_conv_tn_acc(stream(), ptr(g2), g2.stride(0), ptr(x), ptr(scratch), scratch.shape[1], Co, Ts, B, Hs, Cs,
+                                    KH, KW, pad_h, pad_t, Tr, Hr)
+    check(rc, "asr_conv_tn_acc")
 
 
 ACT_KINDS = {"relu": 0, "clipped_relu": 1, "leaky_relu": 2, "elu": 3, "sigmoid": 4, "tanh": 5, "hard_sigmoid": 6,

@@ -218,7 +218,7 @@ class _Conv2D(torch.autograd.Function):
             xpad = _ops.pack_input_pad(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, 8)
             y = _ops.conv_nt(xpad, w16p, b.detach() if b is not None else None, F32 if out_f32 else BF16, KH, KW, pad_h, pad_t,
                              +1, Tout, Hout)
-            ctx.save_for_backward(x, w16t, wbwd)
+            ctx.save_for_backward(xpad, w16t, wbwd)        # (T, B, H, 8) bf16: the operand of the implicit weight gradient
             ctx.params = (W, b)
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, False, 2)
             if out_f32:
@@ -284,14 +284,13 @@ class _Conv2D(torch.autograd.Function):
         gb = grad_buffer(b) if b is not None else None
 
         def weight_grads():
-            nonlocal col
-            if implicit == 2:       # first layer: the saved tensor is the logical (B, C, H, T) input
-                col = _ops.im2col(xphys, (xphys.stride(3), xphys.stride(0), xphys.stride(2), xphys.stride(1)), T, B, Hin, Ci, KH, KW,
-                                  pad_h, pad_t, Tout)
-            elif implicit:          # the column matrix is only needed here, off the critical path
-                col = _ops.im2col(xphys, (xphys.stride(0), xphys.stride(1), xphys.stride(2), xphys.stride(3)), T, B, Hin, Ci, KH, KW,
-                                  pad_h, pad_t, Tout)
-            if Kp == Kreal and KH == 1 and KW == 1:
+            if implicit:            # no column matrix here either: the virtual im2col rows are gathered by the TN kernel
+                Cs = xphys.shape[3]         # 8 for the first layer's zero-padded channels
+                scratch = torch.empty((Co, KH * KW * Cs), dtype=F32, device=gy.device)
+                _ops.fill_(scratch, 0.0)
+                _ops.conv_tn_acc(g2, xphys, scratch, KH, KW, pad_h, pad_t, Tout, Hout)
+                _ops.conv_weight_grad_unpack(scratch, gW, Cs)
+            elif Kp == Kreal and KH == 1 and KW == 1:
                 _ops.gemm_tn_acc(g2, col, gW.reshape(Co, Kreal))
             else:
                 # weights are stored (Co, Ci, kh, kw); the GEMM produces (Co, (kh, kw, ci)): accumulate through a scratch

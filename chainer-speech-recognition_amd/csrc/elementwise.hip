@@ -441,9 +441,9 @@ __global__ void conv_weight_pack_bwd_kernel(const float* __restrict__ W, uint16_
         dst[i] = f32_to_bf16(W[(((long long)co * Ci + ci) * KH + kh) * KW + kw]);
     }
 }
-// unpack: gW[co][ci][kh][kw] += scratch[co][(kh*KW + kw)*Ci + ci]
+// unpack: gW[co][ci][kh][kw] += scratch[co][(kh*KW + kw)*Cs + ci]   (Cs >= Ci: channel pitch of the scratch rows)
 __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch, float* __restrict__ gW, int Co, int Ci,
-                                               int KH, int KW, int Kp) {
+                                               int KH, int KW, int Kp, int Cs) {
     const long long n = (long long)Co * Ci * KH * KW;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         long long r = i;
@@ -451,7 +451,7 @@ __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch
         const int kh = (int)(r % KH); r /= KH;
         const int ci = (int)(r % Ci);
         const int co = (int)(r / Ci);
-        gW[i] += scratch[(long long)co * Kp + (kh * KW + kw) * Ci + ci];
+        gW[i] += scratch[(long long)co * Kp + (kh * KW + kw) * Cs + ci];
     }
 }
 
@@ -861,10 +861,11 @@ extern "C" int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst,
     return ASR_OK;
 }
 extern "C" int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW,
-                                           int Kp) {
-    if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Kp < KH * KW * Ci) return ASR_ERR_BAD_ARG;
+                                           int Kp, int Cs) {
+    if (Cs <= 0) Cs = Ci;
+    if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Cs < Ci || Kp < KH * KW * Cs) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(conv_weight_grad_unpack_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(kThreads), 0,
-                       (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp);
+                       (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp, Cs);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

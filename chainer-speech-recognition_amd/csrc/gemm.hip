@@ -439,9 +439,14 @@ __device__ __forceinline__ bf16x4 lds_tr16(const uint16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
+// CONV: operand B is the virtual im2col matrix of the activation tensor (see ConvDesc; sgn = +1): row = reduction index
+// (t, b, h) over the output positions, column = (kh, kw, c) -- the weight gradient of a convolution without a column
+// matrix in memory (1.2 GB written and read back per step for the second conv layer otherwise).
+template <bool CONV>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                       const uint16_t* __restrict__ B, int ldb, float* __restrict__ C,
-                                                      int ldc, int M, int N, int K, int tiles_n, int k_per_split) {
+                                                      int ldc, int M, int N, int K, int tiles_n, int k_per_split,
+                                                      ConvDesc cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
     uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
@@ -472,13 +477,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
         for (int e = 0; e < 8; ++e) t.s[e] = (gc + e < lim) ? src[e] : (uint16_t)0;
         return t.u;
     };
+    // CONV: a thread's column chunk (tid & 15) never changes: its tap and channel are loop invariant
+    int cv_dt = 0, cv_dh = 0, cv_ci = 0;
+    bool cv_ok = false;
+    if (CONV) {
+        const int k = n0 + (tid & 15) * 8;
+        const int tap = k / cd.Cs, kh = tap / cd.KW, kw = tap - kh * cd.KW;
+        cv_ci = k - tap * cd.Cs;
+        cv_dt = kw - cd.pt;
+        cv_dh = kh - cd.ph;
+        cv_ok = k < N && kh < cd.KH;
+    }
+    auto load_conv = [&](int gk) -> uint4 {
+        if (gk >= kend || !cv_ok) return make_uint4(0, 0, 0, 0);
+        const int h = gk % cd.Hr, tb = gk / cd.Hr, b = tb % cd.B, t = tb / cd.B;
+        const int ti = t + cv_dt, hi = h + cv_dh;
+        if (ti < 0 || ti >= cd.Ts || hi < 0 || hi >= cd.Hs) return make_uint4(0, 0, 0, 0);
+        return ld16(B + (((size_t)ti * cd.B + b) * cd.Hs + hi) * cd.Cs + cv_ci);
+    };
     auto load_global = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256;
             const int row = id >> 4, c = id & 15;
             ra[i] = load_one(A, lda, a_vec, k0 + row, m0 + c * 8, M);
-            rb[i] = load_one(B, ldb, b_vec, k0 + row, n0 + c * 8, N);
+            rb[i] = CONV ? load_conv(k0 + row) : load_one(B, ldb, b_vec, k0 + row, n0 + c * 8, N);
         }
     };
     auto store_lds = [&](int buf) {
@@ -598,8 +621,31 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     if (splits < 1) splits = 1;
     int k_per_split = cdiv(cdiv(K, splits), TK) * TK;
     splits = cdiv(K, k_per_split);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
+                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{});
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B,
+                               int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr) {
+    if (!g || !x || !C || Co <= 0 || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0)
+        return ASR_ERR_BAD_ARG;
+    const int N = KH * KW * Cs;
+    const long long K = (long long)Tr * B * Hr;
+    if (ldg < Co || ldc < N) return ASR_ERR_BAD_ARG;
+    if ((Cs & 7) || K > 0x7fffffffLL || (((uintptr_t)x) & 15)) return ASR_ERR_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles_m = cdiv(Co, BM), tiles_n = cdiv(N, BN);
+    int splits = cdiv(1024, tiles_m * tiles_n);
+    const int max_splits = cdiv((int)K, 8 * TK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int k_per_split = cdiv(cdiv((int)K, splits), TK) * TK;
+    splits = cdiv((int)K, k_per_split);
+    const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
+                       (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

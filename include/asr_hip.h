@@ -157,7 +157,13 @@ int asr_conv_nt(void* stream, const void* x, const void* W, int ldw, void* out, 
 int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,
                        int B, int H, int C, int Cpad, void* out_bf16);
 int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst, int Co, int Ci, int KH, int KW);
-int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp);
+/* weight gradient of the same convolution without a column matrix: g (Tr*B*Hr, Co) bf16 rows of pitch ldg = output gradient,
+ * C[co][(kh*KW + kw)*Cs + c] += sum_{t,b,h} g[(t, b, h)][co] * x[t + kw - pad_t][b][h + kh - pad_h][c]   (f32, split-K atomics);
+ * Cs % 8 == 0.  asr_conv_weight_grad_unpack adds such a (Co, Kp) scratch into the (Co, Ci, KH, KW) gradient; Cs = channel
+ * pitch of the scratch rows (>= Ci; 0 = Ci). */
+int asr_conv_tn_acc(void* stream, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B, int Hs,
+                    int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr);
+int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp, int Cs);
 int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);
 int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out);
 int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);

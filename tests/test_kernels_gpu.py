@@ -423,3 +423,38 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     wb = _ops.conv_weight_pack_bwd(W)
     got_dx = _ops.conv_nt(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin).reshape(T, B, Hin, Ci)
     assert _rel(got_dx.cpu(), ref_dx.cpu()) < 2e-2      # the reference path rounds dcol to bf16 before the gather
+    # weight gradient: gy^T . col without the column matrix (asr_conv_tn_acc), accumulated on top of what is there
+    K = KH * KW * Ci
+    ref_w = torch.ones(Co, col.shape[1], device=device)
+    _ops.gemm_tn_acc(gy.reshape(-1, Co), col, ref_w)
+    got_w = torch.ones(Co, K, device=device)
+    _ops.conv_tn_acc(gy.reshape(-1, Co), x, got_w, KH, KW, ph, pt, Tout, Hout)
+    assert _rel(got_w.cpu(), ref_w[:, :K].cpu()) < 1e-5
+    gW_ref, gW = torch.zeros_like(W), torch.zeros_like(W)
+    _ops.conv_weight_grad_unpack(ref_w, gW_ref)
+    _ops.conv_weight_grad_unpack(got_w, gW, Ci)
+    assert _rel(gW.cpu(), gW_ref.cpu()) < 1e-5
+
+
+def test_first_layer_weight_gradient_with_padded_channels(device):
+    """first conv layer: 3 input channels zero-padded to 8 for the implicit kernels; the weight gradient comes back
+    through a scratch with channel pitch 8 (asr_conv_weight_grad_unpack Cs = 8) and must equal the float64 correlation"""
+    from asr import _ops
+    rs = np.random.RandomState(4)
+    T, B, Hin, Ci, Co, KH, KW, ph = 21, 2, 9, 3, 32, 3, 5, 1
+    pt, Tout, Hout = KW - 1, T, Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randn(B, Ci, Hin, T).astype(np.float32)).to(torch.bfloat16).float()
+    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(torch.bfloat16).float()
+    xd = x.to(device)
+    xpad = _ops.pack_input_pad(xd, (xd.stride(3), xd.stride(0), xd.stride(2), xd.stride(1)), T, B, Hin, Ci, 8)
+    scratch = torch.zeros(Co, KH * KW * 8, device=device)
+    _ops.conv_tn_acc(gy.to(device).to(torch.bfloat16).reshape(-1, Co), xpad, scratch, KH, KW, ph, pt, Tout, Hout)
+    gW = torch.zeros(Co, Ci, KH, KW, device=device)
+    _ops.conv_weight_grad_unpack(scratch, gW, 8)
+    xp = torch.nn.functional.pad(x.double(), (pt, 0, ph, ph))                      # (B, Ci, Hin + 2 ph, T + pt)
+    ref = torch.zeros(Co, Ci, KH, KW, dtype=torch.float64)
+    g = gy.double().permute(1, 3, 2, 0)                                            # (B, Co, Hout, Tout)
+    for kh in range(KH):
+        for kw in range(KW):
+            ref[:, :, kh, kw] = torch.einsum("bohs,bchs->oc", g, xp[:, :, kh:kh + Hout, kw:kw + Tout])
+    assert _rel(gW.cpu().double(), ref) < 1e-5
