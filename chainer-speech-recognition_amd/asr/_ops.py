@@ -249,7 +249,7 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
     return dx
 
 
-GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 = 0, 5 narrow backward, 7 forged placement
+GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 local with flags, 5 narrow backward, 7 forged placement, 8 local with polled payload (= 0)
 
 
 _SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky

@@ -450,10 +450,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
     uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
-    const int bid = blockIdx.x;
+    // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); an XCD takes whole K splits -- every tile
+    // of split (slot / tiles) * 8 + xcd, one after the other -- so the rows of A and B of a split are fetched into ONE L2
+    // and shared by all the tiles there (tile-major ids put every column block on its own XCD: each L2 fetched all of A).
+    // Only a locality hint: any placement computes the same thing.
+    const int tiles = ((M + BM - 1) / BM) * tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int round = slot / tiles, bid = slot - round * tiles;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = blockIdx.y * k_per_split;
+    const int kbeg = (round * 8 + xcd) * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
     if (kbeg >= kend) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -608,20 +614,27 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     return ASR_OK;
 }
 
+// split K so that about 4 workgroups per CU are in flight: a multiple of 8 splits (one set per XCD) where K allows, each
+// split a multiple of the k tile
+static int tn_splits(int tiles, int K, int& k_per_split) {
+    int splits = cdiv(1024, tiles);
+    splits = cdiv(splits, 8) * 8;
+    const int max_splits = cdiv(K, 8 * TK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    k_per_split = cdiv(cdiv(K, splits), TK) * TK;
+    return cdiv(K, k_per_split);
+}
+
 extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M,
                                int N, int K) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
     if (lda < M || ldb < N || ldc < N) return ASR_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    // split K so that about 4 workgroups per CU are in flight, each split a multiple of the k tile
-    int splits = cdiv(1024, tiles_m * tiles_n);
-    const int max_splits = cdiv(K, 8 * TK);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int k_per_split = cdiv(cdiv(K, splits), TK) * TK;
-    splits = cdiv(K, k_per_split);
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
+    int k_per_split;
+    const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
                        (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{});
     ASR_LAUNCH_CHECK();
     return ASR_OK;
@@ -637,14 +650,10 @@ extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void
     if ((Cs & 7) || K > 0x7fffffffLL || (((uintptr_t)x) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     const int tiles_m = cdiv(Co, BM), tiles_n = cdiv(N, BN);
-    int splits = cdiv(1024, tiles_m * tiles_n);
-    const int max_splits = cdiv((int)K, 8 * TK);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int k_per_split = cdiv(cdiv((int)K, splits), TK) * TK;
-    splits = cdiv((int)K, k_per_split);
+    int k_per_split;
+    const int splits = tn_splits(tiles_m * tiles_n, (int)K, k_per_split);
     const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles_m * tiles_n, splits), dim3(256), TN_LDS_BYTES, stream,
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
                        (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd);
     ASR_LAUNCH_CHECK();
     return ASR_OK;

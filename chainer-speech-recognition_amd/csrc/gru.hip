@@ -978,8 +978,8 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                                                           float* __restrict__ db_hh, unsigned* sync, int T, int B, int H, int ndir,
                                                           int forge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                                   // [8 waves][2 tiles][64]
-    char* opring = smem + 8 * 2 * 64 * 16;                                            // [BIO_GD][BIO_SLOT]: 5 x [4 rows][32 units] f32, dy bf16
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [2 (step parity)][8 waves][2 tiles][64]
+    char* opring = smem + 2 * 8 * 2 * 64 * 16;                                          // [BIO_GD][BIO_SLOT]: 5 x [4 rows][32 units] f32, dy bf16
     unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);       // [2][3: ar az an][4 rows][16 pairs]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 4 * 16);
     constexpr int rows = 4;
@@ -1070,13 +1070,15 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
         *s_abort = 0;
         s_abort[1] = 0;
         if (LOCAL) {
-            const int v = decide_local(sync, rec, nwg, abort_word, forge ? 2 + (slot & 1) : 0);
+            const int v = decide_local(sync, rec, nwg, abort_word, (forge & 1) ? 2 + (slot & 1) : 0);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
+    // data polling (forge bit 8, see fwd_persistent_io_kernel): dgh arrives filled with 0xffff and is its own signal
+    const bool dp = local && (forge & 8) != 0;
 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
@@ -1091,7 +1093,8 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
         }
         if (s > 0) {
-            if (local) {        // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
+            if (dp) {
+            } else if (local) { // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
                 if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
             } else {
                 if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) *s_abort = 1;
@@ -1102,14 +1105,30 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 constexpr int NL = (KS8 + 3) / 4;
                 Frag a[NL];
                 const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
+                unsigned spins = 0;
+                for (;;) {
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const int i = 4 * l + sl4, ks = w * KS8 + i;
-                    a[l].u = make_uint4(0, 0, 0, 0);
-                    if (i < KS8 && ks < nks && row < Bl) {
-                        const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
-                        a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                    for (int l = 0; l < NL; ++l) {
+                        const int i = 4 * l + sl4, ks = w * KS8 + i;
+                        a[l].u = make_uint4(0, 0, 0, 0);
+                        if (i < KS8 && ks < nks && row < Bl) {
+                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                            a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    if (!dp) break;
+                    bool missing = false;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        missing |= a[l].u.x == 0xffffffffu || a[l].u.y == 0xffffffffu || a[l].u.z == 0xffffffffu || a[l].u.w == 0xffffffffu;
+                    if (__ballot(missing) == 0ull) break;
+                    if ((++spins & 63u) == 0u) {
+                        if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
+                        if (spins > kSpinLimit) {
+                            if (lane == 0) { __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT); *s_abort = 1; }
+                            break;
+                        }
                     }
                 }
 #pragma unroll
@@ -1121,12 +1140,12 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 }
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn)
-                    if (lane < 16) part[(w * 2 + nn) * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);     // live rows 0..3 only
+                    if (lane < 16) part[((dp ? (s & 1) * 8 : 0) + w) * 2 * 64 + nn * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
             if (*s_abort) break;
             if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
-                const float* pf = reinterpret_cast<const float*>(part) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
+                const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 8 * 2 * 64 : 0)) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
 #pragma unroll
                 for (int ww = 0; ww < 8; ++ww) rcr += pf[ww * 2 * 256];
             }
@@ -1151,8 +1170,13 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
             const bool odd = u0 & 1;
             const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;
-            const unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
-            const unsigned pn_ = (e2 & 0xffffu) | (d2 << 16), pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
+            unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
+            unsigned pn_ = (e2 & 0xffffu) | (d2 << 16), pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
+            if (dp) {       // (NaN pairs of a diverged run) never the sentinel
+                if (pr_ == 0xffffffffu) pr_ = 0x7fc07fc0u;
+                if (pz_ == 0xffffffffu) pz_ = 0x7fc07fc0u;
+                if (pq_ == 0xffffffffu) pq_ = 0x7fc07fc0u;
+            }
             const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
             unsigned* od = oring + (size_t)(s & 1) * 3 * 4 * 16 + b * 16 + (u0 >> 1);
             if (act && !odd) {
@@ -1170,7 +1194,11 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
                 od[4 * 16] = pz_; od[2 * 4 * 16] = pn_;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (dp) {
+            if (s == 0) ASR_RAW_BARRIER();
+            continue;
         }
         ASR_RAW_BARRIER();
         if (tid == kPoller) {
@@ -1199,8 +1227,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
                                                                 int T, int B, int H, int ndir, int rows, int forge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                                   // [4 waves][3 gates][64]
-    float* opring = reinterpret_cast<float*>(part + 4 * 3 * 64);                      // [BIO_GD][3 gates][8 rows][16 units]
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [2 (step parity)][4 waves][3 gates][64]
+    float* opring = reinterpret_cast<float*>(part + 2 * 4 * 3 * 64);                  // [BIO_GD][3 gates][8 rows][16 units]
     float* oring = opring + BIO_GD * 3 * 8 * 16;                                      // [2][5: h r z n q][8 rows][16 units]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 8 * 16);
     const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
@@ -1293,13 +1321,17 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
         *s_abort = 0;
         s_abort[1] = 0;
         if (LOCAL) {
-            const int v = decide_local(sync, rec, nwg, abort_word, forge);
+            const int v = decide_local(sync, rec, nwg, abort_word, forge & 1);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
+    // data polling (forge bit 8, XCD-local form with paired loads): hseq16 arrives filled with 0xffff; a compute wave
+    // simply loads its K slices until no sentinel dword is left -- no flags, no drain of the payload stores before a
+    // signal, and one barrier per step (partials double-buffered by step parity)
+    const bool dp = local && PAIRED && (forge & 8) != 0;
 #ifdef ASR_STAMP
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define ASR_ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_last; st_last = n_; }
@@ -1318,7 +1350,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
         }
         if (s > 0) {
-            if (local) {        // one line of per-producer flags; every compute wave polls it for ITS producers and goes on
+            if (dp) {
+            } else if (local) { // one line of per-producer flags; every compute wave polls it for ITS producers and goes on
                 if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
             } else {
                 if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word))
@@ -1332,16 +1365,33 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
                     Frag a[(KSW + 1) / 2];
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool missing = false;
 #pragma unroll
-                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
-                        const int r16 = lane & 15, row = r16 & 7;
-                        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
-                        const int k = ks * 32 + 8 * (lane >> 4);
-                        a[i2].u = make_uint4(0, 0, 0, 0);
-                        if (ks < nks && row < Bl) {
-                            const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
-                            a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                            const int r16 = lane & 15, row = r16 & 7;
+                            const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+                            const int k = ks * 32 + 8 * (lane >> 4);
+                            a[i2].u = make_uint4(0, 0, 0, 0);
+                            if (ks < nks && row < Bl) {
+                                const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + k) * 2);
+                                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                                a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+                            }
+                        }
+                        if (!dp) break;
+                        // (one attempt at a time: a second one in flight made both slower, 1.78 -> 1.99 us per step)
+#pragma unroll
+                        for (int i2 = 0; i2 < KSW / 2; ++i2)
+                            missing |= a[i2].u.x == 0xffffffffu || a[i2].u.y == 0xffffffffu || a[i2].u.z == 0xffffffffu || a[i2].u.w == 0xffffffffu;
+                        if (__ballot(missing) == 0ull) break;
+                        if ((++spins & 63u) == 0u) {
+                            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
+                            if (spins > kSpinLimit) {
+                                if (lane == 0) { __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT); *s_abort = 1; }
+                                break;
+                            }
                         }
                     }
 #pragma unroll
@@ -1378,7 +1428,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 }
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
-                    if (lane < 32) part[(w * 3 + gg) * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);   // live rows 0..7 only
+                    if (lane < 32) part[((dp ? (s & 1) * 4 : 0) + w) * 3 * 64 + gg * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);   // live rows 0..7 only
             }
             ASR_ST(3)
             ASR_RAW_BARRIER();
@@ -1387,7 +1437,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
                 // nest of divergent branches around narrow reads (measured 0.95 us per step)
-                const float* pf = reinterpret_cast<const float*>(part) + ((b >> 2) * 16 + u) * 4 + (b & 3);
+                const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 4 * 3 * 64 : 0)) + ((b >> 2) * 16 + u) * 4 + (b & 3);
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
@@ -1411,7 +1461,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
             if (act) {
                 if (!(u & 1)) {
-                    const unsigned packed = mine | (other << 16);
+                    unsigned packed = mine | (other << 16);
+                    if (packed == 0xffffffffu) packed = 0x7fc07fc0u;      // (two NaNs of a diverged run) never the sentinel
                     const size_t o = ((size_t)t * B + b0 + b) * hs + (size_t)d * H + j0 + u;
                     if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
                     else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
@@ -1420,8 +1471,12 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
             }
             ASR_ST(6)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ASR_ST(7)
+        }
+        if (dp) {
+            if (s == 0) ASR_RAW_BARRIER();      // step 0 has no barrier of its own (no partial products)
+            continue;
         }
         ASR_RAW_BARRIER();
         ASR_ST(8)
@@ -2195,8 +2250,10 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
 #undef ASR_FWDW
     } else if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-        const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7) && ndir * Gio <= 8;     // try the XCD-local hand-off
-        const int forge = mode == 7;
+        const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
+        // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
+        const int forge = mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0);
+        if (forge == 8 && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \
@@ -2301,8 +2358,9 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         const int ks8 = (3 * H / 32 + 7) / 8;
         if (ks8 <= 6) {
             if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-            const bool local = mode == 0 || mode == 4 || mode == 7;
-            const int forge = mode == 7;
+            const bool local = mode == 0 || mode == 4 || mode == 7 || mode == 8;
+            const int forge = mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0);     // 8: data polling (mode 4: flag line)
+            if (forge == 8 && hipMemsetAsync(dgh_bf16, 0xff, (size_t)T * B * ndir * 3 * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
             const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
 #define ASR_BWDW(K)                                                                                                       \
     do {                                                                                                                  \

@@ -233,8 +233,10 @@ int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, con
  * one-launch-per-layer form.  mode: 0 = automatic (persistent when B <= 32, else one launch per step),
  * 1 = one launch per time step, 2 = persistent with the placement-free hand-off only (sc1 write-through + agent-scope
  * counter), 3 = the 32-unit grouped kernels, 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
- * find themselves on one XCD (what mode 0 selects; decided inside the launch, falls back to the mode-2 protocol
- * otherwise), 5 = mode 4 with the 16-unit x 8-row backward kernel instead of the wide one (comparison),
+ * find themselves on one XCD (decided inside the launch, falls back to the mode-2 protocol otherwise) signalled through a
+ * line of per-producer flags, 8 = the same with the payload as its own signal (what mode 0 selects: the call fills
+ * hseq_bf16 / dgh_bf16 with 0xffff first and consumers load until no such word is left: no flags, no store drain, one
+ * barrier per step), 5 = mode 4 with the 16-unit x 8-row backward kernel instead of the wide one (comparison),
  * 7 = mode 4 with a forged split placement (test hook for that fall-back).  Modes >= 2 return
  * ASR_ERR_UNSUPPORTED instead of falling back to mode 1.
  * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).  That word
