@@ -1394,6 +1394,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                             }
                         }
                     }
+#ifdef ASR_STAMP
+                    st_acc[11] += spins + 1;      // attempts
+#endif
+                    ASR_ST(2)
 #pragma unroll
                     for (int i2 = 0; i2 < KSW / 2; ++i2) {
                         Frag a1;

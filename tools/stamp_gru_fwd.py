@@ -17,10 +17,11 @@ torch.cuda.synchronize()
 s = _ops.LAST_SYNC[0].cpu().view(torch.uint8)
 st = s[4096:4096 + 8 * 6 * 12 * 8].view(torch.int64).reshape(8, 6, 12)
 names = ["poll", "bar1", "loads", "mfma+lds", "bar2", "gates", "stores", "drain", "bar3", "reduce", "gi_lds", "-"]
+att = st[:, :, 11].clone(); st[:, :, 11] = 0
 for wg in (0, 3):
     for w in range(6):
         print("wg", wg, "wave", w, " ".join("%s=%.2f" % (n, st[wg, w, i].item() / 2400.0 / T) for i, n in enumerate(names[:11])),
-              "sum=%.2f" % (st[wg, w].sum().item() / 2400.0 / T))
+              "sum=%.2f" % (st[wg, w].sum().item() / 2400.0 / T), "attempts/step=%.2f" % (att[wg, w].item() / T))
 
 w32 = _ops.LAST_SYNC[0].cpu().view(torch.uint8)[:4096].view(torch.int32)
 print("placement words: xcc", w32[960:968].tolist(), "mismatch", w32[976:984].tolist(), "arrivals", w32[992:1000].tolist())
