@@ -56,7 +56,7 @@ class Census(object):
         for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd",
                      "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "clip_decay_adam",
                      "sqnorm_acc", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
-                     "conv_weight_pack_bwd"):
+                     "conv_weight_pack_bwd", "conv_tn_acc"):
             fn = getattr(ops, name)
             self._orig[name] = fn
             setattr(ops, name, self._timed(name, fn))
@@ -308,7 +308,8 @@ def main():
                                                      "frac": ctc_bytes / (ctc["ctc_grad"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
         frames = T * B
         macs_fwd = frames * 15.25e6
-        gemm_ms = tot["gemm_nt"][0] + tot["gemm_tn_acc"][0] + tot.get("conv_nt", (0.0, 0))[0]      # conv_nt: implicit-GEMM convolutions
+        # conv_nt / conv_tn_acc: the implicit-GEMM convolutions (forward, backward-data; weight gradient)
+        gemm_ms = tot["gemm_nt"][0] + tot["gemm_tn_acc"][0] + tot.get("conv_nt", (0.0, 0))[0] + tot.get("conv_tn_acc", (0.0, 0))[0]
         rec_flops = 2 * (2 * nl * T) * (B * H * 3 * H * 2)      # recurrent MFMA work runs inside the GRU kernels
         gemm_flops = 3 * 2 * macs_fwd - rec_flops
         out["roofline_gemm"] = {"bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
