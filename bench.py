@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--vocab", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
+    ap.add_argument("--halves", type=int, default=int(os.environ.get("ASR_BENCH_HALVES", "0")),
+                    help="1: the batch as two concurrent half batches (asr/pipeline.py; measured slower at the BASELINE "
+                         "configuration, DESIGN.md section 5), 0: one stream (default)")
     return ap.parse_args()
 
 
@@ -199,7 +202,18 @@ def main():
     if comm is not None:
         opt.set_communicator(comm)
 
+    pipe = None
+    if args.halves and B >= 2:
+        from asr.pipeline import HalfBatches
+        pipe = HalfBatches(dev)
+        opt.set_pipeline(pipe)
+
+    def half_loss(sl):
+        return connectionist_temporal_classification(model(x[sl]), labels[sl], 0, x_len[sl], l_len[sl])
+
     def step():
+        if pipe is not None:
+            return pipe.step(opt, half_loss, B, stagger_us=0)
         loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
         opt.update(lossfun=lambda: loss)
         return loss

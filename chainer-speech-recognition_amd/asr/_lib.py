@@ -19,6 +19,7 @@ c_longlong = ctypes.c_longlong
 # name -> (restype, argtypes).  Mirrors include/asr_hip.h one to one; tests/test_abi.py checks both ways.
 SIGNATURES = {
     "asr_version": (c_int, []),
+    "asr_stream_delay": (c_int, [c_void_p, c_int]),
     "asr_ctc_workspace_bytes": (c_size_t, [c_int] * 5),
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
     "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),

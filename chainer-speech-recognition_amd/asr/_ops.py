@@ -253,7 +253,7 @@ GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent 
 
 
 _SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky
-_STATUS = {}        # device index -> [pinned host word, event of the copy in flight]
+_STATUS = {}        # (device index, stream) -> [pinned host word, event of the copy in flight]
 
 
 def _sync_buffer(dev, nbytes):
@@ -268,10 +268,10 @@ def _sync_buffer(dev, nbytes):
 def gru_poll_status():
     """Called once per step (optimizer.update): looks, without synchronising, at the abort words copied out during the
     previous step and raises if a persistent GRU launch gave up; then queues this step's copy."""
-    for (idx, _), buf in list(_SYNC.items()):
-        st = _STATUS.get(idx)
+    for key, buf in list(_SYNC.items()):         # one control buffer per (device, stream) that launched a recurrence
+        st = _STATUS.get(key)
         if st is None:
-            st = _STATUS[idx] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+            st = _STATUS[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
         if st[1] is not None and st[1].query() and int(st[0][0]) != 0:
             code = int(st[0][0])
             buf[1023:1024].zero_()

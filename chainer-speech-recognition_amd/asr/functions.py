@@ -24,21 +24,30 @@ BF16, F32 = torch.bfloat16, torch.float32
 # ---------------------------------------------------------------------------------------------- side stream
 # Weight-gradient GEMMs do not feed the activation-gradient chain: they run on a second HIP stream, beside the next
 # (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
-_SIDE = {"stream": None, "enabled": True}
+# One side stream per launching stream: with two half batches on two streams (asr/pipeline.py) a shared side stream would
+# queue the early weight gradients of the second half behind the late ones of the first.
+_SIDE = {"streams": {}, "enabled": True}
 
 
 def side_stream():
     if not _SIDE["enabled"]:
         return None
-    if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
-    return _SIDE["stream"]
+    key = torch.cuda.current_stream().cuda_stream
+    st = _SIDE["streams"].get(key)
+    if st is None:
+        st = _SIDE["streams"][key] = torch.cuda.Stream()
+    return st
+
+
+def side_streams():
+    return list(_SIDE["streams"].values())
 
 
 def join_side_stream():
-    """called by the optimiser before it reads the gradients"""
-    if _SIDE["stream"] is not None:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+    """called by the optimiser before it reads the gradients: the current stream waits for every side stream"""
+    cur = torch.cuda.current_stream()
+    for st in _SIDE["streams"].values():
+        cur.wait_stream(st)
 
 
 class _OnSide(object):

@@ -76,13 +76,34 @@ class Link(torch.nn.Module):
         stamp = (_WEIGHT_EPOCH[0], param._version, param.data_ptr())
         hit = self._compute_cache.get(key)
         if hit is not None and hit[0] == stamp:
+            _await_copy(hit)
             return hit[1]
         with torch.no_grad():
             value = maker(param.detach())
-        self._compute_cache[key] = (stamp, value)
+        self._compute_cache[key] = _made_copy(stamp, value)
         if layout is not None and value.is_cuda:
             self._cast_registry[key] = (param, value, _cast_jobs(param, layout))
         return value
+
+
+def _made_copy(stamp, value):
+    """cache entry (stamp, value, event, streams that have it): a copy made on one stream may be wanted on another one
+    (asr/pipeline.py runs two half batches on two streams)"""
+    if not value.is_cuda:
+        return (stamp, value, None, None)
+    ev = torch.cuda.Event()
+    ev.record()
+    return (stamp, value, ev, {torch.cuda.current_stream().cuda_stream})
+
+
+def _await_copy(entry):
+    if entry[2] is None:
+        return
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream not in entry[3]:
+        cur.wait_event(entry[2])
+        entry[1].record_stream(cur)
+        entry[3].add(cur.cuda_stream)
 
 
 def _cast_jobs(param, layout):
@@ -130,7 +151,7 @@ def refresh_compute_copies(model):
         object.__setattr__(model, "_cast_table", cached)
     _lib.check(_lib.lib().asr_cast_bf16_many(_lib.stream(), _lib.ptr(cached[1]), cached[2], cached[3]), "asr_cast_bf16_many")
     for m, key, param, out in todo:
-        m._compute_cache[key] = ((_WEIGHT_EPOCH[0], param._version, param.data_ptr()), out)
+        m._compute_cache[key] = _made_copy((_WEIGHT_EPOCH[0], param._version, param.data_ptr()), out)
     return cached[2]
 
 

@@ -39,6 +39,7 @@ class Optimizer(object):
         self._hooks = []
         self._flat = None
         self.communicator = None
+        self.pipeline = None
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -55,6 +56,10 @@ class Optimizer(object):
         self.communicator = comm
         self._flat = None
 
+    def set_pipeline(self, pipeline):
+        """asr.pipeline.HalfBatches whose streams carry gradient kernels the update must wait for"""
+        self.pipeline = pipeline
+
     def update(self, lossfun=None, *args, **kwds):
         if lossfun is not None:
             loss = lossfun(*args, **kwds)
@@ -64,6 +69,8 @@ class Optimizer(object):
             loss.backward()
         self._ensure_flat()
         from .functions import join_side_stream
+        if self.pipeline is not None:
+            self.pipeline.join()            # gradient kernels of the two half batches (asr/pipeline.py)
         join_side_stream()                  # weight-gradient GEMMs issued on the side stream
         _ops.gru_poll_status()              # raises if a persistent GRU launch of the previous step gave up a wait
         scale = 1.0

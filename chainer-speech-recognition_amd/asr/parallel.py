@@ -49,12 +49,17 @@ class Communicator(object):
                 acc = 0
         return plan
 
-    def begin_backward(self, opt):
+    def begin_backward(self, opt, passes=1):
+        """`passes` backward passes will write the gradient buffer one after the other in program order (asr/pipeline.py:
+        two half batches, each on its own stream); a slice is reduced while the LAST pass walks past it, after the events
+        the earlier passes left there."""
         opt._ensure_flat()
         self._plan = self._make_plan(opt)
         self._pending = []
         self._next = 0
         self._opt = opt
+        self._passes, self._pass = max(1, int(passes)), 0
+        self._events = [[] for _ in self._plan]
         if self.backend == "nccl" and self._stream is None:
             self._stream = torch.cuda.Stream()
         from . import link
@@ -71,17 +76,40 @@ class Communicator(object):
         except ValueError:
             return
         while self._next < len(self._plan) and self._plan[self._next][2] > idx:
-            self._launch(self._plan[self._next])
+            self._passed(self._next)
             self._next += 1
 
-    def _launch(self, item):
+    def _passed(self, k):
+        """the current pass has queued every kernel that writes slice k"""
+        if self._pass == self._passes - 1:
+            self._launch(self._plan[k], self._events[k])
+        elif self._stream is not None:
+            from .functions import side_streams
+            for st in [torch.cuda.current_stream()] + side_streams():
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._events[k].append(ev)
+
+    def end_pass(self):
+        """between two backward passes: the pass just queued has written every slice it had not walked past yet"""
+        if self._plan is None:
+            return
+        while self._next < len(self._plan):
+            self._passed(self._next)
+            self._next += 1
+        self._pass += 1
+        self._next = 0
+
+    def _launch(self, item, events=()):
         begin, end = item[0], item[1]
         g = self._opt._flat["G"][begin:end]
         if self._stream is not None:
+            for ev in events:
+                self._stream.wait_event(ev)
             self._stream.wait_stream(torch.cuda.current_stream())
-            from .functions import _SIDE
-            if _SIDE["stream"] is not None:         # weight-gradient GEMMs run on the side stream
-                self._stream.wait_stream(_SIDE["stream"])
+            from .functions import side_streams
+            for st in side_streams():               # weight-gradient GEMMs run on side streams
+                self._stream.wait_stream(st)
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
@@ -94,8 +122,9 @@ class Communicator(object):
             opt._ensure_flat()
             dist.all_reduce(opt._flat["G"], op=dist.ReduceOp.SUM)
             return
+        self._pass = self._passes - 1
         while self._next < len(self._plan):
-            self._launch(self._plan[self._next])
+            self._passed(self._next)
             self._next += 1
         for w in self._pending:
             w.wait()

@@ -451,7 +451,7 @@ __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch
         const int kh = (int)(r % KH); r /= KH;
         const int ci = (int)(r % Ci);
         const int co = (int)(r / Ci);
-        gW[i] += scratch[(long long)co * Kp + (kh * KW + kw) * Cs + ci];
+        atomicAdd(gW + i, scratch[(long long)co * Kp + (kh * KW + kw) * Cs + ci]);      // (two half batches may add at once)
     }
 }
 

@@ -1506,8 +1506,8 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                                                           uint16_t* hseq16, float* __restrict__ gates, unsigned* sync, int T,
                                                           int B, int H, int ndir, int forge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                                   // [8 waves][6 tiles: gate x unit half][64]
-    float* opring = reinterpret_cast<float*>(part + 8 * 6 * 64);                      // [BIO_GD][3 gates][4 rows][32 units]
+    float4* part = reinterpret_cast<float4*>(smem);                                   // [2 (step parity)][8 waves][6 tiles: gate x unit half][16 live lanes]
+    float* opring = reinterpret_cast<float*>(part + 2 * 8 * 6 * 16);                      // [BIO_GD][3 gates][4 rows][32 units]
     float* oring = opring + BIO_GD * 3 * 128;                                         // [2][5: h r z n q][4 rows][32 units]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 128);
     constexpr int rows = 4;
@@ -1597,13 +1597,14 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
         *s_abort = 0;
         s_abort[1] = 0;
         if (LOCAL) {
-            const int v = decide_local(sync, rec, nwg, abort_word, forge ? 2 + (slot & 1) : 0);
+            const int v = decide_local(sync, rec, nwg, abort_word, (forge & 1) ? 2 + (slot & 1) : 0);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
+    const bool dp = local && (forge & 8) != 0;        // payload polled as its own signal (see fwd_persistent_io_kernel)
 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
@@ -1615,7 +1616,8 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
             gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
         }
         if (s > 0) {
-            if (local) {        // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
+            if (dp) {
+            } else if (local) { // every compute wave waits for the producers of ITS K slices only, no workgroup barrier
                 if (is_compute && !wait_flags_mask(shards, nwg, my_producers, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
             } else {
                 if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) *s_abort = 1;
@@ -1628,14 +1630,30 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                 constexpr int NL = (KS8 + 3) / 4;
                 Frag a[NL];
                 const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
+                unsigned spins = 0;
+                for (;;) {
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const int i = 4 * l + sl4, ks = w * KS8 + i;
-                    a[l].u = make_uint4(0, 0, 0, 0);
-                    if (i < KS8 && ks < nks && row < Bl) {
-                        const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + ks * 32 + 8 * (lane >> 4)) * 2);
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
-                        a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                    for (int l = 0; l < NL; ++l) {
+                        const int i = 4 * l + sl4, ks = w * KS8 + i;
+                        a[l].u = make_uint4(0, 0, 0, 0);
+                        if (i < KS8 && ks < nks && row < Bl) {
+                            const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + ks * 32 + 8 * (lane >> 4)) * 2);
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                            a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                    if (!dp) break;
+                    bool missing = false;
+#pragma unroll
+                    for (int l = 0; l < NL; ++l)
+                        missing |= a[l].u.x == 0xffffffffu || a[l].u.y == 0xffffffffu || a[l].u.z == 0xffffffffu || a[l].u.w == 0xffffffffu;
+                    if (__ballot(missing) == 0ull) break;
+                    if ((++spins & 63u) == 0u) {
+                        if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
+                        if (spins > kSpinLimit) {
+                            if (lane == 0) { __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT); *s_abort = 1; }
+                            break;
+                        }
                     }
                 }
 #pragma unroll
@@ -1647,16 +1665,16 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                 }
 #pragma unroll
                 for (int tl = 0; tl < 6; ++tl)
-                    if (lane < 16) part[(w * 6 + tl) * 64 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);     // live rows 0..3 only
+                    if (lane < 16) part[(((dp ? (s & 1) * 8 : 0) + w) * 6 + tl) * 16 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
             if (*s_abort) break;
             if (act) {
-                const float* pf = reinterpret_cast<const float*>(part) + ((u >> 4) * 64 + (u & 15)) * 4 + b;
+                const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 8 * 6 * 16 : 0)) + ((u >> 4) * 16 + (u & 15)) * 4 + b;
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
-                    for (int ww = 0; ww < 8; ++ww) gh[gg] += pf[(ww * 6 + gg * 2) * 256];
+                    for (int ww = 0; ww < 8; ++ww) gh[gg] += pf[(ww * 6 + gg * 2) * 64];
             }
         }
         if (is_loader) {
@@ -1674,7 +1692,8 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
             const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
             if (act) {
                 if (!(u & 1)) {
-                    const unsigned packed = mine | (other << 16);
+                    unsigned packed = mine | (other << 16);
+                    if (packed == 0xffffffffu) packed = 0x7fc07fc0u;      // never the sentinel
                     const size_t o = ((size_t)t * B + b0 + b) * hs + (size_t)d * H + j0 + u;
                     if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
                     else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);
@@ -1682,7 +1701,11 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                 float* od = oring + (size_t)(s & 1) * 5 * 128 + b * 32 + u;
                 od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (dp) {
+            if (s == 0) ASR_RAW_BARRIER();
+            continue;
         }
         ASR_RAW_BARRIER();
         if (tid == kPoller) {
@@ -2227,16 +2250,21 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
-    const int Gio = (B + 7) / 8;
-    if (persist && mode == 2 && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
+    const int io_rows = 8, io_lds = kPersistLds;
+    const int Gio = (B + io_rows - 1) / io_rows;
+    // wide form also for B <= 16 in the default modes: a half batch (asr/pipeline.py) then makes 8 recurrences of 16
+    // workgroups, so that the launch of the other half batch finds a free CU for every workgroup of its own
+    const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
+    if (persist && (mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
         // wide form (32 units x 4-row recurrences).  Measured at T=1000, B=32, H=512: with the XCD-local hand-off it ties
         // the 16-unit x 8-row kernel (2.11 vs 2.12 us: the smaller payload is paid back in the 8-wave reduction), with the
         // placement-free hand-off it wins (2.47 vs 2.72 us) -- so it serves mode 2 only; the backward pass is wide in both.
         const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
         const int ks8 = (H / 32 + 7) / 8;
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-        const bool local = mode == 0 || mode == 4 || mode == 7;
-        const int forge = mode == 7;
+        const bool local = mode == 0 || mode == 4 || mode == 7 || mode == 8;
+        const int forge = mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0);
+        if (forge == 8 && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
 #define ASR_FWDW(K)                                                                                                       \
     do {                                                                                                                  \
@@ -2263,12 +2291,12 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
     do {                                                                                                                  \
         if (local) {                                                                                                      \
             (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true>), igrid, iblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
-                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, 8, forge);                     \
+            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true>), igrid, iblock, io_lds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge);               \
         } else {                                                                                                          \
             (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, false>), igrid, iblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
-                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, 8, 0);                         \
+            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, false>), igrid, iblock, io_lds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, 0);                   \
         }                                                                                                                 \
     } while (0)
         if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);

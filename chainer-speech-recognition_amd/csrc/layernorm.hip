@@ -348,8 +348,8 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sgy, const doubl
                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    dgamma[c] += (float)sgx[c];
-    dbeta[c] += (float)sgy[c];
+    atomicAdd(dgamma + c, (float)sgx[c]);
+    atomicAdd(dbeta + c, (float)sgy[c]);
 }
 
 }  // namespace ln

@@ -18,6 +18,8 @@ extern "C" {
 #endif
 
 int asr_version(void);
+/* a one-wave kernel that idles for `microseconds` (<= 100000) on `stream`: used to stagger two concurrent half batches */
+int asr_stream_delay(void* stream, int microseconds);
 
 /* ---------------------------------------------------------------------------------------- CTC family
  * Replaces chainer.functions.connectionist_temporal_classification (call sites run/ctc/cnn/train.py:162,191,

@@ -69,6 +69,22 @@ def _worker(rank, world, port, q):
     covered = sorted((b, e) for b, e, _, _ in plan)
     contiguous = covered[0][0] == 0 and all(covered[k][1] == covered[k + 1][0] for k in range(len(covered) - 1)) \
         and covered[-1][1] == G.numel()
+    # two backward passes (two half batches): nothing is reduced during the first one, everything once after the second
+    opt._flat["G"].zero_()
+    comm.begin_backward(opt, passes=2)
+    during_first = 0
+    for ps in range(2):
+        for i in range(len(sizes) - 1, -1, -1):
+            g = link.grad_buffer(opt.params[i])
+            g.add_(torch.full_like(g, float(rank + 1) * (i + 1) * (ps + 1)))
+        if ps == 0:
+            during_first = len(comm._pending)
+            comm.end_pass()
+    comm.finish_backward(opt)
+    for i, (p, off) in enumerate(zip(opt.params, opt._flat["offsets"])):
+        expect = float(sum(r + 1 for r in range(world)) * (i + 1) * 3)
+        ok = ok and bool(torch.all(G[off:off + p.numel()] == expect))
+    ok = ok and during_first == 0
     q.put((rank, ok, contiguous, p0.sum().item(), launched, len(plan)))
     comm.barrier()
     torch.distributed.destroy_process_group()
