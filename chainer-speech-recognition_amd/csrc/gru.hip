@@ -1106,7 +1106,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 Frag a[NL];
                 const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
                 unsigned spins = 0;
-                for (;;) {
+                auto fetch = [&]() {        // (first attempt outside the retry loop: see fwd_persistent_io_kernel)
 #pragma unroll
                     for (int l = 0; l < NL; ++l) {
                         const int i = 4 * l + sl4, ks = w * KS8 + i;
@@ -1117,7 +1117,9 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                             a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
-                    if (!dp) break;
+                };
+                fetch();
+                while (dp) {
                     bool missing = false;
 #pragma unroll
                     for (int l = 0; l < NL; ++l)
@@ -1130,6 +1132,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                             break;
                         }
                     }
+                    fetch();
                 }
 #pragma unroll
                 for (int i = 0; i < KS8; ++i) {
@@ -1366,8 +1369,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
                     Frag a[(KSW + 1) / 2];
                     unsigned spins = 0;
-                    for (;;) {
-                        bool missing = false;
+                    // the first attempt is issued outside the retry loop: at a loop header the compiler waits vmcnt(0) for
+                    // the registers it is about to reload, which on the gate waves also drains their own h store (gfx9
+                    // has one counter for loads and stores) -- 0.29 us per step in front of the loads
+                    auto fetch = [&]() {
 #pragma unroll
                         for (int i2 = 0; i2 < KSW / 2; ++i2) {
                             const int r16 = lane & 15, row = r16 & 7;
@@ -1380,8 +1385,11 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                                 a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
                             }
                         }
-                        if (!dp) break;
+                    };
+                    fetch();
+                    while (dp) {
                         // (one attempt at a time: a second one in flight made both slower, 1.78 -> 1.99 us per step)
+                        bool missing = false;
 #pragma unroll
                         for (int i2 = 0; i2 < KSW / 2; ++i2)
                             missing |= a[i2].u.x == 0xffffffffu || a[i2].u.y == 0xffffffffu || a[i2].u.z == 0xffffffffu || a[i2].u.w == 0xffffffffu;
@@ -1393,6 +1401,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                                 break;
                             }
                         }
+                        fetch();
                     }
 #ifdef ASR_STAMP
                     st_acc[11] += spins + 1;      // attempts
@@ -1631,7 +1640,7 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                 Frag a[NL];
                 const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
                 unsigned spins = 0;
-                for (;;) {
+                auto fetch = [&]() {        // (first attempt outside the retry loop: see fwd_persistent_io_kernel)
 #pragma unroll
                     for (int l = 0; l < NL; ++l) {
                         const int i = 4 * l + sl4, ks = w * KS8 + i;
@@ -1642,7 +1651,9 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                             a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
-                    if (!dp) break;
+                };
+                fetch();
+                while (dp) {
                     bool missing = false;
 #pragma unroll
                     for (int l = 0; l < NL; ++l)
@@ -1655,6 +1666,7 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                             break;
                         }
                     }
+                    fetch();
                 }
 #pragma unroll
                 for (int i = 0; i < KS8; ++i) {
@@ -2263,8 +2275,8 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
         const int ks8 = (H / 32 + 7) / 8;
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
         const bool local = mode == 0 || mode == 4 || mode == 7 || mode == 8;
-        const int forge = mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0);
-        if (forge == 8 && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const int forge = (mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0));
+        if ((forge & 8) && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
 #define ASR_FWDW(K)                                                                                                       \
     do {                                                                                                                  \
@@ -2284,8 +2296,8 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
         if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
         const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
         // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
-        const int forge = mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0);
-        if (forge == 8 && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
+        if ((forge & 8) && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \
@@ -2391,8 +2403,8 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         if (ks8 <= 6) {
             if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
             const bool local = mode == 0 || mode == 4 || mode == 7 || mode == 8;
-            const int forge = mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0);     // 8: data polling (mode 4: flag line)
-            if (forge == 8 && hipMemsetAsync(dgh_bf16, 0xff, (size_t)T * B * ndir * 3 * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
+            const int forge = (mode == 7 ? 1 : (mode == 0 || mode == 8 ? 8 : 0));     // 8: data polling (mode 4: flag line)
+            if ((forge & 8) && hipMemsetAsync(dgh_bf16, 0xff, (size_t)T * B * ndir * 3 * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
             const dim3 wgrid = local ? dim3(nrec_pad * (H / 32)) : dim3(H / 32, Gw, ndir), wblock(640);
 #define ASR_BWDW(K)                                                                                                       \
     do {                                                                                                                  \
