@@ -1148,6 +1148,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             ASR_RAW_BARRIER();
             if (*s_abort) break;
             if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
+                // (a reader-side layout -- two float4 per thread, eight scalar writes per wave -- measured no better here)
                 const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 8 * 2 * 64 : 0)) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
 #pragma unroll
                 for (int ww = 0; ww < 8; ++ww) rcr += pf[ww * 2 * 256];
@@ -1439,9 +1440,16 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
 #pragma unroll
                     for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][gg].v, acc[gg], 0, 0, 0);
                 }
+                // partials laid out for the reader: the four waves' values of one (gate, row, unit) are one float4
+                // [parity][gate][row 8][unit 16][wave 4] -- 12 scalar writes here instead of 12 scalar reads on the gate
+                // threads' critical path (which then read three float4)
+                if (lane < 32) {
+                    float* pw = reinterpret_cast<float*>(part) + (dp ? (s & 1) * 3 * 128 * 4 : 0) + (((lane >> 4) * 4) * 16 + (lane & 15)) * 4 + w;
 #pragma unroll
-                for (int gg = 0; gg < 3; ++gg)
-                    if (lane < 32) part[((dp ? (s & 1) * 4 : 0) + w) * 3 * 64 + gg * 64 + lane] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);   // live rows 0..7 only
+                    for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pw[(gg * 128 + r * 16) * 4] = acc[gg][r];
+                }
             }
             ASR_ST(3)
             ASR_RAW_BARRIER();
@@ -1450,11 +1458,12 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
                 // nest of divergent branches around narrow reads (measured 0.95 us per step)
-                const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 4 * 3 * 64 : 0)) + ((b >> 2) * 16 + u) * 4 + (b & 3);
+                const float4* pf = part + (dp ? (s & 1) * 3 * 128 : 0) + b * 16 + u;
 #pragma unroll
-                for (int gg = 0; gg < 3; ++gg)
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) gh[gg] += pf[(ww * 3 + gg) * 256];
+                for (int gg = 0; gg < 3; ++gg) {
+                    const float4 v = pf[gg * 128];
+                    gh[gg] += (v.x + v.y) + (v.z + v.w);
+                }
             }
             ASR_ST(9)
         }
