@@ -1005,25 +1005,30 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
     const long long tstep = d == 0 ? -1 : 1;
     const int tfirst = d == 0 ? T - 1 : 0;
 
-    // ---- loader (wave 8): lanes 0..31 fetch (row lane / 8, units 4 (lane % 8) ..) of each f32 array, lanes 0..15 dy
-    const int lrow = lane >> 3, lyrow = lane >> 2;
-    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4;
+    // ---- loader (wave 8): THREE LDS-DMA instructions per step fill the 2816-byte slot image (every instruction of a step
+    // costs the recurrence about 0.05 us, see fwd_persistent_io_kernel): lanes 0..63 gates r | z, lanes 0..63 gates n | q
+    // (array = lane / 32, then (row, units 4 (lane % 8) ..) = lane % 32), lanes 0..31 h_prev + lanes 32..47 dy (row
+    // (lane - 32) / 4, 8 bf16 each)
+    const int lrow = (lane & 31) >> 3, lyrow = (lane - 32) >> 2;
+    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4 +
+                       (size_t)(lane >> 5) * H;
     const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
                        (size_t)d * H + j0 + (lane & 7) * 4;
-    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
-    const long long lgs = tstep * (long long)B * ndir * 4 * H, lhs = tstep * (long long)B * (long long)hs, lys = tstep * (long long)B * H;
+    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lane >= 32 && lane < 48 && lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
+    const char* l2p = lane < 32 ? reinterpret_cast<const char*>(lhp) : reinterpret_cast<const char*>(lyp);
+    const long long lgs = tstep * (long long)B * ndir * 4 * H;
+    const long long l2s = lane < 32 ? tstep * (long long)B * (long long)hs * 4 : tstep * (long long)B * H * 2;      // bytes
     auto issue = [&](int sq) {
         if (sq < T) {
             char* sl = opring + (sq % BIO_GD) * BIO_SLOT;
-            if (lane < 32 && lrow < Bl) {
-#pragma unroll
-                for (int arr = 0; arr < 4; ++arr)
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)arr * H), (lds_ptr_t)(sl + arr * 512), 16, 0, 0);
-                if (sq < T - 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)lhp, (lds_ptr_t)(sl + 4 * 512), 16, 0, 0);
+            if (lrow < Bl) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)sl, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(sl + 1024), 16, 0, 0);
             }
-            if (lane < 16 && lyrow < Bl) __builtin_amdgcn_global_load_lds((glb_ptr_t)lyp, (lds_ptr_t)(sl + 5 * 512), 16, 0, 0);
+            if (lane < 32 ? (lrow < Bl && sq < T - 1) : (lane < 48 && lyrow < Bl))
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)l2p, (lds_ptr_t)(sl + 2048), 16, 0, 0);
         }
-        lgp += lgs; lhp += lhs; lyp += lys;
+        lgp += lgs; l2p += l2s;
     };
     // ---- storer (wave 9): dgi: 3 gates x 4 rows x 64 B = 48 pieces of 16 B
     auto store_step = [&](int sp) {
@@ -1154,9 +1159,11 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 for (int ww = 0; ww < 8; ++ww) rcr += pf[ww * 2 * 256];
             }
         }
-        if (is_loader) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (is_loader) {        // slot s + 1 must have landed; the two younger issues (3 instructions each) stay in flight
             issue(s + BIO_GD - 1);
+            if (s + BIO_GD - 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (s + BIO_GD - 2 < T) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else if (gate_wave) {
@@ -1254,17 +1261,19 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
     const long long tstep = d == 0 ? 1 : -1;
     const int tfirst = d == 0 ? 0 : T - 1;
 
-    // loader (wave 4), LDS-DMA: lanes 0..31 fetch (row lane / 4, units 4 (lane % 4) ..) of each of the three gi gate
-    // arrays straight into the ring slot (lane-linear image = [3 gates][8 rows][16 units] f32); no data registers
-    const int lrow = lane >> 2;
-    const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 3) * 4;
+    // loader (wave 4), LDS-DMA straight into the ring slot (lane-linear image = [3 gates][8 rows][16 units] f32), no data
+    // registers: TWO instructions per step -- all 64 lanes fetch gates r | z (lane / 32), lanes 0..31 gate n; lane % 32 =
+    // (row, units 4 (lane % 4) ..).  Every LDS-DMA instruction of a step costs the recurrence about 0.05 us (measured with
+    // three, one and none): the hand-off loads of the compute waves return behind it.
+    const int lrow = (lane & 31) >> 2;
+    const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 3) * 4 +
+                       (size_t)(lane >> 5) * H;
     const long long lstride = tstep * (long long)B * 3 * (long long)hs;
     auto issue = [&](int sq) {
-        if (sq < T && lane < 32 && lrow < Bl) {
+        if (sq < T && lrow < Bl) {
             char* slot = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
-#pragma unroll
-            for (int gg = 0; gg < 3; ++gg)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)gg * H), (lds_ptr_t)(slot + gg * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)slot, 16, 0, 0);
+            if (lane < 32) __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(slot + 1024), 16, 0, 0);
         }
         lgp += lstride;
     };
@@ -1324,6 +1333,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
+        s_abort[2] = 0;
+        s_abort[3] = 0;
         if (LOCAL) {
             const int v = decide_local(sync, rec, nwg, abort_word, forge & 1);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
@@ -1342,6 +1353,25 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
 #else
 #define ASR_ST(i)
 #endif
+
+    // hand-off loads of one step (PAIRED form): fragment i2 = K slices 2 (4 i2 + w), + 1 of row tq
+    constexpr int NA = (KSW + 1) / 2;
+    auto fetch_row = [&](Frag (&f)[NA], int tq) {
+#pragma unroll
+        for (int i2 = 0; i2 < KSW / 2; ++i2) {
+            const int r16 = lane & 15, row = r16 & 7;
+            const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+            const int k = ks * 32 + 8 * (lane >> 4);
+            f[i2].u = make_uint4(0, 0, 0, 0);
+            if (ks < nks && row < Bl) {
+                const unsigned off = (unsigned)((((size_t)tq * B + b0 + row) * hs + (size_t)d * H + k) * 2);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+                f[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    Frag ahead[NA];             // gate waves: the next step's first attempt, issued right behind their own h store
+    bool have_ahead = false;
 
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
@@ -1368,26 +1398,27 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
-                    Frag a[(KSW + 1) / 2];
+                    Frag a[NA];
                     unsigned spins = 0;
                     // the first attempt is issued outside the retry loop: at a loop header the compiler waits vmcnt(0) for
                     // the registers it is about to reload, which on the gate waves also drains their own h store (gfx9
                     // has one counter for loads and stores) -- 0.29 us per step in front of the loads
-                    auto fetch = [&]() {
+                    auto fetch = [&]() { fetch_row(a, tp); };
+                    if (have_ahead) {
 #pragma unroll
-                        for (int i2 = 0; i2 < KSW / 2; ++i2) {
-                            const int r16 = lane & 15, row = r16 & 7;
-                            const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
-                            const int k = ks * 32 + 8 * (lane >> 4);
-                            a[i2].u = make_uint4(0, 0, 0, 0);
-                            if (ks < nks && row < Bl) {
-                                const unsigned off = (unsigned)((((size_t)tp * B + b0 + row) * hs + (size_t)d * H + k) * 2);
-                                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
-                                a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
-                            }
+                        for (int i2 = 0; i2 < NA; ++i2) a[i2].u = ahead[i2].u;
+                    } else {
+                        // the pure compute waves would poll from the barrier on and waste one attempt per step (measured:
+                        // 1.01 retries) while the producers are still in their gate phase: they wait on an LDS word that
+                        // the gate waves of THIS workgroup raise when they store (all workgroups are in step), then ask
+                        if (dp) {
+                            volatile int* go = s_abort + 2;
+                            unsigned nap = 0;
+                            while ((go[0] < s || go[1] < s) && !*(volatile int*)s_abort && ++nap < kSpinLimit) __builtin_amdgcn_s_sleep(1);
                         }
-                    };
-                    fetch();
+                        fetch();
+                    }
+                    have_ahead = false;
                     while (dp) {
                         // (one attempt at a time: a second one in flight made both slower, 1.78 -> 1.99 us per step)
                         bool missing = false;
@@ -1468,8 +1499,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             ASR_ST(9)
         }
         if (is_loader) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot issued one step ago has landed (read two steps from now)
+            // slot s + 1 (issued two steps ago) must have landed before this step's barrier; the two younger issues, two
+            // LDS-DMA instructions each, stay in flight.  (vmcnt(0) here waited for the load issued ONE step ago, i.e. for a
+            // fresh HBM round trip, and made the loader the last wave at the barrier: 0.25 us per step.)
             issue(s + BIO_GD - 1);
+            if (s + BIO_GD - 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (s + BIO_GD - 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
         } else if (tid >= 128) {
@@ -1489,6 +1525,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                     if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
                     else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
                 }
+            }
+            if (PAIRED && dp && s + 1 < T) {     // row t is what step s + 1 reads: ask for it before the LDS bookkeeping below
+                if (lane == 0) *(volatile int*)(s_abort + w) = s + 1;       // (waves 2 and 3 -> words 2 and 3)
+                fetch_row(ahead, t);
+                have_ahead = true;
+            }
+            if (act) {
                 float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
                 od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
             }
