@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                     if (lane < 16) part[((dp ? (s & 1) * 8 : 0) + w) * 2 * 64 + nn * 64 + lane] = make_float4(acc[nn][0], acc[nn][1], acc[nn][2], acc[nn][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
-            if (*s_abort) break;
+            if ((s & 15) == 0 && *s_abort) break;      // (every 16 steps: the LDS read sat on the chain behind the barrier; polls give up at once anyway)
             if (act) {      // tile rows 0..3 live in lanes 0..15 (column = lane), component = row
                 // (a reader-side layout -- two float4 per thread, eight scalar writes per wave -- measured no better here)
                 const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 8 * 2 * 64 : 0)) + ((u0 >> 4) * 64 + (u0 & 15)) * 4 + b;
@@ -1356,20 +1356,29 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
 
     // hand-off loads of one step (PAIRED form): fragment i2 = K slices 2 (4 i2 + w), + 1 of row tq
     constexpr int NA = (KSW + 1) / 2;
+    // byte offsets inside hseq16 (< 2^31, can_persist) are kept per lane and stepped by one (t) row: no 64-bit products
+    // on the chain
+    const unsigned row_bytes = (unsigned)((size_t)B * hs * 2);
+    unsigned frag_off[NA];
+    bool frag_on[NA];
+#pragma unroll
+    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+        const int r16 = lane & 15, row = r16 & 7;
+        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+        frag_on[i2] = ks < nks && row < Bl;
+        frag_off[i2] = (unsigned)((((size_t)b0 + row) * hs + (size_t)d * H + ks * 32 + 8 * (lane >> 4)) * 2);
+    }
     auto fetch_row = [&](Frag (&f)[NA], int tq) {
 #pragma unroll
         for (int i2 = 0; i2 < KSW / 2; ++i2) {
-            const int r16 = lane & 15, row = r16 & 7;
-            const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
-            const int k = ks * 32 + 8 * (lane >> 4);
             f[i2].u = make_uint4(0, 0, 0, 0);
-            if (ks < nks && row < Bl) {
-                const unsigned off = (unsigned)((((size_t)tq * B + b0 + row) * hs + (size_t)d * H + k) * 2);
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
+            if (frag_on[i2]) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, frag_off[i2] + (unsigned)tq * row_bytes, 0, 16 /* sc1 */);
                 f[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
     };
+    const unsigned store_off = (unsigned)((((size_t)b0 + b) * hs + (size_t)d * H + j0 + u) * 2);
     Frag ahead[NA];             // gate waves: the next step's first attempt, issued right behind their own h store
     bool have_ahead = false;
 
@@ -1485,7 +1494,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             ASR_ST(3)
             ASR_RAW_BARRIER();
             ASR_ST(4)
-            if (*s_abort) break;
+            if ((s & 15) == 0 && *s_abort) break;      // (every 16 steps: the LDS read sat on the chain behind the barrier; polls give up at once anyway)
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
                 // nest of divergent branches around narrow reads (measured 0.95 us per step)
@@ -1521,9 +1530,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 if (!(u & 1)) {
                     unsigned packed = mine | (other << 16);
                     if (packed == 0xffffffffu) packed = 0x7fc07fc0u;      // (two NaNs of a diverged run) never the sentinel
-                    const size_t o = ((size_t)t * B + b0 + b) * hs + (size_t)d * H + j0 + u;
-                    if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, (unsigned)(o * 2), 0, 0);
-                    else __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
+                    const unsigned ob = store_off + (unsigned)t * row_bytes;
+                    if (local) __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, ob, 0, 0);
+                    else __hip_atomic_store(reinterpret_cast<unsigned*>(reinterpret_cast<char*>(hseq16) + ob), packed, ASR_RLX_AGENT);     // sc1 payload
                 }
             }
             if (PAIRED && dp && s + 1 < T) {     // row t is what step s + 1 reads: ask for it before the LDS bookkeeping below
@@ -1732,7 +1741,7 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
                     if (lane < 16) part[(((dp ? (s & 1) * 8 : 0) + w) * 6 + tl) * 16 + lane] = make_float4(acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]);     // live rows 0..3 only
             }
             ASR_RAW_BARRIER();
-            if (*s_abort) break;
+            if ((s & 15) == 0 && *s_abort) break;      // (every 16 steps: the LDS read sat on the chain behind the barrier; polls give up at once anyway)
             if (act) {
                 const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 8 * 6 * 16 : 0)) + ((u >> 4) * 16 + (u & 15)) * 4 + b;
 #pragma unroll
