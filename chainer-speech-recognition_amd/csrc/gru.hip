@@ -1085,6 +1085,18 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
     // data polling (forge bit 8, see fwd_persistent_io_kernel): dgh arrives filled with 0xffff and is its own signal
     const bool dp = local && (forge & 8) != 0;
 
+    // byte offsets inside dgh (< 2^31, can_persist) kept per lane and stepped by one (t) row: no 64-bit products on the chain
+    constexpr int NLc = (KS8 + 3) / 4;
+    const unsigned row_bytes = (unsigned)((size_t)B * gs3 * 2);
+    unsigned frag_off[NLc];
+    bool frag_on[NLc];
+#pragma unroll
+    for (int l = 0; l < NLc; ++l) {
+        const int r16 = lane & 15, row = r16 & 3, i = 4 * l + (r16 >> 2), ks = w * KS8 + i;
+        frag_on[l] = i < KS8 && ks < nks && row < Bl;
+        frag_off[l] = (unsigned)((((size_t)b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
+    }
+    const unsigned store_off = (unsigned)((((size_t)b0 + b) * gs3 + (size_t)d * 3 * H + j) * 2);
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? t + 1 : t - 1;
@@ -1109,16 +1121,13 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
                 constexpr int NL = (KS8 + 3) / 4;
                 Frag a[NL];
-                const int r16 = lane & 15, row = r16 & 3, sl4 = r16 >> 2;
                 unsigned spins = 0;
                 auto fetch = [&]() {        // (first attempt outside the retry loop: see fwd_persistent_io_kernel)
 #pragma unroll
                     for (int l = 0; l < NL; ++l) {
-                        const int i = 4 * l + sl4, ks = w * KS8 + i;
                         a[l].u = make_uint4(0, 0, 0, 0);
-                        if (i < KS8 && ks < nks && row < Bl) {
-                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
+                        if (frag_on[l]) {
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, frag_off[l] + (unsigned)tn * row_bytes, 0, 16 /* sc1 */);
                             a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
                         }
                     }
@@ -1188,21 +1197,22 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 if (pz_ == 0xffffffffu) pz_ = 0x7fc07fc0u;
                 if (pq_ == 0xffffffffu) pq_ = 0x7fc07fc0u;
             }
-            const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
+            const unsigned ob = store_off + (unsigned)t * row_bytes;
+            char* dghb = reinterpret_cast<char*>(dgh);
             unsigned* od = oring + (size_t)(s & 1) * 3 * 4 * 16 + b * 16 + (u0 >> 1);
             if (act && !odd) {
                 if (local) {
-                    __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, ob, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, ob + 2u * (unsigned)H, 0, 0);
                 } else {
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dghb + ob), pr_, ASR_RLX_AGENT);
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(dghb + ob + 2u * (unsigned)H), pz_, ASR_RLX_AGENT);
                 }
                 od[0] = pr_;
             }
             if (act && odd) {
-                if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
-                else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
+                if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, ob + 4u * (unsigned)H, 0, 0);
+                else __hip_atomic_store(reinterpret_cast<unsigned*>(dghb + ob + 4u * (unsigned)H), pq_, ASR_RLX_AGENT);
                 od[4 * 16] = pz_; od[2 * 4 * 16] = pn_;
             }
             if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
