@@ -573,6 +573,11 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
 }
 
 // rows r and r + 8 of every 16-lane row swap places (DPP row_ror:8), for all four dwords of a fragment
+// value of lane ^ 1 through DPP quad_perm [1,0,3,2]: __shfl_xor compiles to ds_bpermute, an LDS round trip on the chain
+// between the gate math and the payload store
+__device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
 __device__ __forceinline__ uint4 swap_half_rows(uint4 v) {
     uint4 r;
     r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x128, 0xF, 0xF, false);
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_
             }
             // neighbouring lanes hold the two units of a pair: the even lane stores r and z, the odd lane q and n
             const unsigned m1 = (unsigned)ar | ((unsigned)az << 16), m2 = (unsigned)an | ((unsigned)aq << 16);
-            const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
+            const unsigned o1 = lane_xor1_u32(m1), o2 = lane_xor1_u32(m2);
             const bool odd = u0 & 1;
             const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;   // e: even unit, d: odd unit
             const unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
@@ -1187,7 +1192,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
             if (act) { sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq); }
             const unsigned m1 = (unsigned)ar | ((unsigned)az << 16), m2 = (unsigned)an | ((unsigned)aq << 16);
-            const unsigned o1 = (unsigned)__shfl_xor((int)m1, 1), o2 = (unsigned)__shfl_xor((int)m2, 1);
+            const unsigned o1 = lane_xor1_u32(m1), o2 = lane_xor1_u32(m2);
             const bool odd = u0 & 1;
             const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;
             unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
@@ -1535,7 +1540,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             hprev = h;
             ASR_ST(5)
             const unsigned mine = (unsigned)f32_to_bf16(h);
-            const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+            const unsigned other = lane_xor1_u32(mine);
             if (act) {
                 if (!(u & 1)) {
                     unsigned packed = mine | (other << 16);
@@ -1772,7 +1777,7 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
             const float h = (1.0f - z) * n + z * hprev;
             hprev = h;
             const unsigned mine = (unsigned)f32_to_bf16(h);
-            const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+            const unsigned other = lane_xor1_u32(mine);
             if (act) {
                 if (!(u & 1)) {
                     unsigned packed = mine | (other << 16);
