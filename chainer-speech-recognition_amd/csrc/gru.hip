@@ -573,6 +573,13 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
 }
 
 // rows r and r + 8 of every 16-lane row swap places (DPP row_ror:8), for all four dwords of a fragment
+// volatile accesses to an LDS word THROUGH THE LDS ADDRESS SPACE: a cast to `volatile int*` makes the pointer generic and the
+// access a flat_load / flat_store with sc0 sc1 followed by s_waitcnt vmcnt(0) -- on the gate waves that drained their own
+// payload store before the next hand-off loads could be issued
+typedef __attribute__((address_space(3))) volatile int lds_vint;
+__device__ __forceinline__ int lds_peek(const int* p) { return *(const lds_vint*)(const __attribute__((address_space(3))) int*)p; }
+__device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribute__((address_space(3))) int*)p = v; }
+
 // value of lane ^ 1 through DPP quad_perm [1,0,3,2]: __shfl_xor compiles to ds_bpermute, an LDS round trip on the chain
 // between the gate math and the payload store
 __device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
@@ -1383,10 +1390,11 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
         frag_on[i2] = ks < nks && row < Bl;
         frag_off[i2] = (unsigned)((((size_t)b0 + row) * hs + (size_t)d * H + ks * 32 + 8 * (lane >> 4)) * 2);
     }
+    // (no zeroing here: a lane whose fragment is off never loads, so the zeros its registers start with stay; writing them
+    // again each step made the compiler wait vmcnt(0) -- for the h store just issued -- in front of these loads)
     auto fetch_row = [&](Frag (&f)[NA], int tq) {
 #pragma unroll
         for (int i2 = 0; i2 < KSW / 2; ++i2) {
-            f[i2].u = make_uint4(0, 0, 0, 0);
             if (frag_on[i2]) {
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, frag_off[i2] + (unsigned)tq * row_bytes, 0, 16 /* sc1 */);
                 f[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
@@ -1394,7 +1402,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
         }
     };
     const unsigned store_off = (unsigned)((((size_t)b0 + b) * hs + (size_t)d * H + j0 + u) * 2);
-    Frag ahead[NA];             // gate waves: the next step's first attempt, issued right behind their own h store
+    Frag ahead[NA], acur[NA];   // ahead: (gate waves) the next step's first attempt, issued right behind their own h store
+#pragma unroll
+    for (int i2 = 0; i2 < NA; ++i2) { ahead[i2].u = make_uint4(0, 0, 0, 0); acur[i2].u = make_uint4(0, 0, 0, 0); }
     bool have_ahead = false;
 
     for (int s = 0; s < T; ++s) {
@@ -1422,7 +1432,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
-                    Frag a[NA];
+                    Frag (&a)[NA] = acur;
                     unsigned spins = 0;
                     // the first attempt is issued outside the retry loop: at a loop header the compiler waits vmcnt(0) for
                     // the registers it is about to reload, which on the gate waves also drains their own h store (gfx9
@@ -1436,9 +1446,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                         // 1.01 retries) while the producers are still in their gate phase: they wait on an LDS word that
                         // the gate waves of THIS workgroup raise when they store (all workgroups are in step), then ask
                         if (dp) {
-                            volatile int* go = s_abort + 2;
                             unsigned nap = 0;
-                            while ((go[0] < s || go[1] < s) && !*(volatile int*)s_abort && ++nap < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+                            while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
+                                __builtin_amdgcn_s_sleep(1);
                         }
                         fetch();
                     }
@@ -1541,6 +1551,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             ASR_ST(5)
             const unsigned mine = (unsigned)f32_to_bf16(h);
             const unsigned other = lane_xor1_u32(mine);
+            // nothing of this wave is in flight here (its loads fed the MFMAs); saying so keeps the compiler from waiting
+            // vmcnt(0) -- i.e. for the store below -- when it next writes a register that once was a load destination
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             if (act) {
                 if (!(u & 1)) {
                     unsigned packed = mine | (other << 16);
@@ -1551,7 +1564,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
                 }
             }
             if (PAIRED && dp && s + 1 < T) {     // row t is what step s + 1 reads: ask for it before the LDS bookkeeping below
-                if (lane == 0) *(volatile int*)(s_abort + w) = s + 1;       // (waves 2 and 3 -> words 2 and 3)
+                if (lane == 0) lds_poke(s_abort + w, s + 1);       // (waves 2 and 3 -> words 2 and 3)
                 fetch_row(ahead, t);
                 have_ahead = true;
             }
