@@ -1086,6 +1086,8 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
+        s_abort[2] = 0;
+        s_abort[3] = 0;
         if (LOCAL) {
             const int v = decide_local(sync, rec, nwg, abort_word, (forge & 1) ? 2 + (slot & 1) : 0);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
@@ -1109,6 +1111,20 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
         frag_off[l] = (unsigned)((((size_t)b0 + row) * gs3 + (size_t)d * 3 * H + ks * 32 + 8 * (lane >> 4)) * 2);
     }
     const unsigned store_off = (unsigned)((((size_t)b0 + b) * gs3 + (size_t)d * 3 * H + j) * 2);
+    // hand-off fragments: zeroed ONCE (a lane whose fragment is off never loads); `ahead` = the gate waves' first attempt for
+    // the next step, issued right behind their own stores (see fwd_persistent_io_kernel)
+    Frag acur[NLc], ahead[NLc];
+#pragma unroll
+    for (int l = 0; l < NLc; ++l) { acur[l].u = make_uint4(0, 0, 0, 0); ahead[l].u = make_uint4(0, 0, 0, 0); }
+    bool have_ahead = false;
+    auto fetch_row = [&](Frag (&f)[NLc], int tq) {
+#pragma unroll
+        for (int l = 0; l < NLc; ++l)
+            if (frag_on[l]) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, frag_off[l] + (unsigned)tq * row_bytes, 0, 16 /* sc1 */);
+                f[l].u = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+    };
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const int tn = d == 0 ? t + 1 : t - 1;
@@ -1132,19 +1148,21 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             if (is_compute) {
                 f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
                 constexpr int NL = (KS8 + 3) / 4;
-                Frag a[NL];
+                Frag (&a)[NL] = acur;
                 unsigned spins = 0;
-                auto fetch = [&]() {        // (first attempt outside the retry loop: see fwd_persistent_io_kernel)
+                auto fetch = [&]() { fetch_row(a, tn); };       // (first attempt outside the retry loop: see fwd_persistent_io_kernel)
+                if (have_ahead) {
 #pragma unroll
-                    for (int l = 0; l < NL; ++l) {
-                        a[l].u = make_uint4(0, 0, 0, 0);
-                        if (frag_on[l]) {
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, frag_off[l] + (unsigned)tn * row_bytes, 0, 16 /* sc1 */);
-                            a[l].u = make_uint4(v[0], v[1], v[2], v[3]);
-                        }
+                    for (int l = 0; l < NL; ++l) a[l].u = ahead[l].u;
+                } else {
+                    if (dp) {       // pure compute waves: start when this workgroup's gate waves have stored (all are in step)
+                        unsigned nap = 0;
+                        while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
+                            __builtin_amdgcn_s_sleep(1);
                     }
-                };
-                fetch();
+                    fetch();
+                }
+                have_ahead = false;
                 while (dp) {
                     bool missing = false;
 #pragma unroll
@@ -1211,6 +1229,7 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
             }
             const unsigned ob = store_off + (unsigned)t * row_bytes;
             char* dghb = reinterpret_cast<char*>(dgh);
+            __builtin_amdgcn_s_waitcnt(0x0F70);      // nothing of this wave is in flight here: clears the compiler's scoreboard
             unsigned* od = oring + (size_t)(s & 1) * 3 * 4 * 16 + b * 16 + (u0 >> 1);
             if (act && !odd) {
                 if (local) {
@@ -1226,6 +1245,11 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
                 if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, ob + 4u * (unsigned)H, 0, 0);
                 else __hip_atomic_store(reinterpret_cast<unsigned*>(dghb + ob + 4u * (unsigned)H), pq_, ASR_RLX_AGENT);
                 od[4 * 16] = pz_; od[2 * 4 * 16] = pn_;
+            }
+            if (dp && s + 1 < T) {      // row t is what step s + 1 reads
+                if (lane == 0) lds_poke(s_abort + w, s + 1);       // (waves 2 and 3 -> words 2 and 3)
+                fetch_row(ahead, t);
+                have_ahead = true;
             }
             if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
