@@ -259,6 +259,11 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kSpinLimit = 1u << 19;
 constexpr int kPersistLds = 96 * 1024;
+// The wide backward kernel asks for so much LDS that no GEMM workgroup (36..64 KB) fits beside it on a CU.  Sharing the
+// CU paid while the recurrence waited on memory ("Co-residency"); once its step had become an
+// instruction chain on the gate waves, a weight-gradient GEMM beside it cost 27 % per launch (22.4 vs 20.5 ms per train
+// step), so the GEMMs of the side stream now run between the recurrences.
+constexpr int kExclusiveLds = 132 * 1024;
 constexpr size_t kShardBytes = 16 * 8 * 128;      // 16 recurrences x 8 shards x one 128-B line
 
 #define ASR_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
@@ -2522,8 +2527,8 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
 #define ASR_BWDW(K)                                                                                                       \
     do {                                                                                                                  \
         if (local) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)bwd_wide_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_wide_kernel<K, true>), wgrid, wblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
+            (void)hipFuncSetAttribute((const void*)bwd_wide_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kExclusiveLds); \
+            hipLaunchKernelGGL((bwd_wide_kernel<K, true>), wgrid, wblock, kExclusiveLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
                                (unsigned*)sync_ws, T, B, H, ndir, forge);                                                         \
         } else {                                                                                                          \
