@@ -443,7 +443,7 @@ __device__ __forceinline__ bf16x4 lds_tr16(const uint16_t* p) {
 // (t, b, h) over the output positions, column = (kh, kw, c) -- the weight gradient of a convolution without a column
 // matrix in memory (1.2 GB written and read back per step for the second conv layer otherwise).
 template <bool CONV>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                       const uint16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                       int ldc, int M, int N, int K, int tiles_n, int k_per_split,
                                                       ConvDesc cd) {
@@ -614,10 +614,10 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     return ASR_OK;
 }
 
-// split K so that about 4 workgroups per CU are in flight: a multiple of 8 splits (one set per XCD) where K allows, each
+// split K so that about 3 workgroups per CU are in flight: a multiple of 8 splits (one set per XCD) where K allows, each
 // split a multiple of the k tile
 static int tn_splits(int tiles, int K, int& k_per_split) {
-    int splits = cdiv(1024, tiles);
+    int splits = cdiv(768, tiles);      // (3 workgroups per CU; 1024 was 5..17 % slower on the step's shapes, 512 hurt M = 3000)
     splits = cdiv(splits, 8) * 8;
     const int max_splits = cdiv(K, 8 * TK);
     if (splits > max_splits) splits = max_splits;
