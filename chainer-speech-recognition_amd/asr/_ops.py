@@ -183,6 +183,25 @@ def pooled_height(Hin, k):
     return 1 if Hin <= k else -(-(Hin - k) // k) + 1
 
 
+def maxout2_pool_ok(x):
+    return x.dtype == BF16 and x.dim() == 4 and x.is_contiguous() and x.shape[3] % 16 == 0
+
+
+def maxout2_pool_fwd(x, k):
+    """x (T, B, H, 2C) bf16 -> (T, B, ceil(H / k), C): Maxout(2) then MaxPooling2D((k, 1)) in one pass."""
+    T, B, H, C2 = x.shape
+    y = torch.empty((T, B, pooled_height(H, k), C2 // 2), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_maxout2_pool_fwd(stream(), ptr(x), ptr(y), T * B, H, C2 // 2, k), "asr_maxout2_pool_fwd")
+    return y
+
+
+def maxout2_pool_bwd(x, dy, k):
+    T, B, H, C2 = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_maxout2_pool_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), T * B, H, C2 // 2, k), "asr_maxout2_pool_bwd")
+    return dx
+
+
 def maxpool_h_fwd(x, k):
     """x (T, B, H, C) bf16 -> (T, B, Hout, C)."""
     assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4

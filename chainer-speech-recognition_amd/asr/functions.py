@@ -450,6 +450,29 @@ class _MaxPoolH(torch.autograd.Function):
         return _ops.maxpool_h_bwd(p, gy.contiguous(), ctx.k), None
 
 
+class _Maxout2PoolH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, k):
+        ctx.save_for_backward(p)
+        ctx.k = k
+        return _ops.maxout2_pool_fwd(p, k)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        return _ops.maxout2_pool_bwd(p, gy.contiguous(), ctx.k), None
+
+
+def maxout_max_pooling(x, k):
+    """maxout(x, 2) followed by max_pooling_2d(., (k, 1)) -- the tail of every conv block of the recipes -- as one pass
+    over the convolution output (asr.nn containers use it when the two layers follow each other); falls back to the two
+    functions when the layout does not allow the fused kernels."""
+    p = phys4(x)
+    if _ops.maxout2_pool_ok(p):
+        return logical4(_Maxout2PoolH.apply(p, int(k)))
+    return max_pooling_2d(maxout(x, 2), (k, 1))
+
+
 def max_pooling_2d(x, ksize, stride=None, pad=0, cover_all=True):
     """chainer.functions.max_pooling_2d restricted to what the reference uses: ksize (k, 1), stride = ksize,
     pad 0, cover_all True (asr/nn/nn.py:95-103 passes nothing else)."""

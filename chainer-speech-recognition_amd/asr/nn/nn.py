@@ -201,13 +201,41 @@ class Residual(object):
         return x
 
 
+def _fusable_pool(layers, i):
+    """index of the MaxPooling2D((k, 1)) that follows the Maxout(2) at layers[i] (identity Dropout(0) layers in between
+    are skipped), or -1"""
+    if type(layers[i]).__name__ != "Maxout" or layers[i].pool_size != 2:
+        return -1
+    j = i + 1
+    while j < len(layers) and type(layers[j]).__name__ == "Dropout" and layers[j].ratio == 0:
+        j += 1
+    if j >= len(layers) or type(layers[j]).__name__ != "MaxPooling2D":
+        return -1
+    pool = layers[j]
+    ks = pool.ksize if isinstance(pool.ksize, (tuple, list)) else (pool.ksize, pool.ksize)
+    if len(ks) != 2 or ks[1] != 1 or pool.stride is not None or pool.pad not in (0, (0, 0)):
+        return -1
+    return j
+
+
 def _apply_layers(layers, x):
-    """asr/nn/nn.py:322-328 / 408-414: sequential application; a Residual layer adds its input."""
-    for layer in layers:
+    """asr/nn/nn.py:322-328 / 408-414: sequential application; a Residual layer adds its input.  Maxout(2) directly
+    followed by MaxPooling2D((k, 1)) runs as one pass (functions.maxout_max_pooling): same values, one read of the
+    convolution output instead of a write and two reads more."""
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
+        j = _fusable_pool(layers, i) if x.dim() == 4 else -1
+        if j > 0:
+            ks = layers[j].ksize
+            x = functions.maxout_max_pooling(x, ks[0] if isinstance(ks, (tuple, list)) else ks)
+            i = j + 1
+            continue
         y = layer(x)
         if isinstance(layer, Residual):
             y = functions.add(y, x)
         x = y
+        i += 1
     return x
 
 

@@ -168,6 +168,10 @@ int asr_conv_tn_acc(void* stream, const void* g, int ldg, const void* x, float* 
 int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp, int Cs);
 int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);
 int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out);
+/* Maxout(2) + MaxPooling2D((k, 1)) in one pass: x (R, Hin, 2C) bf16 -> y (R, ceil(Hin / k), C); C % 8 == 0 (else
+ * ASR_ERR_UNSUPPORTED: use the two calls).  Same results and tie rules as asr_maxout2_* followed by asr_maxpool_h_*. */
+int asr_maxout2_pool_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
+int asr_maxout2_pool_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
 int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
 int asr_maxpool_h_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
 int asr_add_bf16(void* stream, const void* a, const void* b, void* y, long long n);

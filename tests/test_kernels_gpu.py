@@ -214,6 +214,48 @@ def test_layernorm_one_sweep_backward(device, rows, D, C):
     np.testing.assert_allclose(db2.cpu().numpy() - 1.0, dbeta.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("T,B,H,C,k", [(7, 3, 38, 64, 3), (5, 2, 13, 16, 2), (4, 2, 11, 24, 3), (3, 1, 4, 8, 2), (6, 2, 6, 32, 1)])
+def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
+    """asr_maxout2_pool_fwd / _bwd against asr_maxout2_* followed by asr_maxpool_h_* (cover_all windows, ties included):
+    bit-identical outputs and input gradients"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(T * 100 + H)
+    x = torch.randn(T, B, H, 2 * C, generator=g)
+    x = (x * 2).round() / 2                     # many exact ties inside pairs and windows
+    xd = x.to(device).to(torch.bfloat16)
+    assert _ops.maxout2_pool_ok(xd)
+    y_ref = _ops.maxpool_h_fwd(_ops.maxout2_fwd(xd), k)
+    y = _ops.maxout2_pool_fwd(xd, k)
+    assert y.shape == y_ref.shape and torch.equal(y, y_ref)
+    gy = torch.randn(y.shape, generator=g).to(device).to(torch.bfloat16)
+    mid = _ops.maxout2_fwd(xd)
+    dx_ref = _ops.maxout2_bwd(xd, _ops.maxpool_h_bwd(mid, gy, k))
+    dx = _ops.maxout2_pool_bwd(xd, gy, k)
+    assert torch.equal(dx, dx_ref)
+
+
+def test_layer_stack_fuses_maxout_and_pooling(device):
+    """nn containers run Maxout(2) [+ Dropout(0)] + MaxPooling2D((k, 1)) as one pass: same output and gradient as the layers
+    applied one by one"""
+    from asr import nn, functions as F
+    from asr.nn.nn import _fusable_pool
+    torch.manual_seed(2)
+    x = torch.randn(2, 32, 13, 9).to(device).to(torch.bfloat16)      # logical (B, 2C, H, T)
+    layers = [nn.Maxout(2), nn.Dropout(0), nn.MaxPooling2D(ksize=(3, 1))]
+    assert _fusable_pool(layers, 0) == 2
+    xa = x.clone().requires_grad_(True)
+    ya = nn.Module(*layers)(xa)
+    xb = x.clone().requires_grad_(True)
+    yb = F.max_pooling_2d(F.maxout(xb, 2), (3, 1))
+    assert ya.shape == yb.shape and torch.equal(ya, yb)
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.equal(xa.grad, xb.grad)
+    assert _fusable_pool([nn.Maxout(2), nn.Dropout(0.5), nn.MaxPooling2D(ksize=(3, 1))], 0) == -1
+    assert _fusable_pool([nn.Maxout(2), nn.MaxPooling2D(ksize=(3, 1), stride=2)], 0) == -1
+
+
 # 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
 # 4: persistent with the XCD-local hand-off where placement allows, signalled by flags; 8: the same with the payload as its
 # own signal (= automatic); 7: 4 with a forged split placement
