@@ -59,7 +59,7 @@ class Census(object):
         for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd",
                      "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "clip_decay_adam",
                      "sqnorm_acc", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
-                     "conv_weight_pack_bwd", "conv_tn_acc"):
+                     "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd"):
             fn = getattr(ops, name)
             self._orig[name] = fn
             setattr(ops, name, self._timed(name, fn))
