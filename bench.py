@@ -179,7 +179,7 @@ def main():
     from asr.loss import connectionist_temporal_classification
     from asr.model import ds2
     from asr.optimizers import Adam, GradientClipping, WeightDecay
-    from oracle.model import synthetic_batch
+    from asr.data.synthetic import synthetic_batch
     _lib.lib()      # fail loudly if the HIP library is missing
 
     comm = None

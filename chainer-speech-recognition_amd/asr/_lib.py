@@ -20,6 +20,7 @@ c_longlong = ctypes.c_longlong
 SIGNATURES = {
     "asr_version": (c_int, []),
     "asr_stream_delay": (c_int, [c_void_p, c_int]),
+    "asr_occupy_cus": (c_int, [c_void_p, c_int, c_int, c_int]),
     "asr_ctc_workspace_bytes": (c_size_t, [c_int] * 5),
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
     "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),
@@ -86,6 +87,10 @@ SIGNATURES = {
     "asr_sqnorm_acc": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p]),
     "asr_clip_decay_sgd": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 5 + [c_void_p]),
     "asr_clip_decay_adam": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 7 + [c_void_p, c_int]),
+    "asr_sqnorm_partials_count": (c_int, [c_longlong]),
+    "asr_step_control": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2),
+    "asr_adam_ctl": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 4 + [c_void_p]),
+    "asr_sgd_ctl": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 3 + [c_void_p]),
 }
 
 _ERRORS = {-1: "bad argument", -2: "workspace too small", -3: "unsupported shape", -4: "kernel launch failed"}

@@ -305,6 +305,18 @@ def gru_poll_status():
             st[1] = ev
 
 
+# asr.parallel hangs two callables here during a data-parallel backward pass: "before" runs before a recurrence is
+# queued (the launch stream then waits for every collective in flight), "after" right behind it (complete gradient slices
+# are all-reduced in the gap that follows).  A persistent recurrence wants every CU; see asr/parallel.py.
+RECURRENCE_HOOKS = {"before": None, "after": None}
+
+
+def _hook(name):
+    fn = RECURRENCE_HOOKS[name]
+    if fn is not None:
+        fn()
+
+
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
@@ -330,6 +342,18 @@ def gru_check_sync():
         raise _lib.AsrHipError("persistent GRU kernel timed out waiting for another workgroup")
 
 
+def gru_check_all():
+    """synchronising check of EVERY control buffer of this process: the evaluation path calls it where it reads results back
+    anyway (asr.error.compute_minibatch_error), because forward-only loops never reach optimizer.update's polling"""
+    bad = []
+    for key, buf in list(_SYNC.items()):
+        if int(buf[1023:1024].cpu()[0]) != 0:
+            buf[1023:1024].zero_()
+            bad.append(key)
+    if bad:
+        raise _lib.AsrHipError("a persistent GRU kernel gave up an in-launch wait: the outputs of that forward pass are invalid")
+
+
 def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
     """db_ih / db_hh: (ndir * 3H) f32 buffers the bias gradients are accumulated into (optional)."""
     dev = dy.device
@@ -337,9 +361,11 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
+    _hook("before")
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
                                 ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_bwd")
+    _hook("after")
     LAST_SYNC[0] = sync
     return dgi, dgh
 
@@ -359,6 +385,35 @@ def clip_decay_adam(p, g, m, v, alpha, beta1, beta2, eps, weight_decay, clip, gr
     rc = _lib.lib().asr_clip_decay_adam(stream(), ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), alpha, beta1, beta2, eps,
                                         weight_decay, clip, grad_scale, ptr(sqnorm), int(step))
     check(rc, "asr_clip_decay_adam")
+
+
+def abort_words():
+    """device pointers of the abort words of every control buffer a recurrence of this process has used (asr_hip.h: sync_ws
+    int 1023) -- what asr_step_control looks at to drop a step whose recurrences gave up"""
+    return [buf[1023:1024] for buf in _SYNC.values()]
+
+
+def step_control(g, partials, clip, grad_scale, alpha, beta1, beta2, applied, ctl):
+    words = [w for w in abort_words() if w.device == g.device][:2]
+    a0 = ptr(words[0]) if len(words) > 0 else None
+    a1 = ptr(words[1]) if len(words) > 1 else None
+    rc = _lib.lib().asr_step_control(stream(), ptr(g), g.numel(), ptr(partials), a0, a1, float(clip), float(grad_scale),
+                                     float(alpha), float(beta1), float(beta2), ptr(applied), ptr(ctl))
+    check(rc, "asr_step_control")
+
+
+def sqnorm_partials_count(n):
+    return int(_lib.lib().asr_sqnorm_partials_count(int(n)))
+
+
+def adam_ctl(p, g, m, v, beta1, beta2, eps, weight_decay, ctl):
+    rc = _lib.lib().asr_adam_ctl(stream(), ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), beta1, beta2, eps, weight_decay, ptr(ctl))
+    check(rc, "asr_adam_ctl")
+
+
+def sgd_ctl(p, g, v, kind, lr, momentum, weight_decay, ctl):
+    rc = _lib.lib().asr_sgd_ctl(stream(), ptr(p), ptr(g), ptr(v), p.numel(), int(kind), lr, momentum, weight_decay, ptr(ctl))
+    check(rc, "asr_sgd_ctl")
 
 
 def sru_fwd(x, U, bias, c0, mask, use_tanh):

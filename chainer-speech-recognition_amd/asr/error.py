@@ -70,6 +70,7 @@ def compute_minibatch_error(y_batch, t_batch, BLANK, vocab_token_to_id, vocab_id
         pred_len = torch.tensor([len(r) for r in rows], dtype=torch.int32, device=dev)
     dist = _ops.edit_distance(true, true_len, pred, pred_len)
     d, n = dist.cpu().numpy().astype(np.float64), true_len.cpu().numpy()
+    _ops.gru_check_all()        # the ids came from a forward pass nobody else checks: raise if a recurrence gave up a wait
     per = np.where(n > 0, d / np.maximum(n, 1), d)         # len(r) == 0: the distance is len(h), returned as it is
     if print_sequences and vocab_id_to_token is not None:
         ph, pl, th, tl = pred.cpu().numpy(), pred_len.cpu().numpy(), true.cpu().numpy(), true_len.cpu().numpy()

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _ops
-from .link import grad_buffer
+from .link import grad_buffer, grads_queued
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -312,8 +312,10 @@ class _Conv2D(torch.autograd.Function):
         if w_is_param:
             with _OnSide(g2, col):
                 weight_grads()
+            grads_queued(W, b)
         else:
             weight_grads()
+            grads_queued(b)
         return gx, (None if w_is_param else gW), None, None, None, None, None, None, None, None, None
 
 
@@ -393,6 +395,7 @@ class _Dense(torch.autograd.Function):
             _ops.gemm_tn_acc(gy, x2, gW)
             if gb is not None:
                 _ops.colsum_acc(gy, gb)
+        grads_queued(W, b)
         return gx, None, None, None, None, None
 
 
@@ -612,6 +615,7 @@ class _LayerNorm(torch.autograd.Function):
         handover = mailbox is not None and need_dx      # the producer of x2 takes its gradient in bf16
         dx = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, BF16 if handover else x2.dtype,
                                 grad_buffer(gamma), grad_buffer(beta), need_dx)
+        grads_queued(gamma, beta)
         if handover:
             mailbox.post(dx)
             dx = _zero_token(x2.shape, x2.device)
@@ -662,6 +666,7 @@ class _BatchNorm(torch.autograd.Function):
         if not train:
             raise RuntimeError("backward through BatchNormalization in test mode is not supported (fixed statistics)")
         dx = _ops.batchnorm_bwd(x2, gy, mean, rstd, gamma.detach(), grad_buffer(gamma), grad_buffer(beta), need_dx)
+        grads_queued(gamma, beta)
         return dx, None, None, None, None, None, None, None
 
 
@@ -735,6 +740,7 @@ class _GRU(torch.autograd.Function):
                         _ops.gemm_tn_acc(a[B:], h[:-B], gwhh[d])
                     else:
                         _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
+        grads_queued(w_ih, w_hh, b_ih, b_hh)
         return gx, None, None, None, None, None, None, None, None, None
 
 

@@ -65,6 +65,16 @@ class Link(torch.nn.Module):
             if p.grad is not None:
                 p.grad = None
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """torch's load_state_dict on a freshly built model: a lazily sized parameter (still empty) takes the stored shape
+        first, as Chainer's deserialiser initialises uninitialised parameters from the file."""
+        for name, p in self._parameters.items():
+            src = state_dict.get(prefix + name)
+            if p is not None and p.numel() == 0 and src is not None and src.numel() > 0:
+                p.data = torch.empty(src.shape, dtype=p.dtype, device=p.device)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        bump_weight_epoch()
+
     # -- compute copies ------------------------------------------------------------------------------
     def compute_copy(self, key, param, maker, layout=None):
         """bf16 (possibly re-laid-out) copy of a parameter, rebuilt only when the parameter changed.
@@ -162,10 +172,15 @@ class Chain(Link):
 _GRAD_LISTENER = [None]      # asr.parallel.Communicator hooks in here to overlap the all-reduce with backward
 
 
+def grads_queued(*params):
+    """A backward function calls this AFTER it has queued the last kernel (on the launch stream or a side stream) that
+    writes the gradients of `params`: from here on a data-parallel all-reduce of them may be queued (asr/parallel.py)."""
+    if _GRAD_LISTENER[0] is not None:
+        _GRAD_LISTENER[0]([p for p in params if p is not None])
+
+
 def grad_buffer(param):
     """The f32 buffer the backward kernels accumulate this parameter's gradient into (param.grad)."""
-    if _GRAD_LISTENER[0] is not None:
-        _GRAD_LISTENER[0](param)
     if param.grad is None:
         from . import _ops
         g = torch.empty_like(param, memory_format=torch.contiguous_format)

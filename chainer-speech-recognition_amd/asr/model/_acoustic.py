@@ -1,9 +1,6 @@
 """Shared tail of the AcousticModel classes: turn the stack's (B, V, 1, T) output into what the CTC losses take
 (asr/model/cnn.py:33-49, asr/model/sru.py:29-45) and atomic save / load (asr/model/cnn.py:51-63)."""
 import os
-import uuid
-
-import torch
 
 from .. import nn
 
@@ -54,17 +51,18 @@ def split_output(out_data, batchsize, seq_length, split_into_variables):
 
 
 def save_atomic(module, filename):
-    tmp_filename = str(uuid.uuid4())
-    torch.save(module.state_dict(), tmp_filename)
-    if os.path.isfile(filename):
-        os.remove(filename)
-    os.rename(tmp_filename, filename)
+    """asr/model/cnn.py:51-56: written under a temporary name, then renamed; the reference's parameter paths
+    (asr/serializers.py)"""
+    from .. import serializers
+    serializers.save(filename, module)
 
 
 def load_if_exists(module, filename):
+    """asr/model/cnn.py:58-63; works on a freshly built model (lazily sized parameters take the file's shapes)"""
     if os.path.isfile(filename):
         print("Loading {} ...".format(filename))
-        module.load_state_dict(torch.load(filename, map_location="cpu"))
+        from .. import serializers
+        serializers.load(filename, module)
         return True
     return False
 

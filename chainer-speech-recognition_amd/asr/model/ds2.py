@@ -43,6 +43,11 @@ class Model(nn.Module):
             )
             in_ch = config.ndim_conv
         self.conv_blocks = conv_blocks
+        height = config.num_mel_filters
+        for pool in pools:          # pad_h = 0 convolution, then cover_all pooling
+            height -= kernel_size[0] - 1
+            height = 1 if height <= pool else -(-(height - pool) // pool) + 1
+        self._merged = (config.ndim_conv, height)
 
         rnn_blocks = nn.Module()
         rnn_cls = nn.BiGRU if config.bidirectional else nn.GRU
@@ -69,6 +74,12 @@ class Model(nn.Module):
         out_data = self.dense_blocks(out_data)
         assert out_data.shape[2] == seq_length
         return split_output(out_data, batchsize, seq_length, split_into_variables)
+
+    def column_permutations(self):
+        """parameters whose last axis indexes the merged (channel, height) features of the conv stack: {name: (C, H)}.
+        The reference's ``reshape(out, (B, -1, T))`` (run/ctc/sru/model.py:114) orders them (c, h), the physical layout here
+        (h, c) -- asr/serializers.py stores the reference's order."""
+        return {"rnn_blocks._sequential_0.w_ih": (self._merged[0], self._merged[1])}
 
     def save(self, filename):
         save_atomic(self, filename)

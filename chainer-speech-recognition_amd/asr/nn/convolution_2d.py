@@ -7,7 +7,7 @@
 import torch
 
 from .. import functions, _ops
-from ..link import Link, Parameter, get_initializer, grad_buffer
+from ..link import Link, Parameter, get_initializer, grad_buffer, grads_queued
 
 
 def _pair(x):
@@ -59,6 +59,7 @@ class _WeightNorm(torch.autograd.Function):
         (norm,) = ctx.saved_tensors
         V, g = ctx.params
         _ops.weightnorm_bwd(gW.contiguous(), V.detach(), g.detach(), norm, grad_buffer(V), grad_buffer(g))
+        grads_queued(V, g)
         return None, None
 
 

@@ -297,16 +297,16 @@ class Module(Chain):
         super(Module, self).__setattr__(name, value)
 
     def save(self, filename):
-        tmp_filename = filename + "." + str(uuid.uuid4())
-        torch.save(self.state_dict(), tmp_filename)
-        if os.path.isfile(filename):
-            os.remove(filename)
-        os.rename(tmp_filename, filename)
+        """asr/nn/nn.py:394-399 (temporary file + rename), the reference's parameter paths: asr/serializers.py"""
+        from .. import serializers
+        serializers.save(filename, self)
 
     def load(self, filename):
+        """asr/nn/nn.py:401-406"""
         if os.path.isfile(filename):
             print("Loading {} ...".format(filename))
-            self.load_state_dict(torch.load(filename, map_location="cpu"))
+            from .. import serializers
+            serializers.load(filename, self)
             return True
         return False
 

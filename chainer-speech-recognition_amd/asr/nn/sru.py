@@ -7,7 +7,7 @@ Same parameters (W (3D, D) rows [z; f; r], B (2D,) = [b_f; b_r]), same call sign
 import torch
 
 from .. import functions, _ops
-from ..link import Link, Parameter, get_initializer, grad_buffer
+from ..link import Link, Parameter, get_initializer, grad_buffer, grads_queued
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -39,6 +39,7 @@ class SRUFunction(torch.autograd.Function):
         gU, gxh, gc0 = _ops.sru_bwd(x, U, Bias.detach(), C, c0, ctx.mask, gH.contiguous() if gH is not None else None,
                                     gcT.contiguous() if gcT is not None else None, grad_buffer(Bias), use_tanh)
         _ops.gemm_tn_acc(gU, xm.reshape(T * Bn, D), grad_buffer(W))                # asr/nn/sru.py:429
+        grads_queued(W, Bias)
         gx = None
         if need_dx:
             gproj = _ops.gemm_nt(gU, w16t, None, BF16).reshape(T, Bn, D)           # asr/nn/sru.py:421-422

@@ -40,6 +40,7 @@ class Optimizer(object):
         self._flat = None
         self.communicator = None
         self.pipeline = None
+        self._needs_broadcast = False
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -54,7 +55,7 @@ class Optimizer(object):
     def set_communicator(self, comm):
         """Data parallelism: gradients are summed over ranks (RCCL) before the step and scaled by 1/world."""
         self.communicator = comm
-        self._flat = None
+        self._needs_broadcast = comm is not None    # the flat buffer (and the optimiser state with it) stays as it is
 
     def set_pipeline(self, pipeline):
         """asr.pipeline.HalfBatches whose streams carry gradient kernels the update must wait for"""
@@ -77,7 +78,7 @@ class Optimizer(object):
         if self.communicator is not None:
             self.communicator.finish_backward(self)
             scale = 1.0 / self.communicator.size
-        self.t += 1
+        self.t += 1                         # steps ATTEMPTED; the device counts the applied ones (flat["applied"])
         P, G = self._flat["P"], self._flat["G"]
         clip, decay = 0.0, 0.0
         for h in self._hooks:
@@ -85,14 +86,21 @@ class Optimizer(object):
                 clip = float(h.threshold)
             elif isinstance(h, WeightDecay):
                 decay = float(h.rate)
-        # the squared gradient norm is always taken: it drives the clipping and the device-side "skip a non-finite
-        # step" guard (the reference's NaN check, run/ctc/cnn/train.py:193-197, without a host synchronisation)
-        sq = self._flat["sq"]
-        _ops.fill_(sq, 0.0)
-        _ops.sqnorm_acc(G, sq)
-        self._step(P, G, clip, decay, scale, sq)
+        # the squared gradient norm is always taken: it drives the clipping and the device-side "drop this step" decision
+        # (asr_step_control: non-finite norm = the reference's NaN check, run/ctc/cnn/train.py:193-197, or a persistent GRU
+        # launch that gave up a wait and left garbage behind) -- without a host synchronisation
+        alpha, beta1, beta2 = self._control_constants()
+        _ops.step_control(G, self._flat["partials"], clip, scale, alpha, beta1, beta2, self._flat["applied"], self._flat["ctl"])
+        self._step(P, G, decay, self._flat["ctl"])
         bump_weight_epoch()
         refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
+
+    def applied_steps(self):
+        """number of update steps that were not dropped on the device (synchronises: tests / logging only)"""
+        return 0 if self._flat is None else int(self._flat["applied"].cpu()[0])
+
+    def _control_constants(self):
+        return 0.0, 0.0, 0.0
 
     # -- flat buffers ------------------------------------------------------------------------------
     def _params(self):
@@ -102,6 +110,8 @@ class Optimizer(object):
         params = self._params()
         if self._flat is not None and self._flat["ids"] == [id(p) for p in params] and \
                 all(p.data_ptr() == a for p, a in zip(params, self._flat["ptrs"])):
+            if self._needs_broadcast:
+                self._broadcast_state()
             return
         if len(params) == 0:
             raise RuntimeError("optimizer.setup(model) was given a model without initialised parameters")
@@ -123,13 +133,26 @@ class Optimizer(object):
             p.data = view
             p.grad = G[o:o + p.numel()].view(p.shape)
             o += n
+        applied = old["applied"] if old is not None and old["applied"].device == dev else torch.zeros(1, dtype=torch.int32, device=dev)
         self._flat = dict(P=P, G=G, ids=[id(p) for p in params], ptrs=[p.data_ptr() for p in params], offsets=offs,
-                          sizes=sizes, sq=torch.empty(1, dtype=F32, device=dev))
+                          sizes=sizes, numels=[p.numel() for p in params], applied=applied,
+                          ctl=torch.zeros(8, dtype=F32, device=dev),
+                          partials=torch.empty(_ops.sqnorm_partials_count(total), dtype=F32, device=dev))
+        self._flat["sq"] = self._flat["ctl"][4:5]       # squared norm of the (summed) gradient of the last step
         self._init_state(total, dev, old)
         bump_weight_epoch()
         if self.communicator is not None:
-            self.communicator.broadcast(P)
-            bump_weight_epoch()
+            self._broadcast_state()
+
+    def _state_buffers(self):
+        return []
+
+    def _broadcast_state(self):
+        """every rank takes rank 0's parameters, optimiser state and applied-step count"""
+        self._needs_broadcast = False
+        for t in [self._flat["P"], self._flat["applied"]] + [b for b in self._state_buffers() if b is not None]:
+            self.communicator.broadcast(t)
+        bump_weight_epoch()
 
     def cleargrads(self):
         """model.cleargrads() of Chainer: here one fill of the flat gradient buffer."""
@@ -150,7 +173,21 @@ class Optimizer(object):
     def _init_state(self, total, dev, old):
         pass
 
-    def _step(self, P, G, clip, decay, scale, sq):
+    def _carried(self, total, dev, old, previous):
+        """a zeroed state buffer for the new flat layout with the slices of `previous` (the same state under the layout
+        `old`) copied over for every parameter that is still there: a re-flatten -- a lazily sized parameter appeared, a
+        communicator was attached after training had started -- must not forget the accumulated moments"""
+        state = torch.empty(total, dtype=F32, device=dev)
+        _ops.fill_(state, 0.0)
+        if old is not None and previous is not None and previous.device == dev:
+            where = {pid: (o, n) for pid, o, n in zip(old["ids"], old["offsets"], old["numels"])}
+            for pid, o, n in zip(self._flat["ids"], self._flat["offsets"], self._flat["numels"]):
+                src = where.get(pid)
+                if src is not None and src[1] == n:
+                    state[o:o + n].copy_(previous[src[0]:src[0] + n])
+        return state
+
+    def _step(self, P, G, decay, ctl):
         raise NotImplementedError
 
 
@@ -159,14 +196,20 @@ class Adam(Optimizer):
         super().__init__()
         self.alpha, self.beta1, self.beta2, self.eps = alpha, beta1, beta2, eps
 
-    def _init_state(self, total, dev, old):
-        self.m = torch.empty(total, dtype=F32, device=dev)
-        self.v = torch.empty(total, dtype=F32, device=dev)
-        _ops.fill_(self.m, 0.0)
-        _ops.fill_(self.v, 0.0)
+        self.m = self.v = None
 
-    def _step(self, P, G, clip, decay, scale, sq):
-        _ops.clip_decay_adam(P, G, self.m, self.v, self.alpha, self.beta1, self.beta2, self.eps, decay, clip, scale, sq, self.t)
+    def _init_state(self, total, dev, old):
+        self.m = self._carried(total, dev, old, self.m)
+        self.v = self._carried(total, dev, old, self.v)
+
+    def _control_constants(self):
+        return self.alpha, self.beta1, self.beta2
+
+    def _state_buffers(self):
+        return [self.m, self.v]
+
+    def _step(self, P, G, decay, ctl):
+        _ops.adam_ctl(P, G, self.m, self.v, self.beta1, self.beta2, self.eps, decay, ctl)
 
 
 class SGD(Optimizer):
@@ -180,11 +223,13 @@ class SGD(Optimizer):
 
     def _init_state(self, total, dev, old):
         if self.kind:
-            self.vel = torch.empty(total, dtype=F32, device=dev)
-            _ops.fill_(self.vel, 0.0)
+            self.vel = self._carried(total, dev, old, self.vel)
 
-    def _step(self, P, G, clip, decay, scale, sq):
-        _ops.clip_decay_sgd(P, G, self.vel, self.kind, self.lr, self.momentum, decay, clip, scale, sq)
+    def _state_buffers(self):
+        return [self.vel]
+
+    def _step(self, P, G, decay, ctl):
+        _ops.sgd_ctl(P, G, self.vel, self.kind, self.lr, self.momentum, decay, ctl)
 
 
 class MomentumSGD(SGD):

@@ -2,8 +2,25 @@
 
 The reference is single-GPU (no collective anywhere); BASELINE.json adds data-parallel training.
 Utterances shard over ranks (every op of the path is per-utterance, section 8e), the only exchange is the SUM of the
-flat gradient buffer, issued in a few large slices on a side stream as soon as the backward pass has produced them
-(the last layers finish first) and joined before the optimiser kernel, which applies 1/world and the global-norm clip.
+flat gradient buffer, issued in a few large contiguous slices and joined before the optimiser kernels, which apply
+1/world and the global-norm clip to the REDUCED gradient (run/ctc/cnn/train.py:144-145 clips what the optimiser sees).
+
+When a slice may go
+--------------------
+* A slice is *complete* once every parameter in it has been announced by ``link.grads_queued`` -- which the backward
+  functions call AFTER they have queued the last kernel writing those gradients (main stream or side stream).  Round 1
+  announced a parameter when its buffer was asked for, i.e. before the kernels; a slice starting at ``w_hh`` was then
+  reduced before its weight-gradient GEMM had even been queued.
+* Slices go in plan order (last layers first), the same order on every rank.
+* A complete slice is not launched at once but at the next *recurrence boundary*: the persistent GRU kernels want one
+  workgroup on every CU for the whole launch (csrc/gru.hip), so an RCCL kernel that is resident when such a launch starts
+  -- possibly waiting for a slower peer -- would hold CUs the recurrence needs while its other workgroups spin.  Hence
+  (``_ops.RECURRENCE_HOOKS``):  *before* a recurrence is queued the launch stream waits for every collective in flight;
+  *right after* it is queued the complete slices are launched behind it on the communication stream.  A collective
+  therefore runs in the gap between two recurrences, next to the projection and weight-gradient GEMMs of the NEXT layer
+  (which it does not depend on), never beside a recurrence.  What is complete after the last recurrence (the first GRU
+  layer, the convolutions) goes in ``finish_backward``.  A backward pass without recurrences (the convolutional recipes)
+  launches every slice the moment it is complete.
 """
 import os
 
@@ -12,7 +29,7 @@ import torch.distributed as dist
 
 
 class Communicator(object):
-    def __init__(self, backend=None, buckets=4):
+    def __init__(self, backend=None, buckets=4, overlap=True):
         if not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
@@ -22,67 +39,116 @@ class Communicator(object):
         self.rank = dist.get_rank()
         self.size = dist.get_world_size()
         self.buckets = max(1, int(buckets))
+        self.overlap = bool(overlap)
         self._stream = None
         self._pending = []
         self._plan = None
+        self.launch_log = []            # (slice index, parameters announced so far) per launch of the last step: tests
+        self._recurrent = False         # the previous backward pass met a recurrence: defer launches to the boundaries
 
     # -- parameters -------------------------------------------------------------------------------
     def broadcast(self, flat):
         dist.broadcast(flat, src=0)
 
+    def bcast_data(self, model):
+        """ChainerMN's ``comm.bcast_data(model)``: every initialised parameter and persistent buffer takes rank 0's value.
+        Call it after the first forward pass (lazily sized parameters and the data-dependent weight-norm initialisation,
+        asr/nn/convolution_2d.py:177-187, exist only then) and before the first update; ``Optimizer`` does the same for the
+        flat parameter buffer whenever it (re)builds it."""
+        from .link import bump_weight_epoch
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.numel() > 0:
+                dist.broadcast(t.data, src=0)
+        bump_weight_epoch()
+
     # -- gradients --------------------------------------------------------------------------------
-    def _make_plan(self, opt):
-        """contiguous slices of the flat gradient buffer, split at parameter boundaries, last parameters first"""
-        flat = opt._flat
-        offs, sizes = flat["offsets"], flat["sizes"]
-        total = offs[-1] + sizes[-1]
-        target = (total + self.buckets - 1) // self.buckets
+    @staticmethod
+    def make_plan(offsets, sizes, buckets):
+        """contiguous slices [begin, end) of the flat gradient buffer, cut at parameter boundaries, last parameters first:
+        (begin, end, first parameter index, last parameter index)"""
+        total = offsets[-1] + sizes[-1]
+        target = (total + buckets - 1) // buckets
         plan, end = [], total
-        start_idx = len(offs) - 1
+        last = len(offsets) - 1
         acc = 0
-        for i in range(len(offs) - 1, -1, -1):
+        for i in range(len(offsets) - 1, -1, -1):
             acc += sizes[i]
             if acc >= target or i == 0:
-                plan.append((offs[i], end, i, start_idx))       # [begin, end) covers params i..start_idx
-                end = offs[i]
-                start_idx = i - 1
+                plan.append((offsets[i], end, i, last))
+                end = offsets[i]
+                last = i - 1
                 acc = 0
         return plan
 
     def begin_backward(self, opt, passes=1):
         """`passes` backward passes will write the gradient buffer one after the other in program order (asr/pipeline.py:
-        two half batches, each on its own stream); a slice is reduced while the LAST pass walks past it, after the events
-        the earlier passes left there."""
+        two half batches, each on its own stream); a slice is reduced only after the LAST pass has announced it."""
         opt._ensure_flat()
-        self._plan = self._make_plan(opt)
+        flat = opt._flat
+        self._plan = self.make_plan(flat["offsets"], flat["sizes"], self.buckets)
+        self._slice_of = {}
+        for k, (_, _, lo, hi) in enumerate(self._plan):
+            for i in range(lo, hi + 1):
+                self._slice_of[flat["ids"][i]] = k
         self._pending = []
         self._next = 0
         self._opt = opt
         self._passes, self._pass = max(1, int(passes)), 0
         self._events = [[] for _ in self._plan]
+        self._new_pass()
+        self.launch_log = []
+        self._defer, self._met_recurrence = self._recurrent, False
         if self.backend == "nccl" and self._stream is None:
             self._stream = torch.cuda.Stream()
-        from . import link
-        link._GRAD_LISTENER[0] = self._on_grad_buffer
+        from . import link, _ops
+        link._GRAD_LISTENER[0] = self._on_grads_queued
+        _ops.RECURRENCE_HOOKS["before"] = self._before_recurrence
+        _ops.RECURRENCE_HOOKS["after"] = self._after_recurrence
 
-    def _on_grad_buffer(self, param):
-        """called when a backward kernel is about to write `param.grad`: everything behind it in the flat buffer
-        (parameters registered later = layers closer to the loss) has already been enqueued."""
+    def _new_pass(self):
+        self._missing = [set(range(lo, hi + 1)) for (_, _, lo, hi) in self._plan]
+        self._announced = 0
+        self._index_of = {pid: i for i, pid in enumerate(self._opt._flat["ids"])}
+
+    def _on_grads_queued(self, params):
+        """every kernel that writes the gradients of `params` in this pass has been queued"""
         if self._plan is None:
             return
-        flat = self._opt._flat
-        try:
-            idx = flat["ids"].index(id(param))
-        except ValueError:
-            return
-        while self._next < len(self._plan) and self._plan[self._next][2] > idx:
+        for p in params:
+            i = self._index_of.get(id(p))
+            if i is None:
+                continue
+            k = self._slice_of[id(p)]
+            if k < self._next and self._pass == self._passes - 1:
+                raise RuntimeError("a gradient was written after its slice had been all-reduced (a parameter used by two "
+                                   "layers?): build the Communicator with overlap=False")
+            if i in self._missing[k]:
+                self._missing[k].discard(i)
+                self._announced += 1
+        if self.overlap and not self._defer:
+            self._launch_complete()
+
+    def _complete(self, k):
+        return not self._missing[k]
+
+    # recurrence boundaries (see the module docstring)
+    def _before_recurrence(self):
+        self._defer = self._met_recurrence = True
+        self._join_pending()
+
+    def _after_recurrence(self):
+        if self.overlap:
+            self._launch_complete()
+
+    def _launch_complete(self):
+        while self._next < len(self._plan) and self._complete(self._next):
             self._passed(self._next)
             self._next += 1
 
     def _passed(self, k):
         """the current pass has queued every kernel that writes slice k"""
         if self._pass == self._passes - 1:
-            self._launch(self._plan[k], self._events[k])
+            self._launch(k, self._events[k])
         elif self._stream is not None:
             from .functions import side_streams
             for st in [torch.cuda.current_stream()] + side_streams():
@@ -91,7 +157,7 @@ class Communicator(object):
                 self._events[k].append(ev)
 
     def end_pass(self):
-        """between two backward passes: the pass just queued has written every slice it had not walked past yet"""
+        """between two backward passes: the pass just queued has written every slice"""
         if self._plan is None:
             return
         while self._next < len(self._plan):
@@ -99,39 +165,51 @@ class Communicator(object):
             self._next += 1
         self._pass += 1
         self._next = 0
+        self._new_pass()
 
-    def _launch(self, item, events=()):
-        begin, end = item[0], item[1]
+    def _launch(self, k, events=()):
+        begin, end = self._plan[k][0], self._plan[k][1]
         g = self._opt._flat["G"][begin:end]
+        self.launch_log.append((k, self._announced))
+        from .functions import side_streams
         if self._stream is not None:
             for ev in events:
                 self._stream.wait_event(ev)
             self._stream.wait_stream(torch.cuda.current_stream())
-            from .functions import side_streams
             for st in side_streams():               # weight-gradient GEMMs run on side streams
                 self._stream.wait_stream(st)
             with torch.cuda.stream(self._stream):
                 self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
+            if g.is_cuda:                           # gloo on device tensors: it orders itself after the CURRENT stream only
+                cur = torch.cuda.current_stream()
+                for st in side_streams():
+                    cur.wait_stream(st)
             self._pending.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
 
+    def _join_pending(self):
+        """the current stream waits for every collective in flight (RCCL: a stream dependency, the host goes on)"""
+        for w in self._pending:
+            w.wait()
+        if self._stream is not None and self._pending:
+            torch.cuda.current_stream().wait_stream(self._stream)
+        self._pending = []
+
     def finish_backward(self, opt):
-        from . import link
+        from . import link, _ops
         link._GRAD_LISTENER[0] = None
+        _ops.RECURRENCE_HOOKS["before"] = _ops.RECURRENCE_HOOKS["after"] = None
         if self._plan is None:          # update() without lossfun: reduce everything now
             opt._ensure_flat()
             dist.all_reduce(opt._flat["G"], op=dist.ReduceOp.SUM)
             return
         self._pass = self._passes - 1
-        while self._next < len(self._plan):
+        while self._next < len(self._plan):     # incl. slices with parameters that received no gradient in this step
             self._passed(self._next)
             self._next += 1
-        for w in self._pending:
-            w.wait()
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        self._pending = []
+        self._join_pending()
         self._plan = None
+        self._recurrent = self._met_recurrence
 
     def allreduce_scalar_mean(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

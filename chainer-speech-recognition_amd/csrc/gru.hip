@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
 // forced by the LDS request; a grid of at most 128 workgroups is always co-resident on 256 CUs.  Every spin is bounded:
 // on time-out the workgroup raises the abort word, which all pollers watch, and the launch drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kSpinLimit = 1u << 19;
+// 2^22 polls of >= 1 us each: seconds.  Nothing a launch can legitimately wait for takes that long -- a workgroup that finds
+// its CU busy (a weight-gradient GEMM of the side stream; never a collective: asr/parallel.py joins those before a
+// recurrence is queued) starts milliseconds late at worst -- but a launch that can NEVER be fully resident (partitioned
+// device, another process holding CUs for good) still ends, raises the abort word and costs one dropped step.
+constexpr unsigned kSpinLimit = 1u << 22;
 constexpr int kPersistLds = 96 * 1024;
 // The wide backward kernel asks for so much LDS that no GEMM workgroup (36..64 KB) fits beside it on a CU.  Sharing the
 // CU paid while the recurrence waited on memory ("Co-residency"); once its step had become an
@@ -2360,10 +2364,32 @@ static bool clear_sync(void* sync_ws, size_t extra, hipStream_t st) {
     return hipGetLastError() == hipSuccess;
 }
 
+// compute units of the current device (cached per device ordinal; 0 if the query fails)
+static int device_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = -1;
+        cached[dev] = n > 0 ? n : -1;
+    }
+    return cached[dev] > 0 ? cached[dev] : 0;
+}
+
 static bool can_persist(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
     if (mode == 1 || !sync_ws) return false;
     if (B > 16 * MT || (H / 16) * ndir > 128 || H > 1024) return false;
     if ((size_t)T * B * ndir * 3 * H * 2 >= ((size_t)1 << 31)) return false;
+    // every workgroup of a persistent launch asks for most of a CU's LDS and must be resident together with all the others:
+    // the largest grid any of the forms below builds for these sizes has to fit the device's CUs (a partitioned device --
+    // CPX mode, a CU mask -- reports fewer), otherwise the per-step launches serve.  Which XCD a workgroup lands on is NOT
+    // assumed: the XCD-local hand-off is chosen inside the launch and falls back to the placement-free one (decide_local).
+    const int rec8 = (ndir * ((B + 7) / 8) + 7) & ~7, rec4 = (ndir * ((B + 3) / 4) + 7) & ~7;
+    const int narrow = rec8 * (H / 16), wide = rec4 * ((H + 31) / 32);
+    const int need = narrow > wide ? narrow : wide;
+    const int cus = device_cus();
+    if (cus > 0 && need > cus) return false;
     return true;
 }
 

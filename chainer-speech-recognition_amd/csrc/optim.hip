@@ -78,6 +78,91 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
 }
 
+// One thread decides what the update kernels of this step do, so that neither the host nor 500 000 threads have to:
+//   ctl[0] = 1 when the step is dropped (non-finite gradient norm -- the reference's NaN check, run/ctc/cnn/train.py:193-197 --
+//            or a raised abort word of a persistent GRU launch whose outputs are therefore garbage), else 0
+//   ctl[1] = gradient factor = grad_scale * min(1, clip / (||g|| * |grad_scale|))        (GradientClipping on the reduced gradient)
+//   ctl[2] = Adam's alpha_t = alpha * sqrt(1 - beta2^t) / (1 - beta1^t), t = number of APPLIED steps including this one
+//            (a dropped step does not advance t: the reference `continue`s before optimizer.update)
+//   ctl[3] = t
+//   ctl[4] = the squared gradient norm (sum of the per-workgroup partial sums in a FIXED order: every data-parallel rank
+//            derives bit-identical clipping factors from bit-identical reduced gradients -- float atomics would not)
+__global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* __restrict__ g, long long n, float* __restrict__ partials) {
+    __shared__ float scratch[32];
+    float s = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        s += v * v;
+    }
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void step_control_kernel(const float* __restrict__ partials, int npartials,
+                                                           const int* __restrict__ abort0, const int* __restrict__ abort1,
+                                                           float clip, float grad_scale, float alpha, float beta1, float beta2,
+                                                           int* __restrict__ applied, float* __restrict__ ctl) {
+    __shared__ float scratch[32];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < npartials; i += blockDim.x) s += partials[i];
+    const float sq = block_sum(s, scratch);
+    if (threadIdx.x != 0) return;
+    ctl[4] = sq;
+    const float* sqnorm = &sq;
+    bool drop = !isfinite(sqnorm[0]);
+    if (abort0 && abort0[0] != 0) drop = true;
+    if (abort1 && abort1[0] != 0) drop = true;
+    float rate = grad_scale;
+    if (!drop && clip > 0.f) {
+        const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
+        const float r = clip / norm;
+        if (r < 1.f) rate *= r;
+    }
+    int t = applied[0];
+    if (!drop) applied[0] = ++t;
+    const double tt = t < 1 ? 1.0 : (double)t;
+    const double fix1 = 1.0 - pow((double)beta1, tt), fix2 = 1.0 - pow((double)beta2, tt);
+    ctl[0] = drop ? 1.f : 0.f;
+    ctl[1] = rate;
+    ctl[2] = (float)((double)alpha * sqrt(fix2) / fix1);
+    ctl[3] = (float)t;
+}
+
+__global__ __launch_bounds__(256) void adam_ctl_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long long n, float beta1, float beta2, float eps,
+                                                       float decay, const float* __restrict__ ctl) {
+    if (ctl[0] != 0.f) return;
+    const float rate = ctl[1], lr_t = ctl[2];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * rate + decay * pi;
+        float mi = m[i], vi = v[i];
+        mi += (1.f - beta1) * (gi - mi);
+        vi += (1.f - beta2) * (gi * gi - vi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void sgd_ctl_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+                                                      long long n, int kind, float lr, float mu, float decay,
+                                                      const float* __restrict__ ctl) {
+    if (ctl[0] != 0.f) return;
+    const float rate = ctl[1];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] * rate + decay * pi;
+        if (kind == 0) {
+            p[i] = pi - lr * gi;
+        } else {
+            const float vi = mu * v[i] - lr * gi;
+            v[i] = vi;
+            p[i] = kind == 1 ? pi + vi : pi + mu * mu * vi - (1.f + mu) * lr * gi;
+        }
+    }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, long long n, float value) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = value;
 }
@@ -126,6 +211,38 @@ extern "C" int asr_clip_decay_sgd(void* stream, float* p, const float* g, float*
     if (!p || !g || n <= 0 || kind < 0 || kind > 2 || (kind > 0 && !v)) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, n, kind, lr, momentum,
                        weight_decay, clip_threshold, grad_scale, sqnorm);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_sqnorm_partials_count(long long n) { return grid_for(n); }
+
+extern "C" int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
+                                float clip_threshold, float grad_scale, float alpha, float beta1, float beta2,
+                                int* applied_steps, float* ctl) {
+    if (!g || n <= 0 || !partials || !applied_steps || !ctl) return ASR_ERR_BAD_ARG;
+    const int blocks = grid_for(n);
+    hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+    hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, blocks, abort0,
+                       abort1, clip_threshold, grad_scale, alpha, beta1, beta2, applied_steps, ctl);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2,
+                            float eps, float weight_decay, const float* ctl) {
+    if (!p || !g || !m || !v || !ctl || n <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(adam_ctl_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
+                       weight_decay, ctl);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_sgd_ctl(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,
+                           float weight_decay, const float* ctl) {
+    if (!p || !g || !ctl || n <= 0 || kind < 0 || kind > 2 || (kind > 0 && !v)) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sgd_ctl_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, v, n, kind, lr, momentum,
+                       weight_decay, ctl);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -20,6 +20,9 @@ extern "C" {
 int asr_version(void);
 /* a one-wave kernel that idles for `microseconds` (<= 100000) on `stream`: used to stagger two concurrent half batches */
 int asr_stream_delay(void* stream, int microseconds);
+/* diagnostic: `blocks` workgroups holding `lds_bytes` of LDS each idle for `microseconds` (<= 200000) on `stream` -- makes CUs
+ * temporarily unavailable to launches on other streams (tests of the persistent GRU kernels under partial residency) */
+int asr_occupy_cus(void* stream, int microseconds, int lds_bytes, int blocks);
 
 /* ---------------------------------------------------------------------------------------- CTC family
  * Replaces chainer.functions.connectionist_temporal_classification (call sites run/ctc/cnn/train.py:162,191,
@@ -282,6 +285,23 @@ int asr_clip_decay_adam(void* stream, float* p, const float* g, float* m, float*
 /* kind 0 SGD, 1 MomentumSGD, 2 NesterovAG (asr/optimizers.py:43-52), same clipping / decay front end */
 int asr_clip_decay_sgd(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,
                        float weight_decay, float clip_threshold, float grad_scale, const float* sqnorm);
+/* The same step with its decisions taken on the device by one thread (no host synchronisation, no host-side step count):
+ * asr_step_control takes the squared norm of the flat gradient g (n floats; per-workgroup partial sums into `partials`,
+ * asr_sqnorm_partials_count(n) floats, then summed in a fixed order -- bit-identical on every data-parallel rank, which
+ * float atomics are not), reads up to two abort words of persistent GRU launches (sync_ws int 1023 of asr_gru_fwd /
+ * asr_gru_bwd; NULL = none) and writes ctl[8] = {drop, gradient factor, Adam's alpha_t, t, squared norm, ...}: the step is
+ * dropped when the norm is not finite (the reference's NaN check, run/ctc/cnn/train.py:193-197) or an abort word is raised
+ * (the recurrence's outputs are garbage); *applied_steps (device int, zero at start) counts the steps that were NOT dropped
+ * and is the t of Adam's bias correction (the reference `continue`s before optimizer.update).  asr_adam_ctl / asr_sgd_ctl
+ * apply the step ctl describes. */
+int asr_sqnorm_partials_count(long long n);
+int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
+                     float clip_threshold, float grad_scale, float alpha, float beta1, float beta2, int* applied_steps,
+                     float* ctl);
+int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps,
+                 float weight_decay, const float* ctl);
+int asr_sgd_ctl(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,
+                float weight_decay, const float* ctl);
 
 #ifdef __cplusplus
 }

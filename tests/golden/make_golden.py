@@ -18,6 +18,8 @@ NumPy statements:
   G6  asr/vocab.py:107-126, asr/error.py:7-68   tokeniser + greedy-collapse CER
   G7  asr/data/loaders/base.py:64-80,39-41      running mean / n*var statistics
   G8  asr/fft.py:21-50              augment_specgram under a fixed NumPy seed
+  G9  asr/nn/layernorm.py:33-48     NormalizeLayer.forward (4-d and 3-d inputs; no epsilon);  asr/nn/convolution_2d.py:21-25,
+      62-64  _norm and the weight-normalised W = g * V / _norm(V)
 
 usage:  python tests/golden/make_golden.py
 """
@@ -55,7 +57,14 @@ def _install_stubs():
             return _Anything()
 
     cuda = mod("chainer.cuda", get_array_module=lambda *a: np, cudnn_enabled=False, to_gpu=lambda x: x)
-    function = mod("chainer.function", Function=object)
+    class _Function(object):        # chainer.Function's book-keeping calls, no arithmetic
+        def retain_inputs(self, indexes):
+            pass
+
+        def retain_outputs(self, indexes):
+            pass
+
+    function = mod("chainer.function", Function=_Function)
     utils = mod("chainer.utils", force_array=np.asarray)
     type_check = mod("chainer.utils.type_check", expect=lambda *a, **k: None)
     conv_nd = mod("chainer.utils.conv_nd")
@@ -66,6 +75,11 @@ def _install_stubs():
     initializers = mod("chainer.initializers", _get_initializer=lambda *a: None)
     configuration = mod("chainer.configuration")
     functions = mod("chainer.functions")
+    f_array = mod("chainer.functions.array")
+    f_array.broadcast = mod("chainer.functions.array.broadcast", _backward_one=None)    # backward only: never called here
+    f_conn = mod("chainer.functions.connection")
+    f_conn.convolution_2d = mod("chainer.functions.connection.convolution_2d", Convolution2DFunction=_Function)
+    functions.array, functions.connection = f_array, f_conn
     links = mod("chainer.links")
     serializers = mod("chainer.serializers")
     optimizers = mod("chainer.optimizers")
@@ -327,8 +341,28 @@ def g_stats():
                         bmean=mean, bstd=std, **{"chunk%d" % i: c for i, c in enumerate(chunks)})
 
 
+def g_norm():
+    """G9: the reference's own NumPy statements for the layer normalisation forward and the weight-norm scale"""
+    ln = _load("ref_layernorm", "asr/nn/layernorm.py")
+    c2d = _load("ref_convolution_2d", "asr/nn/convolution_2d.py")
+    rs = np.random.RandomState(9)
+    out = {}
+    for name, shape, dtype in (("x4", (3, 6, 5, 7), np.float32), ("x4_f64", (2, 4, 3, 5), np.float64), ("x3", (2, 11, 6), np.float32),
+                               ("x4_wide", (2, 3000, 1, 4), np.float32)):
+        x = (rs.randn(*shape) * 2.0 + 0.5).astype(dtype)
+        f = ln.NormalizeLayer()
+        y, = f.forward((x,))
+        out[name], out[name + ".y"], out[name + ".std"] = x, np.asarray(y), np.asarray(f.std)
+    V = (rs.randn(5, 3, 3, 5) * 0.3).astype(np.float32)
+    g = (rs.rand(5, 1, 1, 1) + 0.5).astype(np.float32)
+    norm = c2d._norm(V)
+    out["V"], out["g"], out["norm"], out["W"] = V, g, np.asarray(norm), np.asarray(g * (V / norm))    # asr/nn/convolution_2d.py:62-64
+    np.savez_compressed(os.path.join(OUT, "norm.npz"), **out)
+
+
 def main():
     _install_stubs()
+    g_norm()
     fft = _load("ref_fft", "asr/fft.py")
     gc = _load("ref_gram_ctc", "asr/loss/gram_ctc.py")
     sru = _load("ref_sru", "asr/nn/sru.py")

@@ -198,7 +198,7 @@ def test_eval_loop_on_a_model(device):
     import asr.functions as F
     from asr import error, vocab
     from asr.model import ds2
-    from oracle.model import synthetic_batch
+    from asr.data.synthetic import synthetic_batch
     cfg = ds2.configure()
     cfg.vocab_size = 119
     cfg.ndim_rnn = 64

@@ -217,3 +217,86 @@ def test_bucket_reader_matches_reference(tmp_path):
     assert reader.get_statistics() == g["statistics"]
     limited = Reader(root, buckets_limit=2, dev_split=0.25, seed=3)
     assert limited.get_num_buckets() == 2
+
+
+# ---------------------------------------------------------------------------------------------- checkpoints (row f4)
+def _ds2_small():
+    from asr.model import ds2
+    cfg = ds2.configure()
+    cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = 17, 8, 32, 16, 2
+    return cfg, ds2.Model(cfg)
+
+
+def _materialise_ds2(cfg, m):
+    m.rnn_blocks.layers[0]._initialize_params(cfg.ndim_conv * 6)
+    for i in range(1, cfg.num_rnn_layers):
+        m.rnn_blocks.layers[2 * i]._initialize_params(cfg.ndim_rnn)
+    m.dense_blocks.layers[0]._initialize_params(cfg.ndim_rnn)
+    m.dense_blocks.layers[7].norm._initialize_params(cfg.vocab_size)
+
+
+def test_checkpoint_names_follow_the_reference(tmp_path):
+    """Chainer's serialisers store a parameter under the attribute path that leads to it; the reference's containers name
+    those attributes layer_%d / layer_%d_%d (asr/nn/nn.py:304-320) and _module_<ns>_sequential_%d (:355-392)"""
+    import torch
+    from asr import serializers
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    torch.manual_seed(0)
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers, cfg.architecture = 19, 3, 8, 12, 3, "zhang+residual"
+    model = build_model(cfg)
+    names = sorted(serializers.to_table(model).keys())
+    # first block: conv at 0; residual blocks at layer index 5 and 6 hold their conv at inner index 0; plain block conv at 7
+    assert "layer_0/W" in names and "layer_0/b" in names
+    assert "layer_5_0/W" in names and "layer_6_0/W" in names and "layer_7/W" in names
+    assert all("/" in n and "." not in n for n in names)
+    cfg.architecture = "glu"
+    glu = build_model(cfg)
+    gl = sorted(serializers.to_table(glu).keys())
+    assert "layer_5/W" in gl and "layer_7/b" in gl          # GLU registers its convolution under the layer's own index (:312-313)
+    cfg2, m = _ds2_small()
+    _materialise_ds2(cfg2, m)
+    t = serializers.to_table(m)
+    for key in ("_module_conv_blocks_sequential_0/W", "_module_rnn_blocks_sequential_0/w_ih", "_module_rnn_blocks_sequential_2/w_hh",
+                "_module_dense_blocks_sequential_6/W", "_module_dense_blocks_sequential_7/norm/gamma"):
+        assert key in t, (key, sorted(t)[:8])
+
+
+def test_checkpoint_round_trip_on_a_fresh_model(tmp_path):
+    """build_model(config); model.load(path) -- the reference's resume / eval flow (run/ctc/cnn/train.py:
+    105-106) -- on a model whose lazily sized parameters are still empty"""
+    import numpy as np
+    import torch
+    from asr import serializers
+    torch.manual_seed(1)
+    cfg, m = _ds2_small()
+    _materialise_ds2(cfg, m)
+    path = str(tmp_path / "model.hdf5")            # the reference's file name; the container is sniffed on load
+    m.save(path)
+    assert serializers.sniff(path) in ("npz", "hdf5")
+    torch.manual_seed(2)
+    _, fresh = _ds2_small()
+    assert fresh.rnn_blocks.layers[0].w_ih.numel() == 0
+    assert fresh.load(path) is True
+    a, b = m.state_dict(), fresh.state_dict()
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert fresh.load(str(tmp_path / "missing.hdf5")) is False
+    # the merged (channel, height) columns of the first recurrent layer are stored in the reference's (c, h) order
+    C, H = m._merged
+    w = m.rnn_blocks.layers[0].w_ih.detach().numpy()
+    stored = np.load(path)["_module_rnn_blocks_sequential_0/w_ih"]
+    h, c = 3, 5
+    assert np.array_equal(stored[..., c * H + h], w[..., h * C + c])
+    # a torch.save'd state_dict of round 1 still loads (own names, own column order)
+    old = str(tmp_path / "old.pt")
+    torch.save(m.state_dict(), old)
+    _, again = _ds2_small()
+    assert again.load(old) is True
+    assert torch.equal(again.rnn_blocks.layers[0].w_ih, m.rnn_blocks.layers[0].w_ih)
+    # torch's own load_state_dict also sizes the lazy parameters now
+    _, third = _ds2_small()
+    third.load_state_dict(m.state_dict())
+    assert torch.equal(third.dense_blocks.layers[7].norm.gamma, m.dense_blocks.layers[7].norm.gamma)

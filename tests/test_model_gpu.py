@@ -295,3 +295,101 @@ def test_staggered_half_batch_step_matches_plain_step(device):
     for name in p0:
         # three Adam steps of 1e-3 each: the parameters moved by ~3e-3; the two routes may differ by a fraction of a step
         assert float((p0[name] - p1[name]).abs().max()) < 1.5e-3, name
+
+
+def test_step_is_dropped_on_the_device_when_a_recurrence_gave_up(device):
+    """a persistent GRU launch that abandons an in-launch wait leaves finite garbage behind, which the
+    isfinite(norm) guard lets through.  asr_step_control drops the step on the device when an abort word is raised: the
+    parameters, Adam's moments and the applied-step count stay untouched; the host learns one step later (AsrHipError) and
+    training resumes after that."""
+    from asr import _ops, _lib
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import Adam, GradientClipping, WeightDecay
+    B, T, V = 4, 50, 29
+    cfg, model = _build(device, V=V, seed=3)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=2)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    model(xd)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    opt.add_hook(WeightDecay(1e-5))
+
+    def step():
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
+    step()
+    torch.cuda.synchronize()
+    assert opt.applied_steps() == 1
+    snap = [t.clone() for t in (opt.flat_parameters(), opt.m, opt.v)]
+    _ops.LAST_SYNC[0][1023:1024].fill_(1)             # forge: "a launch gave up"
+    step()                                            # every recurrence of this step gives up at once: garbage gradients
+    torch.cuda.synchronize()
+    for a, b_ in zip(snap, (opt.flat_parameters(), opt.m, opt.v)):
+        assert torch.equal(a, b_)
+    assert opt.applied_steps() == 1 and float(opt._flat["ctl"][0].item()) == 1.0
+    with pytest.raises(_lib.AsrHipError):             # the host notices one step later, without ever having synchronised
+        step()
+    torch.cuda.synchronize()
+    for a, b_ in zip(snap, (opt.flat_parameters(), opt.m, opt.v)):
+        assert torch.equal(a, b_)
+    step()                                            # the word was cleared: back to normal
+    torch.cuda.synchronize()
+    assert opt.applied_steps() == 2 and not torch.equal(snap[0], opt.flat_parameters())
+    # the evaluation path checks too (it synchronises anyway)
+    from asr import error
+    _ops.LAST_SYNC[0][1023:1024].fill_(1)
+    ids = torch.zeros(2, 5, dtype=torch.int32, device=device)
+    with pytest.raises(_lib.AsrHipError):
+        error.compute_minibatch_error(ids, ids, 0, None, None)
+    _ops.gru_check_all()                              # cleared
+
+
+def test_optimiser_state_survives_a_reflatten(device):
+    """attaching / detaching a communicator or a parameter appearing late rebuilds the flat buffers; Adam's
+    moments and the applied-step count must come along"""
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import Adam
+    B, T, V = 3, 40, 29
+    cfg, model = _build(device, V=V, seed=5)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=2)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    model(xd)
+    opt.setup(model)
+    for _ in range(2):
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
+    torch.cuda.synchronize()
+    params = list(opt._params())
+    m_before = {id(p): opt.m[o:o + p.numel()].clone() for p, o in zip(params, opt._flat["offsets"])}
+    w_before = {id(p): p.detach().clone() for p in params}
+    # force a re-flatten: one parameter moves to fresh storage (what a lazily (re)initialised layer does)
+    p0 = params[3]
+    p0.data = p0.data.clone()
+    opt._ensure_flat()
+    assert opt.applied_steps() == 2
+    for p, o in zip(opt._params(), opt._flat["offsets"]):
+        assert torch.equal(opt.m[o:o + p.numel()], m_before[id(p)])
+        assert torch.equal(p.detach(), w_before[id(p)])
+    assert float(opt.m.abs().sum()) > 0
+
+
+def test_save_fresh_build_load_gives_identical_logits(device, tmp_path):
+    """row f4 + ADVICE r1: model.save(path); build_model(config); model.load(path) on the FRESH model (lazily sized
+    parameters still empty) reproduces the logits bit for bit; the file carries the reference's parameter paths"""
+    import numpy as np
+    from asr import serializers
+    cfg, model = _build(device, V=29, seed=11)
+    x, *_ = omodel.synthetic_batch(3, 40, 29, Lmin=3, Lmax=8, seed=5)
+    xd = x.to(device)
+    y0 = torch.stack(model(xd)).detach().clone()
+    path = str(tmp_path / "model.hdf5")
+    model.save(path)
+    keys = set(np.load(path).files) if serializers.sniff(path) == "npz" else None
+    if keys is not None:
+        assert "_module_rnn_blocks_sequential_0/w_ih" in keys and "_module_dense_blocks_sequential_7/norm/gamma" in keys
+    cfg2, fresh = _build(device, V=29, seed=12)
+    assert fresh.load(path) is True
+    y1 = torch.stack(fresh(xd)).detach()
+    assert torch.equal(y0, y1)

@@ -337,3 +337,30 @@ def test_bf16_gradient_handover_from_layernorm_to_projection(device):
             # with a second consumer the sum is rounded once more
             scale = float(v.abs().max()) + 1e-6
             torch.testing.assert_close(u, v, rtol=2e-2, atol=(2e-2 if second else 4e-3) * scale)
+
+
+def test_layernorm_and_weightnorm_against_reference_goldens(device, golden_dir):
+    """HIP layer-norm forward (f32 in, f32 out) and weight-norm kernel against the REFERENCE's outputs
+    (tests/golden/norm.npz: NormalizeLayer.forward asr/nn/layernorm.py:33-48, _norm asr/nn/convolution_2d.py:21-25,62-64)."""
+    import os
+    import asr.nn as nn
+    from asr import _ops
+    g = np.load(os.path.join(golden_dir, "norm.npz"))
+    for name in ("x4", "x3", "x4_wide", "x4_f64"):
+        x = torch.tensor(g[name].astype(np.float32))
+        ln = nn.LayerNormalization(x.shape[1]).to_gpu()          # gamma = 1, beta = 0: the bare normalize_layer
+        ln.output_float32 = True
+        # float32 input in physical order so that nothing is rounded to bf16 on the way in
+        if x.dim() == 4:
+            xd = x.to(device).permute(3, 0, 2, 1).contiguous().permute(1, 3, 2, 0)
+        else:
+            xd = x.to(device).permute(0, 2, 1).contiguous().permute(0, 2, 1)
+        y = ln(xd)
+        assert y.dtype == torch.float32 and tuple(y.shape) == tuple(x.shape)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[name + ".y"], rtol=2e-5, atol=2e-5)
+        from asr.nn.layernorm import normalize_layer
+        y2 = normalize_layer(xd)
+        np.testing.assert_allclose(y2.detach().float().cpu().numpy(), g[name + ".y"], rtol=1e-2, atol=1e-2)   # bf16 output
+    W, norm = _ops.weightnorm_fwd(torch.tensor(g["V"]).to(device), torch.tensor(g["g"]).to(device))
+    np.testing.assert_allclose(norm.cpu().numpy(), g["norm"].reshape(-1), rtol=1e-6)
+    np.testing.assert_allclose(W.cpu().numpy(), g["W"], rtol=2e-6, atol=1e-7)

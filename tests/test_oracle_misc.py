@@ -134,3 +134,19 @@ def test_weightnorm_backward_by_finite_differences():
     gm[2] -= eps
     num = ((onn.weightnorm_W(V, gp)[0] - onn.weightnorm_W(V, gm)[0]) * gW).sum() / (2 * eps)
     assert num == pytest.approx(gg[2, 0, 0, 0], rel=1e-5)
+
+
+def test_normalize_layer_and_weightnorm_match_reference(golden_dir):
+    """oracle.nn against the reference's own NumPy statements (tests/golden/norm.npz, written by make_golden.py G9):
+    NormalizeLayer.forward asr/nn/layernorm.py:33-48 (4-d, 3-d, f32/f64; no epsilon) and _norm / W = g V / _norm(V)
+    asr/nn/convolution_2d.py:21-25,62-64"""
+    g = np.load(os.path.join(golden_dir, "norm.npz"))
+    for name in ("x4", "x4_f64", "x3", "x4_wide"):
+        x = g[name]
+        y, diff, std = onn.normalize_layer_fwd(x.astype(np.float64))
+        tol = 1e-12 if x.dtype == np.float64 else 2e-6
+        np.testing.assert_allclose(y, g[name + ".y"], rtol=tol, atol=tol * 5)
+        np.testing.assert_allclose(std, g[name + ".std"], rtol=max(tol, 1e-6))
+    W, Vn, norm = onn.weightnorm_W(g["V"].astype(np.float64), g["g"].astype(np.float64))
+    np.testing.assert_allclose(norm, g["norm"], rtol=1e-6)
+    np.testing.assert_allclose(W, g["W"], rtol=2e-6, atol=1e-7)

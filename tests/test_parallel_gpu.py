@@ -16,7 +16,7 @@ import torch
 from asr.model import ds2
 from asr.loss import connectionist_temporal_classification
 from asr.optimizers import Adam, GradientClipping, WeightDecay
-from oracle.model import synthetic_batch
+from asr.data.synthetic import synthetic_batch
 
 def run(use_comm):
     torch.manual_seed(0)
@@ -53,3 +53,112 @@ def test_single_rank_rccl_step_matches_plain_step(tmp_path):
     for la, lb in zip(res["plain"][0], res["comm"][0]):
         assert abs(la - lb) <= 2e-3 * abs(la)
     assert abs(res["plain"][1] - res["comm"][1]) <= 1e-3 * abs(res["plain"][1]) + 1e-2
+
+
+# ---------------------------------------------------------------------------------------------- two ranks == one rank
+# the REAL model and optimiser, 2 ranks (gloo between two processes that share the one GPU of the test
+# box) each with half of a batch, against 1 rank with the whole batch: mean of local means (asr/loss/gram_ctc.py:280-281),
+# 1/world scaling, clipping AFTER the reduction (run/ctc/cnn/train.py:144-145), broadcast of lazily sized and
+# data-dependently initialised (weight-norm, asr/nn/convolution_2d.py:177-187) parameters.  GRU mode 1 (one launch per
+# time step): two processes' persistent launches would compete for the CUs of the shared device.
+DP_SCRIPT = r'''
+import os, sys, json
+ROOT = os.environ["ASR_ROOT"]
+sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd")); sys.path.insert(0, ROOT)
+import torch
+from asr import _ops
+from asr.loss import connectionist_temporal_classification
+from asr.optimizers import get_optimizer, GradientClipping, WeightDecay
+from asr.data.synthetic import synthetic_batch
+
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+kind, optname, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+dev = torch.device("cuda:0")
+_ops.GRU_MODE[0] = 1
+torch.manual_seed(1234 + rank)                  # DIFFERENT seeds: only the broadcast can make the ranks agree
+V, B, T = 31, 8, 64
+if kind == "ds2":
+    from asr.model import ds2
+    cfg = ds2.configure(); cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 128, 32, 2
+    model = ds2.Model(cfg).to_gpu(0)
+else:                                           # weight-normalised convolutional recipe with lazily sized layer norms
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = V, 3, 16, 24, 2
+    cfg.architecture, cfg.weightnorm = "zhang+layernorm", True
+    model = build_model(cfg).to_gpu(0)
+x, labels, x_len, l_len = synthetic_batch(B, T, V, Lmin=3, Lmax=9, seed=0, ragged=True)
+first = slice(0, B // 2)
+mine = slice(rank * (B // world), (rank + 1) * (B // world))
+with torch.no_grad():
+    model(x[first].to(dev) if rank == 0 else x[mine].to(dev))      # lazy sizes + data-dependent initialisation, rank-local
+opt = get_optimizer(optname, 1e-3 if optname == "adam" else 0.05, 0.9)
+opt.setup(model); opt.add_hook(GradientClipping(1.0)); opt.add_hook(WeightDecay(1e-5))
+comm = None
+if world > 1:
+    from asr.parallel import Communicator
+    comm = Communicator("gloo", buckets=3)
+    comm.bcast_data(model)
+    opt.set_communicator(comm)
+xd, ld, xl, ll = x[mine].to(dev), labels[mine].to(dev), x_len[mine].to(dev), l_len[mine].to(dev)
+opt._ensure_flat()
+p_start = opt.flat_parameters().detach().cpu().clone()
+losses, norms = [], []
+for _ in range(3):
+    loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+    opt.update(lossfun=lambda: loss)
+    losses.append(loss.item())
+    norms.append(float(opt._flat["sq"].item()) ** 0.5 / world)       # norm of the MEAN gradient
+torch.cuda.synchronize()
+torch.save({"losses": losses, "norms": norms, "start": p_start, "end": opt.flat_parameters().detach().cpu(),
+            "launches": (comm.launch_log if comm is not None else []), "applied": opt.applied_steps()}, out_path)
+if comm is not None:
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+'''
+
+
+def _spawn(root, tmp_path, world, kind, optname, port):
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / ("%s_%s_w%d_r%d.pt" % (kind.replace("+", "_"), optname, world, r)))
+        env = dict(os.environ, ASR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
+                   LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", DP_SCRIPT, kind, optname, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+        outs.append(out)
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    import torch
+    return [torch.load(o) for o in outs]
+
+
+@pytest.mark.parametrize("kind,optname", [("ds2", "adam"), ("ds2", "msgd"), ("cnn+weightnorm", "msgd")])
+def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname):
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29541 + (hash((kind, optname)) % 40)
+    one = _spawn(root, tmp_path, 1, kind, optname, port)[0]
+    two = _spawn(root, tmp_path, 2, kind, optname, port + 50)
+    # the broadcast made the ranks start from rank 0's parameters (seeds differ), i.e. from the one-rank run's
+    assert torch.equal(two[0]["start"], two[1]["start"])
+    assert torch.equal(two[0]["start"], one["start"])
+    assert torch.equal(two[0]["end"], two[1]["end"]), "ranks diverged"
+    assert one["applied"] == 3 and two[0]["applied"] == 3
+    # loss: mean of the local means == global mean (equal local batches)
+    for s in range(3):
+        mean2 = 0.5 * (two[0]["losses"][s] + two[1]["losses"][s])
+        assert abs(mean2 - one["losses"][s]) <= 2e-3 * abs(one["losses"][s]), (s, mean2, one["losses"][s])
+        # gradient norm the optimiser clipped with: ||sum over ranks|| / world == ||gradient of the whole batch||
+        assert abs(two[0]["norms"][s] - one["norms"][s]) <= 2e-2 * one["norms"][s], (s, two[0]["norms"][s], one["norms"][s])
+    assert one["norms"][0] > 1.0, "the clipping threshold must bite for this test to see clip-before-reduce"
+    moved1, moved2 = one["end"] - one["start"], two[0]["end"] - two[0]["start"]
+    rel = float((moved2 - moved1).norm() / moved1.norm())
+    # momentum SGD is linear in the (clipped, scaled) gradient: a wrong 1/world, a clip before the reduction or a stale slice
+    # shows as an O(1) error; Adam divides by sqrt(v), which amplifies bf16 noise on near-zero gradients
+    assert rel < (0.15 if optname == "adam" else 0.03), rel
+    # every slice went exactly once per step
+    ks = [k for k, _ in two[0]["launches"]]
+    assert sorted(ks) == list(range(len(ks)))

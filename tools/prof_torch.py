@@ -4,7 +4,7 @@ from asr import _lib, _ops, functions as F
 from asr.loss import connectionist_temporal_classification
 from asr.model import ds2
 from asr.optimizers import Adam, GradientClipping, WeightDecay
-from oracle.model import synthetic_batch
+from asr.data.synthetic import synthetic_batch
 dev = torch.device("cuda:0")
 cfg = ds2.configure(); cfg.vocab_size = 3000
 torch.manual_seed(0)

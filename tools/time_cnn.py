@@ -7,7 +7,7 @@ from asr.model import cnn
 from asr.model.architectures import build_model
 from asr.loss import connectionist_temporal_classification
 from asr.optimizers import get_optimizer, GradientClipping, WeightDecay
-from oracle.model import synthetic_batch
+from asr.data.synthetic import synthetic_batch
 arch = sys.argv[1] if len(sys.argv) > 1 else "zhang+residual"
 B, T, V = 32, 1000, 119
 dev = torch.device("cuda:0")

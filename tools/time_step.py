@@ -6,7 +6,7 @@ import torch
 from asr.model import ds2
 from asr.loss import connectionist_temporal_classification
 from asr.optimizers import Adam, GradientClipping, WeightDecay
-from oracle.model import synthetic_batch
+from asr.data.synthetic import synthetic_batch
 
 def main(B=32, T=1000, V=3000, steps=5):
     dev = torch.device("cuda:0")
