@@ -57,8 +57,8 @@ class Census(object):
     def wrap(self, ops):
         self._orig = {}
         for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd",
-                     "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "clip_decay_adam",
-                     "sqnorm_acc", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
+                     "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "adam_ctl",
+                     "step_control", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
                      "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd"):
             fn = getattr(ops, name)
             self._orig[name] = fn
@@ -120,8 +120,10 @@ def time_ctc(lib_mod, ops, T, B, V, L, x_len, l_len, labels, dev):
     return res
 
 
-def cpu_baseline(cfg, T, V, seconds_budget=25.0):
-    """The CPU oracle (torch-CPU fp32 restatement, oracle/model.py) on a bounded sample of the same workload."""
+def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
+    """The CPU oracle (torch-CPU fp32 restatement, oracle/model.py) on a bounded sample of the same workload, and -- with
+    `dev` -- the parity of the HIP path against it on that very sample: the SAME B=4 batch and the SAME initial parameters go
+    through one forward + CTC + backward on both sides (the step of run/ctc/cnn/train.py:190-200 before the update)."""
     from asr.model import ds2
     from oracle import model as omodel
     torch.manual_seed(0)
@@ -147,18 +149,60 @@ def cpu_baseline(cfg, T, V, seconds_budget=25.0):
     cores = max(1, min(16, avail, torch.get_num_threads()))
     torch.set_num_threads(cores)
     log("cpu_baseline: %d threads" % cores)
+    parity = None
     t0 = time.time()
+    if dev is not None:
+        # warm-up pass of the oracle = the parity pass: forward + loss + backward, nothing updated yet
+        logits_ref = ref(x)
+        loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+        loss_ref.backward()
+        from asr.loss import connectionist_temporal_classification
+        gpu = ds2.Model(cfg)
+        gpu.load_state_dict(state)
+        gpu.to_gpu(dev.index)
+        ys = gpu(x.to(dev))
+        loss = connectionist_temporal_classification(ys, labels.to(dev), 0, x_len.to(dev), l_len.to(dev))
+        loss.backward()
+        from asr.functions import join_side_stream
+        join_side_stream()
+        torch.cuda.synchronize()
+
+        def cos(a, b):
+            a, b = a.double().flatten(), b.double().flatten()
+            return float(a @ b / (a.norm() * b.norm() + 1e-30))
+        logits = torch.stack(tuple(ys)).detach().float().cpu()
+        worst, worst_name, norm_ratio = 1.0, None, []
+        for name, p in gpu.named_parameters():
+            gr = ref.g(name).grad
+            c = cos(p.grad.detach().cpu(), gr)
+            norm_ratio.append(float(p.grad.detach().cpu().double().norm() / (gr.double().norm() + 1e-30)))
+            if c < worst:
+                worst, worst_name = c, name
+        parity = {"against": "oracle/model.py (torch-CPU fp32), same B=%d batch and initial parameters, T=%d, V=%d" % (B, T, V),
+                  "loss_gpu": float(loss.item()), "loss_oracle": float(loss_ref.item()),
+                  "loss_rel": abs(float(loss.item()) - float(loss_ref.item())) / abs(float(loss_ref.item())),
+                  "logits_cos": cos(logits, logits_ref.detach()), "worst_param_grad_cos": worst,
+                  "worst_param": worst_name, "grad_norm_ratio_min_max": [min(norm_ratio), max(norm_ratio)],
+                  "note": "bf16 activations / MFMA operands against fp32: BASELINE.md section 3 expects ~1e-2 on the loss; "
+                          "the CTC kernel itself is held to 1e-4 on identical logits (tests/test_ctc_gpu.py)"}
+        del gpu, ys, loss
+        for p in ref.parameters():
+            p.grad = None
     omodel.train_step(ref, mm, vv, 1, x, labels, x_len, l_len)           # warm-up (allocations, oneDNN primitives)
     warm = time.time() - t0
-    log("cpu_baseline: warm-up step %.1f s" % warm)
-    n = max(1, min(5, int(seconds_budget / max(warm, 1e-3)) - 1))
+    log("cpu_baseline: warm-up %.1f s" % warm)
+    t0 = time.time()
+    omodel.train_step(ref, mm, vv, 2, x, labels, x_len, l_len)
+    one = time.time() - t0
+    n = max(1, min(5, int(seconds_budget / max(one, 1e-3)) - 1))
     t0 = time.time()
     for s in range(n):
-        omodel.train_step(ref, mm, vv, 2 + s, x, labels, x_len, l_len)
+        omodel.train_step(ref, mm, vv, 3 + s, x, labels, x_len, l_len)
     dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of B=%d utterances (T=%d, V=%d, same model, fp32, torch-CPU oracle) after 1 warm-up; %.2f s/step"
-                      % (n, B, T, V, dt)}
+    out = {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+           "sample": "%d train steps of B=%d utterances (T=%d, V=%d, same model, fp32, torch-CPU oracle) after 2 warm-up; %.2f s/step"
+                     % (n, B, T, V, dt)}
+    return out, parity
 
 
 def main():
@@ -330,7 +374,7 @@ def main():
                                 "unit": "TFLOP/s", "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                 "ms": gemm_ms}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, T, V)
+        out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, T, V, dev)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
