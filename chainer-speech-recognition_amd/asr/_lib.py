@@ -30,6 +30,7 @@ SIGNATURES = {
     "asr_logmel": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_void_p]),
     "asr_deltas": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     "asr_batchnorm_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_float, c_float] + [c_void_p] * 5),
+    "asr_rsqrt_eps": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int]),
     "asr_batchnorm_fwd": (c_int, [c_void_p] * 6 + [c_longlong, c_int, c_void_p]),
     "asr_batchnorm_bwd": (c_int, [c_void_p] * 6 + [c_longlong, c_int] + [c_void_p] * 4),
     "asr_cmn_pspec": (c_int, [c_void_p] * 3 + [c_int] * 3),

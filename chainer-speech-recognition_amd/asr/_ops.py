@@ -571,6 +571,12 @@ def batchnorm_stats(x2, eps, decay, avg_mean=None, avg_var=None):
     return mean, rstd
 
 
+def rsqrt_eps(var, eps):
+    out = torch.empty_like(var)
+    check(_lib.lib().asr_rsqrt_eps(stream(), ptr(var), float(eps), ptr(out), var.numel()), "asr_rsqrt_eps")
+    return out
+
+
 def batchnorm_fwd(x2, mean, rstd, gamma, beta):
     R, C = x2.shape
     y = torch.empty_like(x2)

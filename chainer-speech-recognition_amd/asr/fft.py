@@ -27,17 +27,21 @@ def mel2hz(mel):
 
 
 def get_filterbanks(nfilt=20, nfft=512, samplerate=16000, lowfreq=0, highfreq=None):
-    """asr/fft.py:68-82 (host constant, float64)."""
+    """The (nfilt, nfft/2+1) triangular mel filterbank of asr/fft.py:68-82 -- a CONSTANT TABLE that must equal the reference's
+    bit for bit (tests/golden/fft.npz), built once on the host in float64: filter j rises over FFT bins [b_j, b_{j+1}) as
+    (i - b_j) / (b_{j+1} - b_j) and falls over [b_{j+1}, b_{j+2}) as (b_{j+2} - i) / (b_{j+2} - b_{j+1}), with
+    b = floor((nfft + 1) * mel2hz(linspace(hz2mel(low), hz2mel(high), nfilt + 2)) / samplerate).  Same float64 operations
+    per entry as the reference's double loop, evaluated per filter on index vectors."""
     highfreq = highfreq or samplerate / 2
     assert highfreq <= samplerate / 2, "highfreq is greater than samplerate/2"
-    melpoints = np.linspace(hz2mel(lowfreq), hz2mel(highfreq), nfilt + 2)
-    bin = np.floor((nfft + 1) * mel2hz(melpoints) / samplerate)
+    edges = np.floor((nfft + 1) * mel2hz(np.linspace(hz2mel(lowfreq), hz2mel(highfreq), nfilt + 2)) / samplerate)
     fbank = np.zeros([nfilt, nfft // 2 + 1])
-    for j in range(0, nfilt):
-        for i in range(int(bin[j]), int(bin[j + 1])):
-            fbank[j, i] = (i - bin[j]) / (bin[j + 1] - bin[j])
-        for i in range(int(bin[j + 1]), int(bin[j + 2])):
-            fbank[j, i] = (bin[j + 2] - i) / (bin[j + 2] - bin[j + 1])
+    for j in range(nfilt):
+        lo, mid, hi = edges[j], edges[j + 1], edges[j + 2]
+        rise = np.arange(int(lo), int(mid))
+        fall = np.arange(int(mid), int(hi))
+        fbank[j, rise] = (rise - lo) / (mid - lo)
+        fbank[j, fall] = (hi - fall) / (hi - mid)
     return fbank
 
 

@@ -671,9 +671,8 @@ class _BatchNorm(torch.autograd.Function):
 
 
 def _rsqrt_eps(var, eps):
-    """1 / sqrt(var + eps) on C values through the library (asr_batchnorm_stats is not needed for fixed statistics)"""
-    import numpy as np
-    return torch.from_numpy((1.0 / np.sqrt(var.cpu().numpy().astype(np.float64) + eps)).astype(np.float32)).to(var.device)
+    """1 / sqrt(var + eps) on C values (asr_rsqrt_eps): the inference form's rstd from the running variance"""
+    return _ops.rsqrt_eps(var, eps)
 
 
 def batch_normalization(x, gamma, beta, avg_mean, avg_var, eps=2e-5, decay=0.9):

@@ -49,19 +49,48 @@ class BiGRU(_GRUBase):
 
 
 class _NStep(Link):
+    """chainer.links.NStepGRU / NStepBiGRU call semantics: ``hy, ys = rnn(hx, xs)`` with ``xs`` a list of (T_i, I) sequences
+    (any lengths), ``hx`` None (zero initial state; a given initial state is not supported by the recurrence kernels),
+    ``ys`` a list of (T_i, ndir * H) outputs with the two directions CONCATENATED, ``hy`` (n_layers * ndir, B, H) the last
+    states.  The reference never builds one, so this is API surface, not hot path: sequences are grouped by
+    length, every group runs as one batch through per-direction GRU links (the backward direction on the time-reversed
+    group); joins / reversals are torch copies."""
+
     def __init__(self, n_layers, in_size, out_size, dropout, ndir):
         super().__init__()
-        self.n_layers = n_layers
-        self.dropout = dropout
+        self.n_layers, self.out_size, self.dropout, self.ndir = n_layers, out_size, dropout, ndir
         for i in range(n_layers):
-            setattr(self, "l%d" % i, _GRUBase(in_size if i == 0 else out_size, out_size, ndir))
+            for d in range(ndir):
+                setattr(self, "l%d_%d" % (i, d), _GRUBase(in_size if i == 0 else out_size * ndir, out_size, 1))
 
-    def __call__(self, x):
-        for i in range(self.n_layers):
-            x = getattr(self, "l%d" % i)(x)
-            if self.dropout and i + 1 < self.n_layers:
-                x = functions.dropout(x, self.dropout)
-        return x
+    def __call__(self, hx, xs):
+        if hx is not None:
+            raise NotImplementedError("an initial hidden state is not supported: pass hx=None (zeros)")
+        if not isinstance(xs, (list, tuple)) or len(xs) == 0:
+            raise TypeError("xs must be a list of (T_i, I) sequences")
+        groups = {}
+        for idx, x in enumerate(xs):
+            groups.setdefault(int(x.shape[0]), []).append(idx)
+        ys = [None] * len(xs)
+        hy = [[None] * len(xs) for _ in range(self.n_layers * self.ndir)]
+        for T, members in groups.items():
+            h = torch.stack([xs[i] for i in members], dim=0).permute(0, 2, 1)        # (Bg, I, T), the links' layout
+            for layer in range(self.n_layers):
+                outs = []
+                for d in range(self.ndir):
+                    link = getattr(self, "l%d_%d" % (layer, d))
+                    y = link(h if d == 0 else torch.flip(h, dims=(2,)))
+                    y = y if d == 0 else torch.flip(y, dims=(2,))
+                    outs.append(y)
+                    last = y[:, :, -1] if d == 0 else y[:, :, 0]
+                    for k, i in enumerate(members):
+                        hy[layer * self.ndir + d][i] = last[k]
+                h = outs[0] if self.ndir == 1 else torch.cat(outs, dim=1)
+                if self.dropout and layer + 1 < self.n_layers:
+                    h = functions.dropout(h, self.dropout)
+            for k, i in enumerate(members):
+                ys[i] = h[k].permute(1, 0)                                              # (T_i, ndir * H)
+        return torch.stack([torch.stack(row, dim=0) for row in hy], dim=0), ys
 
 
 class NStepGRU(_NStep):

@@ -582,6 +582,22 @@ extern "C" int asr_batchnorm_stats(void* stream, const void* x_bf16, long long R
     return ASR_OK;
 }
 
+namespace asr { namespace ln {
+__global__ void rsqrt_eps_kernel(const float* __restrict__ var, float eps, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)(1.0 / sqrt((double)var[i] + (double)eps));
+}
+} }
+
+// inference-mode batch normalisation: rstd from the running variance (chainer.links.BatchNormalization with
+// chainer.config.train == False normalises with avg_var + eps)
+extern "C" int asr_rsqrt_eps(void* stream, const float* var, float eps, float* out, int n) {
+    if (!var || !out || n <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(asr::ln::rsqrt_eps_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, var, eps, out, n);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 extern "C" int asr_batchnorm_fwd(void* stream, const void* x_bf16, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, long long R, int C, void* y_bf16) {
     if (!x_bf16 || !mean || !rstd || !gamma || !beta || !y_bf16 || R <= 0 || C <= 0) return ASR_ERR_BAD_ARG;

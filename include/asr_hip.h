@@ -227,6 +227,8 @@ int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, floa
  */
 int asr_batchnorm_stats(void* stream, const void* x_bf16, long long R, int C, float eps, float decay, double* ws2C,
                         float* mean, float* rstd, float* avg_mean, float* avg_var);
+/* out[i] = 1 / sqrt(var[i] + eps): rstd of the inference form from the running variance */
+int asr_rsqrt_eps(void* stream, const float* var, float eps, float* out, int n);
 int asr_batchnorm_fwd(void* stream, const void* x_bf16, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, long long R, int C, void* y_bf16);
 int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, const float* mean, const float* rstd,

@@ -300,3 +300,21 @@ def test_checkpoint_round_trip_on_a_fresh_model(tmp_path):
     _, third = _ds2_small()
     third.load_state_dict(m.state_dict())
     assert torch.equal(third.dense_blocks.layers[7].norm.gamma, m.dense_blocks.layers[7].norm.gamma)
+
+
+@pytest.mark.parametrize("arch,nconv,wn", [("zhang", 3, False), ("zhang", 6, False), ("zhang+fc_relu", 2, False), ("zhang+residual", 4, False),
+                                           ("zhang+residual", 6, True), ("zhang+layernorm", 2, False), ("glu", 3, True),
+                                           ("relu+layernorm", 2, False), ("relu+layernorm+residual", 3, False)])
+def test_recipe_parameter_names_agree_with_the_oracles_bookkeeping(arch, nconv, wn):
+    """asr.model.architectures.build_model and oracle/cnn.py both replay run/ctc/cnn/model.py's layer bookkeeping
+    (``layer_%d`` / ``layer_%d_%d``, asr/nn/nn.py:304-320) -- independently; their parameter names must coincide"""
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    from oracle import cnn as ocnn
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = 19, 3, 8, 12, nconv
+    cfg.architecture, cfg.weightnorm = arch, wn
+    model = build_model(cfg)
+    mine = sorted({n.rsplit(".", 1)[0] for n, _ in model.named_parameters()})
+    theirs = sorted({name for _, name, _ in ocnn.program(arch, cfg) if name is not None})
+    assert mine == theirs

@@ -393,3 +393,92 @@ def test_save_fresh_build_load_gives_identical_logits(device, tmp_path):
     assert fresh.load(path) is True
     y1 = torch.stack(fresh(xd)).detach()
     assert torch.equal(y0, y1)
+
+
+def test_joint_gram_ctc_and_ctc_on_one_model_output(device):
+    """run/gram_ctc/cnn/train.py:163-167,195-198 (--joint-training): loss = gram_ctc(y, t, bigram, ...) + CTC(y, t, ...) on
+    the SAME logits.  Two consumers of the float32 logits: each loss hands autograd a float32 gradient, LayerNormalization's
+    backward sums them and posts ONE bf16 gradient into the projection's mailbox.  Checked: the joint loss is the sum of the
+    two, and every parameter gradient of the joint step equals the sum of the gradients of the two separate steps."""
+    from asr.loss import connectionist_temporal_classification, gram_ctc
+    from asr.data.synthetic import synthetic_batch, synthetic_gram_labels
+    from oracle import ctc as octc
+    B, T, V, nuni = 4, 60, 60, 20
+    x, labels, x_len, l_len = synthetic_batch(B, T, nuni, Lmin=3, Lmax=8, seed=3, ragged=True)
+    bigram = synthetic_gram_labels(labels, l_len, V, first_bigram=nuni, seed=3)
+    xd, ld, bd, xl, ll = (t.to(device) for t in (x, labels, bigram, x_len, l_len))
+
+    def run(which):
+        cfg, model = _build(device, V=V, seed=21)
+        ys = model(xd)
+        terms = []
+        if which in ("gram", "joint"):
+            terms.append(gram_ctc(ys, ld, bd, 0, xl, ll))
+        if which in ("ctc", "joint"):
+            terms.append(connectionist_temporal_classification(ys, ld, 0, xl, ll))
+        loss = terms[0] if len(terms) == 1 else terms[0] + terms[1]
+        loss.backward()
+        from asr.functions import join_side_stream
+        join_side_stream()
+        torch.cuda.synchronize()
+        return loss.item(), torch.stack(tuple(ys)).detach().cpu(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}
+
+    lg, logits, gg = run("gram")
+    lc, _, gc = run("ctc")
+    lj, _, gj = run("joint")
+    assert abs(lj - (lg + lc)) <= 1e-5 * abs(lj)
+    # both loss values against the float64 oracle on the device's own logits (1e-4: BASELINE.json)
+    lo_g, _ = octc.gram_ctc_loss_grad(logits.numpy(), labels.numpy(), bigram.numpy(), 0, x_len.numpy(), l_len.numpy(), "mean")
+    lo_c, _ = octc.ctc_loss_grad(logits.numpy(), labels.numpy(), 0, x_len.numpy(), l_len.numpy(), "mean")
+    assert abs(lg - lo_g) <= 1e-4 * abs(lo_g) and abs(lc - lo_c) <= 1e-4 * abs(lo_c)
+    for name in gj:
+        want = gg[name] + gc[name]
+        err = float((gj[name] - want).norm() / (want.norm() + 1e-30))
+        assert err < 2e-2, (name, err)          # one bf16 rounding of the summed logit gradient instead of two
+
+
+@pytest.mark.parametrize("arch,nconv,wn", [("zhang", 3, False), ("zhang+fc_relu", 2, False), ("zhang+residual", 4, False),
+                                           ("zhang+residual", 6, False), ("zhang+residual", 5, True), ("zhang+layernorm", 2, False),
+                                           ("glu", 2, False), ("glu", 2, True), ("relu+layernorm", 2, False),
+                                           ("relu+layernorm+residual", 3, False)])
+def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
+    """row a19 / BASELINE configs[4]: every recipe of run/ctc/cnn/model.py -- incl. `zhang+residual` at 4 conv layers and its
+    wide "VGG-deep" branch (num_conv_layers > 4, :153-157,177-187) and the weight-normalised variants -- forward + CTC +
+    backward on the HIP path against oracle/cnn.py (torch-CPU fp32 restatement of the recipe) with the same parameters:
+    logits, loss and every parameter gradient."""
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    from asr.loss import connectionist_temporal_classification
+    from oracle import cnn as ocnn
+    torch.manual_seed(3)
+    V, B, T = 19, 3, 36
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = V, 3, 16, 24, nconv
+    cfg.architecture, cfg.weightnorm = arch, wn
+    model = build_model(cfg).to_gpu()
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=2, Lmax=6, seed=7, ragged=True)
+    xd = x.to(device)
+    with torch.no_grad():
+        model(xd)                                   # lazily sized parameters; data-dependent weight-norm initialisation
+    ys = model(xd)
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+    loss.backward()
+    from asr.functions import join_side_stream
+    join_side_stream()
+    torch.cuda.synchronize()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    out = ocnn.forward(arch, cfg, params, x)
+    assert out.shape == (B, V, 1, T)
+    logits_ref = ocnn.logits_tbv(out)
+    loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+    loss_ref.backward()
+    logits = torch.stack(tuple(ys)).detach().float().cpu()
+    assert _cos(logits, logits_ref.detach()) > 0.998, _cos(logits, logits_ref.detach())
+    assert abs(loss.item() - loss_ref.item()) <= 3e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    for name, p in model.named_parameters():
+        g_ref = params[name].grad
+        assert p.grad is not None and g_ref is not None, name
+        c = _cos(p.grad.cpu(), g_ref)
+        assert c > 0.95, (name, c)
+        ratio = p.grad.cpu().norm().item() / (g_ref.norm().item() + 1e-30)
+        assert 0.85 < ratio < 1.15, (name, ratio)

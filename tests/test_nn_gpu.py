@@ -364,3 +364,34 @@ def test_layernorm_and_weightnorm_against_reference_goldens(device, golden_dir):
     W, norm = _ops.weightnorm_fwd(torch.tensor(g["V"]).to(device), torch.tensor(g["g"]).to(device))
     np.testing.assert_allclose(norm.cpu().numpy(), g["norm"].reshape(-1), rtol=1e-6)
     np.testing.assert_allclose(W.cpu().numpy(), g["W"], rtol=2e-6, atol=1e-7)
+
+
+def test_nstep_bigru_has_chainers_call_semantics(device):
+    """hy, ys = NStepBiGRU(n_layers, in, out, dropout)(None, [x_0, x_1, ...]) with ragged (T_i, I) sequences: outputs
+    (T_i, 2H) with the directions concatenated, hy (n_layers * 2, B, H); against torch.nn.GRU per sequence"""
+    import asr.nn as nn
+    torch.manual_seed(0)
+    I, H, L = 16, 32, 2
+    rnn = nn.NStepBiGRU(L, I, H, 0).to_gpu()
+    lens = [9, 14, 9, 5]
+    xs = [_bf(torch.randn(t, I)) for t in lens]
+    hy, ys = rnn(None, [x.to(device) for x in xs])
+    assert hy.shape == (L * 2, len(lens), H) and [tuple(y.shape) for y in ys] == [(t, 2 * H) for t in lens]
+    ref = torch.nn.GRU(I, H, num_layers=L, bidirectional=True)
+    with torch.no_grad():
+        for layer in range(L):
+            for d, suf in enumerate(("", "_reverse")):
+                link = getattr(rnn, "l%d_%d" % (layer, d))
+                getattr(ref, "weight_ih_l%d%s" % (layer, suf)).copy_(_bf(link.w_ih.detach().cpu()[0]))
+                getattr(ref, "weight_hh_l%d%s" % (layer, suf)).copy_(_bf(link.w_hh.detach().cpu()[0]))
+                getattr(ref, "bias_ih_l%d%s" % (layer, suf)).copy_(link.b_ih.detach().cpu()[0])
+                getattr(ref, "bias_hh_l%d%s" % (layer, suf)).copy_(link.b_hh.detach().cpu()[0])
+    for i, x in enumerate(xs):
+        yr, hr = ref(x[:, None, :])
+        assert _rel(ys[i].float().cpu(), yr[:, 0].detach()) < 2e-2, i
+        assert _rel(hy[:, i].float().cpu(), hr[:, 0].detach()) < 2e-2, i
+    loss = sum(y.float().sum() for y in ys)
+    loss.backward()
+    assert rnn.l0_1.w_hh.grad is not None and torch.isfinite(rnn.l1_0.w_ih.grad).all()
+    with pytest.raises(NotImplementedError):
+        rnn(torch.zeros(L * 2, len(lens), H, device=device), [x.to(device) for x in xs])
