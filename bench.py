@@ -39,7 +39,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--vocab", type=int, default=3000)
+    ap.add_argument("--vocab", type=int, default=None, help="default 3000 (ds2) / 119 (cnn: the reference's unigram inventory)")
+    ap.add_argument("--config", choices=("ds2", "cnn"), default="ds2",
+                    help="ds2: BASELINE configs[1] (the metric's configuration, default); cnn: BASELINE configs[4], the fully "
+                         "convolutional `zhang+residual` recipe of run/ctc/cnn/model.py:142-204 (V=119 unless --vocab is given)")
+    ap.add_argument("--num-conv-layers", type=int, default=4,
+                    help="--config cnn: 4 = the reference's default depth (164 GFLOP/utterance); > 4 = the wide 'VGG-deep' "
+                         "branch, always 8 conv layers (822 GFLOP/utterance): run/ctc/cnn/model.py:153-157,177-187")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--halves", type=int, default=int(os.environ.get("ASR_BENCH_HALVES", "0")),
@@ -205,8 +211,118 @@ def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
     return out, parity
 
 
+def cnn_config(args, V):
+    from asr.model import cnn
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense = V, 3, 128, 320      # run/ctc/cnn/args.py:28-30
+    cfg.num_conv_layers, cfg.architecture = int(args.num_conv_layers), "zhang+residual"
+    return cfg
+
+
+def cnn_macs_per_frame(cfg):
+    """multiply-accumulates of one forward pass of `zhang+residual` per frame, layer by layer from the recipe
+    (run/ctc/cnn/model.py:142-204; SURVEY.md section 8d: 27.3 M at 4 conv layers, 137 M for the wide branch)"""
+    import math
+    h, dense, V, cin = cfg.ndim_h, cfg.ndim_dense, cfg.vocab_size, cfg.ndim_audio_features
+    kh, kw = cfg.kernel_size
+    taps = kh * kw
+    height = cfg.num_mel_filters - (kh - 1)                       # first layer: pad_h = 0
+    macs = height * (2 * h) * cin * taps
+    height = int(math.ceil(height / 3.0))                         # MaxPooling2D((3, 1)), cover_all
+    narrow, wide = min(cfg.num_conv_layers, 4), max(0, cfg.num_conv_layers - 4)
+    for idx in range(narrow):
+        co = 4 * h if (wide > 0 and idx == narrow - 1) else 2 * h
+        macs += height * co * h * taps
+    if wide > 0:
+        macs += narrow * height * (4 * h) * (2 * h) * taps
+    dense_in = 2 * h if wide > 0 else h
+    kernel_height = int(math.ceil((cfg.num_mel_filters - 2) / 3))
+    macs += (2 * dense) * dense_in * kernel_height + (2 * dense) * dense + V * dense
+    return macs
+
+
+def cpu_baseline_cnn(cfg, T, V, dev=None, seconds_budget=25.0):
+    """--config cnn: oracle/cnn.py (torch-CPU fp32 restatement of the recipe) + the oracle's clip/decay/Adam step on a
+    bounded sample, and the parity of the HIP path on that sample (same B=2 batch, same initial parameters)."""
+    import numpy as np
+    from asr.model.architectures import build_model
+    from oracle import cnn as ocnn
+    from oracle import model as omodel
+    torch.manual_seed(0)
+    B = 2
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, seed=0)
+    gpu = build_model(cfg)
+    if dev is None:
+        raise RuntimeError("the CNN recipes size their layer norms lazily: a device is needed to materialise them")
+    gpu.to_gpu(dev.index)
+    with torch.no_grad():
+        gpu(x.to(dev))
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in gpu.named_parameters()}
+    plist = list(params.values())
+
+    class Ref(object):
+        def parameters(self):
+            return plist
+
+        def __call__(self, xx):
+            return ocnn.logits_tbv(ocnn.forward(cfg.architecture, cfg, params, xx))
+    ref = Ref()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail, torch.get_num_threads()))
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d threads" % cores)
+    t0 = time.time()
+    logits_ref = ref(x)
+    loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+    loss_ref.backward()
+    from asr.loss import connectionist_temporal_classification
+    ys = gpu(x.to(dev))
+    loss = connectionist_temporal_classification(ys, labels.to(dev), 0, x_len.to(dev), l_len.to(dev))
+    loss.backward()
+    from asr.functions import join_side_stream
+    join_side_stream()
+    torch.cuda.synchronize()
+
+    def cos(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float(a @ b / (a.norm() * b.norm() + 1e-30))
+    worst, worst_name = 1.0, None
+    for name, p in gpu.named_parameters():
+        c = cos(p.grad.detach().cpu(), params[name].grad)
+        if c < worst:
+            worst, worst_name = c, name
+    parity = {"against": "oracle/cnn.py (torch-CPU fp32), same B=%d batch and initial parameters, T=%d, V=%d" % (B, T, V),
+              "loss_gpu": float(loss.item()), "loss_oracle": float(loss_ref.item()),
+              "loss_rel": abs(float(loss.item()) - float(loss_ref.item())) / abs(float(loss_ref.item())),
+              "logits_cos": cos(torch.stack(tuple(ys)).detach().float().cpu(), logits_ref.detach()),
+              "worst_param_grad_cos": worst, "worst_param": worst_name}
+    del gpu, ys, loss
+    for q in plist:
+        q.grad = None
+    mm = [torch.zeros_like(q) for q in plist]
+    vv = [torch.zeros_like(q) for q in plist]
+    omodel.train_step(ref, mm, vv, 1, x, labels, x_len, l_len)
+    log("cpu_baseline: warm-up %.1f s" % (time.time() - t0))
+    t0 = time.time()
+    omodel.train_step(ref, mm, vv, 2, x, labels, x_len, l_len)
+    one = time.time() - t0
+    n = max(1, min(5, int(seconds_budget / max(one, 1e-3)) - 1))
+    t0 = time.time()
+    for k in range(n):
+        omodel.train_step(ref, mm, vv, 3 + k, x, labels, x_len, l_len)
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of B=%d utterances (T=%d, V=%d, same recipe, fp32, torch-CPU oracle) after 2 warm-up; %.2f s/step"
+                      % (n, B, T, V, dt)}, parity
+
+
 def main():
     args = parse()
+    if args.vocab is None:
+        args.vocab = 3000 if args.config == "ds2" else 119
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -232,12 +348,20 @@ def main():
         comm = Communicator(os.environ.get("ASR_BENCH_BACKEND", "nccl"))
 
     B, T, V = args.batch, args.frames, args.vocab
-    cfg = ds2.configure()
-    cfg.vocab_size = V
     torch.manual_seed(0)                         # identical initial weights on every rank (also broadcast below)
-    model = ds2.Model(cfg).to_gpu(local_rank)
+    if args.config == "cnn":
+        from asr.model.architectures import build_model
+        cfg = cnn_config(args, V)
+        model = build_model(cfg).to_gpu(local_rank)
+    else:
+        cfg = ds2.configure()
+        cfg.vocab_size = V
+        model = ds2.Model(cfg).to_gpu(local_rank)
     x, labels, x_len, l_len = synthetic_batch(B, T, V, seed=rank)
     x, labels, x_len, l_len = x.to(dev), labels.to(dev), x_len.to(dev), l_len.to(dev)
+    if args.config == "cnn":
+        with torch.no_grad():
+            model(x)                             # the recipes size their layer norms lazily: materialise before opt.setup
 
     opt = Adam(alpha=1e-3, beta1=0.9)
     opt.setup(model)
@@ -291,8 +415,12 @@ def main():
     out = {"metric": "utterances/sec (T=1000, 40x3 feat, |V|~3000) CTC train step", "value": value, "unit": "utterances/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
-                                  "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V),
+           "config": {"workload": ("BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
+                                   "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V)) if args.config == "ds2" else
+                                  ("BASELINE configs[4]: fully convolutional zhang+residual (run/ctc/cnn/model.py:142-204), ndim_h 128, "
+                                   "ndim_dense 320, %s, + LayerNorm + CTC train step, B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120; "
+                                   "bf16 MFMA operands (the deliberate substitute for fp16: DESIGN.md section 4)"
+                                   % ("4 conv layers" if args.num_conv_layers <= 4 else "wide branch: 8 conv layers", B, T, V)),
                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
                       "final_loss": loss_value}}
 
@@ -324,6 +452,30 @@ def main():
         tot["ctc_grad"] = (ctc["ctc_grad"], 1)
         breakdown = {k: {"ms": round(ms, 3), "calls": n} for k, (ms, n) in sorted(tot.items(), key=lambda kv: -kv[1][0])}
         out["kernel_ms_per_step"] = breakdown
+        if args.config == "cnn":
+            # dominant kernel class: the implicit-GEMM convolutions (forward, backward-data, weight gradient) and the 1x1 /
+            # kernel_height "dense" convolutions -- MFMA-bound: 2 flops per multiply-accumulate, x3 for the train step
+            macs = cnn_macs_per_frame(cfg)
+            gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
+            launches = sum(tot.get(k, (0.0, 0))[1] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
+            flops = 3 * 2.0 * macs * T * B
+            out["roofline"] = {"bound": "mfma", "kernel": "asr::gemm implicit-GEMM convolutions (conv_nt / conv_tn_acc) + gemm_nt / gemm_tn",
+                               "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "ms": gemm_ms, "launches_per_step": launches, "gflop_per_utterance": 3 * 2.0 * macs * T / 1e9,
+                               "note": "algorithmic flops of the recipe (SURVEY.md section 8d) / HIP-event time of the GEMM-class calls "
+                                       "of one single-stream step; HBM-bound elementwise kernels (maxout, pooling, residual add, "
+                                       "layer norm) and the CTC sweep are listed in kernel_ms_per_step"}
+            ctc_bytes = 2.0 * T * B * V * 4
+            ctc_ms = ctc["ctc_forward"] + ctc["ctc_grad"]
+            out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                                         "unit": "GB/s", "frac": ctc_bytes / (ctc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "ms": ctc_ms,
+                                         "algorithmic_bytes": ctc_bytes}
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"], out["parity"] = cpu_baseline_cnn(cfg, T, V, dev)
+                out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
+            print(json.dumps(out))
+            return
         H, nl = cfg.ndim_rnn, cfg.num_rnn_layers
         # dominant kernel class: the persistent GRU kernels.  One launch = one layer, both directions, all T steps.
         gru_ms = tot["gru_fwd"][0] + tot["gru_bwd"][0]
