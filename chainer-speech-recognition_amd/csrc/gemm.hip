@@ -294,6 +294,13 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
     const uint16_t* ga[4];
     const uint16_t* gb[WN];
     int cth[4];                            // CONV: (t << 8) | h of the slot's row; rows beyond M get a t far below zero
+    // CONV with Cs % 32 == 0 (every layer but the first): a 32-wide K step lies inside ONE tap, the same for every row, so
+    // the tap walk (kh, kw, channel base) is scalar state advanced once per issued tile, and a lane only adds a uniform
+    // offset to its own row pointer and checks two ranges.  (The general form below decomposes k per lane and per piece:
+    // two integer divisions by runtime values, ~60 VALU instructions per LDS-DMA piece -- more issue time than the tile's
+    // MFMAs, which is what held the implicit convolutions near 500 TFLOP/s.)
+    const bool tap_uniform = CONV && (cd.Cs % B2K) == 0;
+    int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // tap walk of the NEXT tile to issue (tiles are issued in k order)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int sl = i * 256 + tid, row = sl >> 2, c = (sl & 3) ^ g4(row);
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
             const int h = rr % cd.Hr, tb = rr / cd.Hr, b = tb % cd.B, t = r < M ? tb / cd.B : -(1 << 20);
             cth[i] = t * 256 + h;
             ga[i] = A + ((size_t)b * cd.Hs) * cd.Cs;                 // + ((ti * B) * Hs + hi) * Cs + ci per tile
+            if (tap_uniform && r < M) ga[i] += ((long long)t * cd.B * cd.Hs + h) * cd.Cs + c * 8;      // the row's own (t, h), this lane's chunk
         } else {
             ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
         }
@@ -313,10 +321,26 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
         gb[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
     }
     auto issue_tile = [&](int kt, int buf) {
+        // uniform part of the fast convolution form
+        int dt = 0, dh = 0;
+        long long delta = 0;
+        bool tap_ok = false;
+        if (tap_uniform) {
+            dt = cd.sgn * (tw_kw - cd.pt);
+            dh = cd.sgn * (tw_kh - cd.ph);
+            delta = ((long long)dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci;
+            tap_ok = tw_kh < cd.KH;                                  // (K may be padded with empty taps)
+            tw_ci += B2K;
+            if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint16_t* src;
-            if (CONV) {
+            if (CONV && tap_uniform) {
+                const int ti = (cth[i] >> 8) + dt, hi = (cth[i] & 255) + dh;
+                const bool ok = tap_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                src = ok ? ga[i] + delta : reinterpret_cast<const uint16_t*>(g_zero_page);
+            } else if (CONV) {
                 const int sl = i * 256 + tid, row = sl >> 2;
                 const int k = kt * B2K + ((sl & 3) ^ g4(row)) * 8;
                 const int tap = k / cd.Cs, ci = k - tap * cd.Cs;
@@ -430,6 +454,193 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256 x 256 tile
+// The 256 x 128 kernel above is bound by operand fill, not by the matrix pipes (SQ counters on the model's projections:
+// waves parked on vmcnt / barriers half of their life, MFMA pipes 22 % busy): a 256 x 128 x 32 step moves 24 KB from L2
+// into LDS for 128 MFMAs.  Here EIGHT waves -- 2 (M) x 4 (N), each the same 128 x 64 = 8 x 4 MFMA tiles -- share a
+// 256 x 256 tile: 32 KB per 256 MFMAs, two thirds of the fill per flop (and for N <= 256 -- the convolutions of the recipes
+// -- the activation operand is streamed ONCE instead of once per column tile); every wave issues 4 LDS-DMA pieces per 32
+// MFMAs instead of 6.  One workgroup per CU, two waves per SIMD, STAGES-deep ring (STAGES - 1 tiles in flight).
+// BKT = 32: LDS rows of 64 B, swizzle as above.  BKT = 64: rows of 128 B = whole cache lines per row and K step, 16-B chunk
+// c of row r at position c ^ (r & 7) (the ds_read_b128 lane groups then cover all 64 banks).
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+template <typename OutT, bool CONV, int BKT, int STAGES>
+__global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
+                                                           int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                           int M, int N, int K, int tiles_n, ConvDesc cd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 256, TNC = 256, THREADS = 512, MI = 8;
+    constexpr int CH = BKT / 8;                         // 16-B chunks per LDS row
+    constexpr int ROWB = BKT * 2;                       // bytes per LDS row
+    constexpr int A_SLOTS = TM * CH / THREADS, B_SLOTS = TNC * CH / THREADS, P = A_SLOTS + B_SLOTS;
+    constexpr int A_STAGE = TM * ROWB, B_STAGE = TNC * ROWB;
+    int tm, tn;
+    tile_of(blockIdx.x, (M + TM - 1) / TM, tiles_n, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TNC;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    char* As = smem;
+    char* Bs = smem + STAGES * A_STAGE;
+    auto swz = [](int row) { return BKT == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : (row & 7); };
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const uint16_t* ga[A_SLOTS];
+    const uint16_t* gb[B_SLOTS];
+    int cth[A_SLOTS];
+    int tw_kh = 0, tw_kw = 0, tw_ci = 0;
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) {
+        const int sl = i * THREADS + tid, row = sl / CH, c = (sl % CH) ^ swz(row);
+        if (CONV) {
+            const int r = m0 + row;
+            const int rr = r < M ? r : 0;
+            const int h = rr % cd.Hr, tb = rr / cd.Hr, b = tb % cd.B, t = r < M ? tb / cd.B : -(1 << 20);
+            cth[i] = t * 256 + h;
+            ga[i] = A + ((size_t)b * cd.Hs) * cd.Cs;
+            if (r < M) ga[i] += ((long long)t * cd.B * cd.Hs + h) * cd.Cs + c * 8;
+        } else {
+            ga[i] = A + (size_t)min(m0 + row, M - 1) * lda + c * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_SLOTS; ++i) {
+        const int sl = i * THREADS + tid, row = sl / CH, c = (sl % CH) ^ swz(row);
+        gb[i] = B + (size_t)min(n0 + row, N - 1) * ldb + c * 8;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        int dt = 0, dh = 0;
+        long long delta = 0;
+        bool tap_ok = false;
+        if (CONV) {
+            dt = cd.sgn * (tw_kw - cd.pt);
+            dh = cd.sgn * (tw_kh - cd.ph);
+            delta = ((long long)dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci;
+            tap_ok = tw_kh < cd.KH;
+            tw_ci += BKT;
+            if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } }
+        }
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const uint16_t* src;
+            if (CONV) {
+                const int ti = (cth[i] >> 8) + dt, hi = (cth[i] & 255) + dh;
+                const bool ok = tap_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                src = ok ? ga[i] + delta : reinterpret_cast<const uint16_t*>(g_zero_page);
+            } else {
+                src = ga[i] + kt * BKT;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + (i * THREADS + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[i] + kt * BKT), (lds_ptr_t)(Bs + buf * B_STAGE + (i * THREADS + wid * 64) * 16), 16, 0, 0);
+    };
+    // fragment byte offsets inside a stage, per 32-wide K slice
+    int aoff[MI], boff[4];
+    {
+        const int q = lane >> 4, r = lane & 15;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * 128 + i * 16 + r;
+            aoff[i] = row * ROWB + ((q ^ swz(row)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wn * 64 + j * 16 + r;
+            boff[j] = row * ROWB + ((q ^ swz(row)) << 4);
+        }
+    }
+    auto wait_tiles_in_flight = [](int tiles) {
+        if (tiles >= 2) wait_vmcnt<2 * P>();
+        else if (tiles == 1) wait_vmcnt<P>();
+        else wait_vmcnt<0>();
+    };
+    static_assert(STAGES >= 2 && STAGES <= 3, "ring depth");
+    constexpr int S = STAGES;
+    const int nk = K / BKT;
+    for (int t = 0; t < S - 1 && t < nk; ++t) issue_tile(t, t);
+    wait_tiles_in_flight(min(S - 2, nk - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + S - 1 < nk) issue_tile(kt + S - 1, buf == 0 ? S - 1 : buf - 1);
+        const char* Ab = As + buf * A_STAGE;
+        const char* Bb = Bs + buf * B_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BKT / 32; ++ks) {
+            // second 32-wide slice of a 128-B row: chunk index + 4, i.e. the position XORed with 4 (the swizzle only
+            // touches the low bits it was given)
+            const int kx = ks << 6;
+            Frag b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const uint4*>(Bb + (boff[j] ^ kx));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                Frag a;
+                a.u = *reinterpret_cast<const uint4*>(Ab + (aoff[i] ^ kx));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+            }
+        }
+        wait_tiles_in_flight(min(S - 2, nk - 2 - kt));
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        buf = buf == S - 1 ? 0 : buf + 1;
+    }
+
+    // epilogue: 32 rows at a time through LDS (f32, row pitch 260 floats = 33 KB) and whole rows out
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CP = TNC + 4, ER = 32;
+#pragma unroll
+    for (int chunk = 0; chunk < TM / ER; ++chunk) {
+        if (wm == chunk / 4) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ii * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * CP + col] = acc[(chunk & 3) * 2 + ii][j][r];
+                    }
+        }
+        __syncthreads();
+        for (int id = tid; id < ER * (TNC / 4); id += THREADS) {
+            const int row = id / (TNC / 4), c4 = (id - row * (TNC / 4)) * 4;
+            const int gm = m0 + chunk * ER + row, gn = n0 + c4;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[row * CP + c4]);
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            OutT* dst = C + (size_t)gm * ldc + gn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (bias && gn + e < N) vv[e] += bias[gn + e];
+            if (gn + 3 < N && ((((uintptr_t)dst) & (sizeof(OutT) * 4 - 1)) == 0)) {
+                if (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(vv[0]) | ((uint32_t)f32_to_bf16(vv[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(vv[2]) | ((uint32_t)f32_to_bf16(vv[3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) store_out<OutT>(dst + e, vv[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ TN
 constexpr int TK = 32;               // k rows per LDS tile (one MFMA K step)
 constexpr int TP = BM + 16;          // padded row pitch in elements (288 B): 8 consecutive rows cover all 64 banks
@@ -494,20 +705,47 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
         cv_dh = kh - cd.ph;
         cv_ok = k < N && kh < cd.KH;
     }
-    auto load_conv = [&](int gk) -> uint4 {
+    // CONV: the (t, b, h) of this thread's two reduction rows, decomposed ONCE and then stepped by the k tile (32 rows) with
+    // single carries: three integer divisions by runtime values per load were more issue time than the tile's 16 MFMAs
+    int cv_t[2] = {0, 0}, cv_b[2] = {0, 0}, cv_h[2] = {0, 0};
+    int inc_h = 0, inc_b = 0, inc_t = 0;
+    if (CONV) {
+        inc_h = TK % cd.Hr;
+        const int inc_tb = TK / cd.Hr;
+        inc_b = inc_tb % cd.B;
+        inc_t = inc_tb / cd.B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gk = kbeg + ((tid + i * 256) >> 4);
+            cv_h[i] = gk % cd.Hr;
+            const int tb = gk / cd.Hr;
+            cv_b[i] = tb % cd.B;
+            cv_t[i] = tb / cd.B;
+        }
+    }
+    auto load_conv = [&](int gk, int i) -> uint4 {
+        const int t = cv_t[i], b = cv_b[i], h = cv_h[i];
+        {   // advance to the same row of the next k tile
+            int hh = h + inc_h;
+            const int c1 = hh >= cd.Hr;
+            hh -= c1 ? cd.Hr : 0;
+            int bb = b + inc_b + c1;
+            const int c2 = bb >= cd.B;
+            bb -= c2 ? cd.B : 0;
+            cv_h[i] = hh; cv_b[i] = bb; cv_t[i] = t + inc_t + c2;
+        }
         if (gk >= kend || !cv_ok) return make_uint4(0, 0, 0, 0);
-        const int h = gk % cd.Hr, tb = gk / cd.Hr, b = tb % cd.B, t = tb / cd.B;
         const int ti = t + cv_dt, hi = h + cv_dh;
         if (ti < 0 || ti >= cd.Ts || hi < 0 || hi >= cd.Hs) return make_uint4(0, 0, 0, 0);
         return ld16(B + (((size_t)ti * cd.B + b) * cd.Hs + hi) * cd.Cs + cv_ci);
     };
-    auto load_global = [&](int k0) {
+    auto load_global = [&](int k0) {        // called with k0 = kbeg, kbeg + TK, ... in order (the CONV row walk relies on it)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256;
             const int row = id >> 4, c = id & 15;
             ra[i] = load_one(A, lda, a_vec, k0 + row, m0 + c * 8, M);
-            rb[i] = CONV ? load_conv(k0 + row) : load_one(B, ldb, b_vec, k0 + row, n0 + c * 8, N);
+            rb[i] = CONV ? load_conv(k0 + row, i) : load_one(B, ldb, b_vec, k0 + row, n0 + c * 8, N);
         }
     };
     auto store_lds = [&](int buf) {
@@ -570,6 +808,54 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
 using namespace asr;
 using namespace asr::gemm;
 
+// Which NT kernel serves a call (measured, tools/time_nt.py, TFLOP/s at T=1000, B=32, 13 rows of height, k 3x5):
+//                                      256x128x32 (3 WG/CU)   256x256x32, 3 stages   256x256x64, 2 stages
+//   conv 128->256 fwd                         598                    617                   684
+//   conv 128->512 fwd                         711                    703                   839
+//   conv 256->512 fwd / bwd-data           762 / 752              781 / 754             931 / 914
+//   32000 x 3072 x 512 (f32 out)              527                    428                   487
+//   8192^3                                    963                    765                   953
+// Whole 128-B lines per row and K step are what pays (a 64-B half line per row leaves the other half to be fetched again
+// by the next K step once the tile no longer fits the L1), and only where the 256-wide tile removes a second pass over the
+// activations: the convolutions with more than 128 output channels.  ASR_NT_WIDE overrides (tests, experiments):
+// -1 (default) = 64-wide K for those convolutions only; 0 = never; 1 / 2 = 256x256x32 / 256x256x64 wherever the shape allows.
+static int nt_wide_mode() {
+    static int mode = -2;
+    if (mode == -2) {
+        const char* e = getenv("ASR_NT_WIDE");
+        mode = e ? atoi(e) : -1;
+        if (mode < -1 || mode > 2) mode = -1;
+    }
+    return mode;
+}
+
+// ASR_NT_WIDE_FORCE=1 (tests): take the wide kernel whatever the number of tiles
+static bool nt_wide_force() {
+    static int f = -1;
+    if (f < 0) { const char* e = getenv("ASR_NT_WIDE_FORCE"); f = e && atoi(e) ? 1 : 0; }
+    return f == 1;
+}
+
+template <typename OutT, bool CONV>
+static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const uint16_t* B, int ldb, OutT* C, int ldc, const float* bias,
+                          int M, int N, int K, bool b_fits_l2, const ConvDesc& cd, int mode) {
+    const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+    const int tn_arg = b_fits_l2 ? -tn : tn;
+    if (mode == 2) {
+        constexpr int LDS = 2 * 512 * 128;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, 64, 2>), dim3(tm * tn), dim3(512), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd);
+    } else {
+        constexpr int LDS = 3 * 512 * 64;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, 32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, 32, 3>), dim3(tm * tn), dim3(512), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd);
+    }
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                            const float* bias, int M, int N, int K, int out_bf16) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
@@ -586,6 +872,13 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     }
     const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;      // 2.5 MB of the 4 MB per XCD
     const bool aligned = (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
+    {
+        const int wide = nt_wide_mode() > 0 ? nt_wide_mode() : 0;      // plain GEMMs: only on request
+        if (wide && aligned && (K % (wide == 2 ? 64 : 32)) == 0 && N >= 256 && ((long long)cdiv(M, 256) * cdiv(N, 256) >= 512 || nt_wide_force())) {
+            if (out_bf16) return launch_nt_wide<uint16_t, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
+            return launch_nt_wide<float, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
+        }
+    }
     if (aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024) {      // at least two rounds of 2 workgroups per CU
         static bool attr2 = false;
         if (!attr2) {
@@ -678,6 +971,15 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
         attr = true;
     }
     const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, sgn, Hr};
+    {
+        const int wide = nt_wide_mode() == -1 ? 2 : nt_wide_mode();
+        const int bkt = wide == 2 ? 64 : 32;
+        if (wide && N > 128 && (Cs % bkt) == 0 && (K % bkt) == 0 && (cdiv((int)M, 256) * cdiv(N, 256) >= 256 || nt_wide_force())) {
+            const bool fits = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;
+            if (out_bf16) return launch_nt_wide<uint16_t, true>(stream, (const uint16_t*)x, 0, (const uint16_t*)W, K, (uint16_t*)out, N, bias, (int)M, N, K, fits, cd, wide);
+            return launch_nt_wide<float, true>(stream, (const uint16_t*)x, 0, (const uint16_t*)W, K, (float*)out, N, bias, (int)M, N, K, fits, cd, wide);
+        }
+    }
     const bool narrow = N <= 64;                 // 256 x 64 tiles: no MFMA work on columns that do not exist
     const int t2m = cdiv((int)M, B2M), t2n = cdiv(N, narrow ? 64 : B2N);
     const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;

@@ -558,3 +558,15 @@ def test_persistent_recurrence_waits_out_busy_cus(device):
     for a, b_ in zip(ref, got):
         assert torch.equal(a, b_)
     assert t0.elapsed_time(t1) > 25.0          # the hog really was in the way
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_wide_nt_kernels_in_a_forced_process(mode):
+    """the 256 x 256 NT kernels (csrc/gemm.hip gemm_nt_wide_kernel) normally serve only large convolutions; ASR_NT_WIDE /
+    ASR_NT_WIDE_FORCE (read once per process) route the GEMM and implicit-convolution tests of this file through them"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_NT_WIDE=mode, ASR_NT_WIDE_FORCE="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gemm_nt or test_implicit_conv or test_conv_as_im2col"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
