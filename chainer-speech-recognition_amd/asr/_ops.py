@@ -317,6 +317,17 @@ def _hook(name):
         fn()
 
 
+GRU_GI_BF16 = [True]        # write the input projections in bf16 where the recurrence kernel takes them (tests may switch it off)
+
+
+def gru_gi_dtype(T, B, H, ndir):
+    """dtype the input-projection GEMM should write for the recurrence that follows: bf16 when the kernel serving this
+    shape streams it (half the projection's output bytes and of the recurrence's loader traffic), else float32"""
+    if GRU_GI_BF16[0] and _lib.lib().asr_gru_fwd_accepts_bf16_gi(T, B, H, ndir, GRU_MODE[0]):
+        return BF16
+    return F32
+
+
 def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     dev = gi.device
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
@@ -324,7 +335,7 @@ def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
     y = torch.empty((T * B, H), dtype=BF16, device=dev)
-    rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
+    rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), _is_bf16(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
                                 T, B, H, ndir, ptr(sync), GRU_MODE[0])
     check(rc, "asr_gru_fwd")
     LAST_SYNC[0] = sync

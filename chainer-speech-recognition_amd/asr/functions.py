@@ -711,7 +711,7 @@ class _GRU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir):
         wih16, wih16t, whh16, whh16t = copies
-        gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), F32)
+        gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), _ops.gru_gi_dtype(T, B, H, ndir))
         y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, b_hh.detach().reshape(-1), T, B, H, ndir)
         ctx.save_for_backward(x2, hseq, hseq16, gates, wih16t, whh16t)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)

@@ -1287,8 +1287,10 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
 // most 8 rows, 4 compute waves (K = H split in 4) + loader (gi ring) + storer (f32 state and the four saved gate arrays,
 // one step behind).  The exchanged payload is the bf16 h row (hseq16), written sc1 by the gate threads themselves.
 // Raw barriers (s_barrier + lgkmcnt(0)): __syncthreads() would also wait for the loader's LDS-DMA in flight.
-template <int KSW, bool LOCAL>
-__global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
+// GI16: the input projections arrive in bf16 (asr_gemm_nt with a bf16 output: half the bytes written by the projection and
+// read here, ONE LDS-DMA instruction per step instead of two): ring slot = [3 gates][8 rows][16 units] bf16 = 768 B.
+template <int KSW, bool LOCAL, bool GI16>
+__global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
                                                                 int T, int B, int H, int ndir, int rows, int forge) {
@@ -1320,17 +1322,42 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
     // registers: TWO instructions per step -- all 64 lanes fetch gates r | z (lane / 32), lanes 0..31 gate n; lane % 32 =
     // (row, units 4 (lane % 4) ..).  Every LDS-DMA instruction of a step costs the recurrence about 0.05 us (measured with
     // three, one and none): the hand-off loads of the compute waves return behind it.
-    const int lrow = (lane & 31) >> 2;
+    const float* gi = reinterpret_cast<const float*>(gi_);
+    const uint16_t* gi16 = reinterpret_cast<const uint16_t*>(gi_);
+    const int b_ = ((tid - 128) >> 4) & 7, u_ = tid & 15;          // the gate thread's (row, unit)
+    // GI16: lane = (gate lane / 16, row (lane % 16) / 2, units 8 (lane % 2) ..), lanes 0..47
+    const int lrow = GI16 ? (lane & 15) >> 1 : (lane & 31) >> 2;
     const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 3) * 4 +
                        (size_t)(lane >> 5) * H;
+    const uint16_t* lgp16 = gi16 + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 1) * 8 +
+                            (size_t)(lane >> 4) * H;
     const long long lstride = tstep * (long long)B * 3 * (long long)hs;
+    constexpr int kIssueInstr = GI16 ? 1 : 2;          // LDS-DMA instructions per issued step (what vmcnt counts)
     auto issue = [&](int sq) {
-        if (sq < T && lrow < Bl) {
-            char* slot = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)slot, 16, 0, 0);
-            if (lane < 32) __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(slot + 1024), 16, 0, 0);
+        if (GI16) {
+            if (sq < T && lane < 48 && lrow < Bl) {
+                char* slot = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp16, (lds_ptr_t)slot, 16, 0, 0);
+            }
+            lgp16 += lstride;
+        } else {
+            if (sq < T && lrow < Bl) {
+                char* slot = reinterpret_cast<char*>(opring) + (sq % BIO_GD) * (3 * 512);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)slot, 16, 0, 0);
+                if (lane < 32) __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(slot + 1024), 16, 0, 0);
+            }
+            lgp += lstride;
         }
-        lgp += lstride;
+    };
+    // this step's (r, z, n) input projections of gate thread (b, u) out of ring slot `sl`
+    auto read_gi = [&](int sl, float& gr, float& gz, float& gn) {
+        if (GI16) {
+            const uint16_t* o16 = reinterpret_cast<const uint16_t*>(opring) + sl * (3 * 256) + b_ * 16 + u_;
+            gr = bf16_to_f32(o16[0]); gz = bf16_to_f32(o16[128]); gn = bf16_to_f32(o16[256]);
+        } else {
+            const float* osrc = opring + (size_t)sl * 3 * 8 * 16 + b_ * 16 + u_;
+            gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
+        }
     };
     // storer: 5 arrays x 8 rows x 64 B = 160 pieces: piece p = lane + 64 i (i < 3, p < 160): array p / 32, row (p % 32) / 4
     auto store_step = [&](int sp) {
@@ -1440,16 +1467,138 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
     for (int i2 = 0; i2 < NA; ++i2) { ahead[i2].u = make_uint4(0, 0, 0, 0); acur[i2].u = make_uint4(0, 0, 0, 0); }
     bool have_ahead = false;
 
+#ifndef ASR_STAMP
+    // ---------------------------------------------------------------------------------------------------------------
+    // Role-specialised time loops for the default form (XCD-local, payload polled, paired loads).  The generic loop below
+    // serves every hand-off form with one body, so each wave walks a maze of exec-mask and scalar branches per step
+    // (rocprofv3: ~104 SALU + 87 VALU instructions per wave and step, most of them control) and the step had become an
+    // instruction chain.  Here every role runs its own loop: loader / storer / pure compute waves / compute + gate waves,
+    // ONE s_barrier per step (beta_s: "the partial products of step s are in LDS").  The arithmetic, the LDS layouts and the
+    // hand-off are those of the generic loop: results are bit-identical.  The gi ring is re-indexed: after beta_s the
+    // loader refills the slot step s has just read with step s + BIO_GD and waits until step s + 2 has landed, which the
+    // gate waves read after beta_{s+1} -- a barrier now separates every landing check from the read it covers.
+    if (dp) {
+        constexpr int GD = BIO_GD;
+        if (is_loader) {
+            issue(GD - 1);                                          // (the prologue issued steps 0 .. GD - 2)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int s = 0; s < T; ++s) {
+                ASR_RAW_BARRIER();
+                if ((s & 15) == 0 && lds_peek(s_abort)) break;
+                issue(s + GD);                                       // slot s % GD: read at the top of step s, before beta_s
+                // in flight afterwards: the issues of steps s + 3 .. s + GD that exist (two LDS-DMA instructions each)
+                const int left = T - 1 - (s + 2);
+                if (left >= GD - 2) { if (GI16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else if (left == 1) { if (GI16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else if (is_storer) {
+            for (int s = 0; s < T; ++s) {
+                ASR_RAW_BARRIER();
+                if ((s & 15) == 0 && lds_peek(s_abort)) break;
+                if (s > 0) store_step(s - 1);
+            }
+        } else {
+            const bool gate_wave = w >= 2;
+            int slot = 0;
+            for (int s = 0; s < T; ++s) {
+                const int t = d == 0 ? s : T - 1 - s;
+                float gr = 0.f, gz = 0.f, gn = 0.f;
+                if (gate_wave) {                                    // this step's gi: in the ring, checked two barriers ago
+                    read_gi(slot, gr, gz, gn);
+                    slot = slot == GD - 1 ? 0 : slot + 1;
+                }
+                if (s > 0) {
+                    const int tp = d == 0 ? t - 1 : t + 1;
+                    if (gate_wave) {
+#pragma unroll
+                        for (int i2 = 0; i2 < NA; ++i2) acur[i2].u = ahead[i2].u;
+                    } else {
+                        unsigned nap = 0;
+                        while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
+                            __builtin_amdgcn_s_sleep(1);
+                        fetch_row(acur, tp);
+                    }
+                    unsigned spins = 0;
+                    for (;;) {
+                        bool missing = false;
+#pragma unroll
+                        for (int i2 = 0; i2 < KSW / 2; ++i2)
+                            missing |= acur[i2].u.x == 0xffffffffu || acur[i2].u.y == 0xffffffffu || acur[i2].u.z == 0xffffffffu || acur[i2].u.w == 0xffffffffu;
+                        if (__ballot(missing) == 0ull) break;
+                        if ((++spins & 63u) == 0u) {
+                            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
+                            if (spins > kSpinLimit) {
+                                if (lane == 0) { __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT); *s_abort = 1; }
+                                break;
+                            }
+                        }
+                        fetch_row(acur, tp);
+                    }
+                    f32x4 acc[3];
+#pragma unroll
+                    for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                        Frag a1;
+                        a1.u = swap_half_rows(acur[i2].u);
+#pragma unroll
+                        for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[i2].v, bb[2 * i2][gg].v, acc[gg], 0, 0, 0);
+#pragma unroll
+                        for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1][gg].v, acc[gg], 0, 0, 0);
+                    }
+                    if (lane < 32) {
+                        float* pw = reinterpret_cast<float*>(part) + (s & 1) * 3 * 128 * 4 + (((lane >> 4) * 4) * 16 + (lane & 15)) * 4 + w;
+#pragma unroll
+                        for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pw[(gg * 128 + r * 16) * 4] = acc[gg][r];
+                    }
+                }
+                ASR_RAW_BARRIER();
+                if ((s & 15) == 0 && lds_peek(s_abort)) break;
+                if (gate_wave) {
+                    float gh0 = bh[0], gh1 = bh[1], gh2 = bh[2];
+                    if (s > 0 && act) {
+                        const float4* pf = part + (s & 1) * 3 * 128 + b * 16 + u;
+                        const float4 v0 = pf[0], v1 = pf[128], v2 = pf[256];
+                        gh0 += (v0.x + v0.y) + (v0.z + v0.w);
+                        gh1 += (v1.x + v1.y) + (v1.z + v1.w);
+                        gh2 += (v2.x + v2.y) + (v2.z + v2.w);
+                    }
+                    const float r = sigmoidf_(gr + gh0);
+                    const float z = sigmoidf_(gz + gh1);
+                    const float n = tanhf_(gn + r * gh2);
+                    const float h = (1.0f - z) * n + z * hprev;
+                    hprev = h;
+                    const unsigned mine = (unsigned)f32_to_bf16(h);
+                    const unsigned other = lane_xor1_u32(mine);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);              // nothing of this wave is in flight (see the generic loop)
+                    if (act && !(u & 1)) {
+                        unsigned packed = mine | (other << 16);
+                        if (packed == 0xffffffffu) packed = 0x7fc07fc0u;
+                        __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, store_off + (unsigned)t * row_bytes, 0, 0);
+                    }
+                    if (s + 1 < T) {
+                        if (lane == 0) lds_poke(s_abort + w, s + 1);
+                        fetch_row(ahead, t);
+                    }
+                    if (act) {
+                        float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
+                        od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh2;
+                    }
+                }
+            }
+        }
+    } else
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
         const int tp = d == 0 ? t - 1 : t + 1;
         float gh[3] = {bh[0], bh[1], bh[2]};
         // this step's gi (in the ring since at least three steps ago) is read before the wait, off the chain
         float gr = 0.f, gz = 0.f, gn = 0.f;
-        if (tid >= 128 && tid < 256) {
-            const float* osrc = opring + (size_t)(s % BIO_GD) * 3 * 8 * 16 + b * 16 + u;
-            gr = osrc[0]; gz = osrc[128]; gn = osrc[256];
-        }
+        if (tid >= 128 && tid < 256) read_gi(s % BIO_GD, gr, gz, gn);
         if (s > 0) {
             if (dp) {
             } else if (local) { // one line of per-producer flags; every compute wave polls it for ITS producers and goes on
@@ -1570,8 +1719,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const float* 
             // LDS-DMA instructions each, stay in flight.  (vmcnt(0) here waited for the load issued ONE step ago, i.e. for a
             // fresh HBM round trip, and made the loader the last wave at the barrier: 0.25 us per step.)
             issue(s + BIO_GD - 1);
-            if (s + BIO_GD - 1 < T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (s + BIO_GD - 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (s + BIO_GD - 1 < T) { if (GI16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (s + BIO_GD - 2 < T) { if (GI16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
@@ -2393,12 +2542,33 @@ static bool can_persist(int T, int B, int H, int ndir, int mode, const void* syn
     return true;
 }
 
-extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq,
+// which forward kernel family serves a call: 0 one launch per step, 1 wide, 2 16-unit x 8-row (the default at B <= 32),
+// 3 grouped, 4 plain persistent
+static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
+    const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
+    if (!persist) return 0;
+    const int Gio = (B + 7) / 8;
+    const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
+    if ((mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) return 1;
+    if (mode != 3 && H % 16 == 0 && ndir * Gio <= 16) return 2;
+    if (can_group(B, H)) return 3;
+    return 4;
+}
+
+extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode) {
+    if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
+    static int dummy;
+    return fwd_family(T, B, H, ndir, mode, &dummy) == 2 ? 1 : 0;
+}
+
+extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
                            void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
                            int mode) {
-    if (!gi || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
+    if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
+    const float* gi = reinterpret_cast<const float*>(gi_any);
+    if (gi_bf16 && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(H / 16, ndir), block(256);
     const int ksw = (H / 32 + 3) / 4;
@@ -2443,19 +2613,19 @@ extern "C" int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, 
         const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
         if ((forge & 8) && hipMemsetAsync(hseq_bf16, 0xff, (size_t)T * B * ndir * H * 2, st) != hipSuccess) return ASR_ERR_LAUNCH;
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
+#define ASR_FWDIO_(K, L, G)                                                                                               \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge : 0);           \
+    } while (0)
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \
-        if (local) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true>), igrid, iblock, io_lds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
-                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge);               \
-        } else {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((fwd_persistent_io_kernel<K, false>), igrid, iblock, io_lds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
-                               (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, 0);                   \
-        }                                                                                                                 \
+        if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true); else ASR_FWDIO_(K, true, false); }                           \
+        else { if (gi_bf16) ASR_FWDIO_(K, false, true); else ASR_FWDIO_(K, false, false); }                               \
     } while (0)
         if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
+#undef ASR_FWDIO_
 #undef ASR_FWDIO
     } else if (grouped) {
         const int G = (B + RG - 1) / RG;

@@ -255,7 +255,11 @@ int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, con
  * once) can look at it whenever convenient; once set, later launches give up immediately.
  */
 size_t asr_gru_sync_bytes(int B, int H, int ndir);
-int asr_gru_fwd(void* stream, const float* gi, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
+/* gi: (T*B, ndir*3H) input projections, f32 (gi_bf16 = 0) or bf16 (gi_bf16 = 1: half the bytes written by the projection
+ * GEMM and streamed here; accepted by the default persistent kernel only -- ask asr_gru_fwd_accepts_bf16_gi first, the call
+ * returns -3 otherwise) */
+int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode);
+int asr_gru_fwd(void* stream, const void* gi, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
                 float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode);
 int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
                 void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh, int T, int B, int H,

@@ -264,7 +264,7 @@ def test_layer_stack_fuses_maxout_and_pooling(device):
                                           (150, 32, 32, 256, 2), (40, 19, 48, 128, 2), (30, 7, 32, 384, 1)])
 def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
     """forward states and all gradients of the (Bi)GRU against torch.nn.GRU on CPU (weights rounded to bf16)."""
-    from asr import _ops
+    from asr import _ops, _lib
     if mode >= 2 and B > 32:
         pytest.skip("persistent form covers B <= 32")
     if mode == 3 and H % 128:
@@ -273,6 +273,10 @@ def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
     try:
         _gru_case(device, T, B, I, H, ndir)
         _ops.gru_check_sync()
+        if _lib.lib().asr_gru_fwd_accepts_bf16_gi(T, B, H, ndir, mode):      # the same with the input projections in bf16
+            _gru_case(device, T, B, I, H, ndir, gi_dtype=BF16,
+                      tol=dict(y=1e-2, dx=3e-2, dwih=3e-2, dbih=3e-2, dbhh=3e-2, dwhh=3e-2))
+            _ops.gru_check_sync()
     finally:
         _ops.GRU_MODE[0] = 0
 
@@ -286,9 +290,14 @@ def test_gru_full_size_against_fp32_oracle(device):
     errs = _gru_case(device, 1000, 32, 384, 512, 2, tol=dict(y=5e-3, dx=6e-3, dwih=6e-3, dbih=6e-3, dbhh=6e-3, dwhh=6e-3))   # measured: 1.0e-3 .. 2.0e-3
     _ops.gru_check_sync()
     print("full-size GRU vs fp32 oracle, relative L2 errors:", {k: "%.2e" % v for k, v in errs.items()})
+    # what the model runs: the input projections written in bf16 by the projection GEMM
+    assert _ops.gru_gi_dtype(1000, 32, 512, 2) == BF16
+    errs = _gru_case(device, 1000, 32, 384, 512, 2, gi_dtype=BF16, tol=dict(y=8e-3, dx=1e-2, dwih=1e-2, dbih=1e-2, dbhh=1e-2, dwhh=1e-2))
+    _ops.gru_check_sync()
+    print("full-size GRU, bf16 input projections, vs fp32 oracle:", {k: "%.2e" % v for k, v in errs.items()})
 
 
-def _gru_case(device, T, B, I, H, ndir, tol=None):
+def _gru_case(device, T, B, I, H, ndir, tol=None, gi_dtype=F32):
     from asr import _ops
     tol = tol or dict(y=6e-3, dx=2e-2, dwih=2e-2, dbih=2e-2, dbhh=2e-2, dwhh=2e-2)
     errs = {}
@@ -309,7 +318,7 @@ def _gru_case(device, T, B, I, H, ndir, tol=None):
     y_ref.backward(gy)
     xd = x.reshape(T * B, I).to(device, BF16)
     wih = P["w_ih"].reshape(ndir * 3 * H, I).to(device, BF16)
-    gi = _ops.gemm_nt(xd, wih, P["b_ih"].reshape(-1).to(device), F32)
+    gi = _ops.gemm_nt(xd, wih, P["b_ih"].reshape(-1).to(device), gi_dtype)
     whh = P["w_hh"].to(device, BF16).contiguous()
     y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh, P["b_hh"].reshape(-1).to(device), T, B, H, ndir)
     gate("y", y.float().cpu().reshape(T, B, H), y_ref.detach())
@@ -459,7 +468,10 @@ def test_non_finite_step_is_skipped(device):
 
 
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
-                                                          (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True)])
+                                                          (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
+                                                          # > 128 output (or, for backward-data, input) channels: 256 x 256 tiles
+                                                          (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),
+                                                          (12, 2, 6, 256, 64, 3, 5, 1, True)])
 def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
     """asr_conv_nt (no column matrix) against the im2col + GEMM path it replaces, forward and backward-data: the same
     products in the same bf16 operands, so they agree to accumulation order"""

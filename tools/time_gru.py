@@ -38,6 +38,15 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
         else: res['fwd_maxdiff'] = max(float((o.float() - r).abs().max()) for o, r in zip(fo, fref))
         if ref is None: ref = [o.float().clone() for o in out[:2]]
         else: res['maxdiff_vs_step'] = max(float((o.float() - r).abs().max()) for o, r in zip(out[:2], ref))
+        if mode == 8:       # the default form with the input projections in bf16
+            gi16 = gi.to(torch.bfloat16)
+            fn = lambda: _ops.gru_fwd(gi16, whh16, bhh, T, B, H, ndir)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters): fn()
+            e1.record(); torch.cuda.synchronize()
+            res["fwd_bf16gi_us_per_step"] = e0.elapsed_time(e1) / iters / T * 1e3
         print(json.dumps(dict(mode=mode, T=T, B=B, H=H, **res)))
     _ops.GRU_MODE[0] = 0
 
