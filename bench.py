@@ -62,7 +62,7 @@ class Census(object):
 
     def wrap(self, ops):
         self._orig = {}
-        for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd",
+        for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd", "layernorm_ctc_bwd",
                      "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "adam_ctl",
                      "step_control", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
                      "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd"):
@@ -510,12 +510,21 @@ def main():
         out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                                      "unit": "GB/s", "frac": ctc_bytes / (ctc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                      "ms": ctc_ms, "algorithmic_bytes": ctc_bytes,
-                                     "note": "forward = prep + rows (one read of the logits) + lattice (T serial steps per "
-                                             "utterance, latency-bound, no HBM stream); backward = grad (one read of the "
-                                             "logits + one write of the gradient)",
+                                     "note": "the loss as a stand-alone operator (asr_ctc_forward + asr_ctc_backward): forward = prep + "
+                                             "rows (one read of the logits) + lattice (T serial steps per utterance, latency-bound, no "
+                                             "HBM stream); backward = grad (one read of the logits + one write of the gradient)",
                                      "grad_kernel": {"ms": ctc["ctc_grad"], "bytes": ctc_bytes,
                                                      "achieved": ctc_bytes / (ctc["ctc_grad"] * 1e-3) / 1e9,
                                                      "frac": ctc_bytes / (ctc["ctc_grad"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        if "layernorm_ctc_bwd" in tot:
+            # in the model the gradient of the logits is never written: LayerNormalization's backward forms it in registers
+            # (csrc/ctc_ln.hip).  Algorithmic bytes of that sweep: x in (f32) + alpha/beta of the path + dx out (bf16)
+            fb = T * B * (V * 4 + V * 2 + 2.0 * 241 * 8)
+            fms = tot["layernorm_ctc_bwd"][0]
+            out["roofline_ctc_sweep"]["in_model_backward"] = {
+                "kernel": "asr::ctcln::bwd_kernel (CTC gradient + LayerNormalization backward, one sweep)", "ms": fms,
+                "algorithmic_bytes": fb, "achieved": fb / (fms * 1e-3) / 1e9, "frac": fb / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "replaces": "ctc::grad (%.3f ms alone) + ln::bwd_rows_f32: 1.73 GB of traffic -> 0.70 GB" % ctc["ctc_grad"]}
         frames = T * B
         macs_fwd = frames * 15.25e6
         # conv_nt / conv_tn_acc: the implicit-GEMM convolutions (forward, backward-data; weight gradient)

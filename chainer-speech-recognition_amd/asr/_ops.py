@@ -268,6 +268,28 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
     return dx
 
 
+CALLS = {}          # call counters of a few entry points (tests check which path ran)
+
+
+def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta, need_dx, recipes):
+    """asr_layernorm_ctc_bwd: `recipes` = one or two dicts left by CTC-family losses on the normalised rows (asr/loss/ctc.py):
+    ws, Lmax, gram, x_len, gy, gy_per_utt, scale"""
+    rows, V = x.shape
+    assert x.dtype == F32 and x.is_contiguous() and rows == T * B and 1 <= len(recipes) <= 2
+    CALLS["layernorm_ctc_bwd"] = CALLS.get("layernorm_ctc_bwd", 0) + 1
+    lib = _lib.lib()
+    dx = torch.empty((rows, V), dtype=dx_dtype, device=x.device) if need_dx else None
+    nbytes = lib.asr_layernorm_ctc_bwd_ws_bytes(T, B, V)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if dgamma is not None else None
+    args = []
+    for r in (recipes + recipes)[:2]:
+        args += [ptr(r["ws"]), int(r["Lmax"]), int(r["gram"]), ptr(r["x_len"]), ptr(r["gy"]), int(r["gy_per_utt"]), float(r["scale"])]
+    rc = lib.asr_layernorm_ctc_bwd(stream(), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), _is_bf16(dx) if need_dx else 0,
+                                   ptr(dgamma), ptr(dbeta), T, B, V, ptr(ws), nbytes, len(recipes), *args)
+    check(rc, "asr_layernorm_ctc_bwd")
+    return dx
+
+
 GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 local with flags, 5 narrow backward, 7 forged placement, 8 local with polled payload (= 0)
 
 

@@ -111,21 +111,58 @@ def _is_zero_token(t):
     return z is not None and t.data_ptr() == z.data_ptr()
 
 
-def _producer_mailbox(x2):
-    """the mailbox of the node that produced the buffer `x2` is a contiguous re-view of, or None"""
+def _producer_box(x2, attr="_asr_mailbox", hops=12):
+    """the box (attribute `attr`) of the node that produced the buffer `x2` is a contiguous re-view of, or None"""
     if x2.dtype != F32 or not x2.is_contiguous():
         return None
     node = x2.grad_fn
-    for _ in range(8):
+    for _ in range(hops):
         if node is None:
             return None
-        box = getattr(node, "_asr_mailbox", None)
+        box = getattr(node, attr, None)
         if box is not None:
             return box if (box.ptr == x2.data_ptr() and box.numel == x2.numel()) else None
         if not type(node).__name__.startswith(_VIEW_NODES) or len(node.next_functions) != 1:
             return None
         node = node.next_functions[0][0]
     return None
+
+
+def _producer_mailbox(x2):
+    return _producer_box(x2, "_asr_mailbox", 8)
+
+
+# A CTC-family loss whose logits come straight out of a per-frame LayerNormalization does not write its gradient (384 MB of
+# float32 at the BASELINE size, read back at once by the normalisation's backward): it leaves a RECIPE -- the workspace with
+# alpha / beta / log-sum-exp of its forward pass, lengths, upstream gradient, scale -- in the box the normalisation hung on
+# its graph node, and hands autograd a zero token (the first loss) or nothing (a second loss on the same logits: the joint
+# Gram-CTC + CTC step of run/gram_ctc/cnn/train.py:163-167).  LayerNormalization's backward then forms (softmax - occupancy)
+# in registers inside its own sweep (csrc/ctc_ln.hip).  Whatever else flows into the logits arrives through autograd as usual
+# and is added by a second, plain backward sweep.
+FUSE_CTC_INTO_LAYERNORM = [True]
+
+
+class _CtcBox(object):
+    __slots__ = ("ptr", "numel", "shape", "recipes")
+
+    def __init__(self, y, T, B, V):
+        self.ptr, self.numel, self.shape, self.recipes = y.data_ptr(), y.numel(), (T, B, V), []
+
+    def post(self, recipe):
+        self.recipes.append(recipe)
+        return len(self.recipes) == 1
+
+    def take(self):
+        r, self.recipes = self.recipes, []
+        return r
+
+
+def ctc_box_of(xs):
+    """the recipe box of the LayerNormalization that produced the (T, B, V) logits `xs`, or None"""
+    if not FUSE_CTC_INTO_LAYERNORM[0] or xs.dim() != 3:
+        return None
+    box = _producer_box(xs, "_asr_ctc_box")
+    return box if (box is not None and box.shape == tuple(xs.shape)) else None
 
 
 def _incoming_bf16(ctx, gy, width):
@@ -600,11 +637,15 @@ def add(a, b):
 # ---------------------------------------------------------------------------------------------- layer normalisation
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x2, gamma, beta, C, out_f32, mailbox):
+    def forward(ctx, x2, gamma, beta, C, out_f32, mailbox, tb):
         y, mean, rstd = _ops.layernorm_fwd(x2, gamma.detach(), beta.detach(), C, F32 if out_f32 else BF16)
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params = (gamma, beta)
         ctx.meta = (C, ctx.needs_input_grad[0], mailbox)
+        # float32 rows normalised over their whole width = logits normalised over the vocabulary of each (t, b) frame: a
+        # CTC-family loss on them may leave a recipe instead of a gradient (see _CtcBox)
+        if out_f32 and tb is not None and x2.dtype == F32 and C == x2.shape[1] and C % 4 == 0 and C <= 4096:
+            ctx._asr_ctc_box = _CtcBox(y, tb[0], tb[1], C)
         return y
 
     @staticmethod
@@ -613,13 +654,26 @@ class _LayerNorm(torch.autograd.Function):
         gamma, beta = ctx.params
         C, need_dx, mailbox = ctx.meta
         handover = mailbox is not None and need_dx      # the producer of x2 takes its gradient in bf16
-        dx = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, BF16 if handover else x2.dtype,
-                                grad_buffer(gamma), grad_buffer(beta), need_dx)
+        dx_dtype = BF16 if handover else x2.dtype
+        box = getattr(ctx, "_asr_ctc_box", None)
+        recipes = box.take() if box is not None else []
+        dx = None
+        if recipes:
+            T, B, _ = box.shape
+            dx = _ops.layernorm_ctc_bwd(x2, gamma.detach(), beta.detach(), mean, rstd, T, B, dx_dtype, grad_buffer(gamma),
+                                        grad_buffer(beta), need_dx, recipes)
+        if not recipes or not _is_zero_token(gy):       # a gradient that did arrive through autograd
+            dx2 = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, dx_dtype, grad_buffer(gamma),
+                                     grad_buffer(beta), need_dx)
+            if dx is None:
+                dx = dx2
+            elif need_dx:
+                dx = _ops.add_bf16(dx, dx2) if dx_dtype == BF16 else dx.add_(dx2)
         grads_queued(gamma, beta)
         if handover:
             mailbox.post(dx)
             dx = _zero_token(x2.shape, x2.device)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def layer_normalization(x, gamma, beta, out_f32=False):
@@ -630,7 +684,7 @@ def layer_normalization(x, gamma, beta, out_f32=False):
             p = phys4(x)
         T, B, H, C = p.shape
         x2 = p.reshape(T * B, H * C)
-        y = _LayerNorm.apply(x2, gamma, beta, C, bool(out_f32), _producer_mailbox(x2))
+        y = _LayerNorm.apply(x2, gamma, beta, C, bool(out_f32), _producer_mailbox(x2), (T, B) if H == 1 else None)
         return logical4(y.reshape(T, B, H, C))
     if x.dim() == 3:
         # (B, V, T): the reference normalises over V AND T jointly (axes 1, 2).  Physical rows are (t, b); joint
@@ -639,7 +693,7 @@ def layer_normalization(x, gamma, beta, out_f32=False):
         rows = x.permute(0, 2, 1)                # (B, T, V)
         if not (rows.is_contiguous() and rows.dtype in (BF16, F32)):
             rows = _ToPhys.apply(x, (0, 2, 1))
-        y = _LayerNorm.apply(rows.reshape(Bn, T * V), gamma, beta, V, bool(out_f32), None)
+        y = _LayerNorm.apply(rows.reshape(Bn, T * V), gamma, beta, V, bool(out_f32), None, None)
         return y.reshape(Bn, T, V).permute(0, 2, 1)
     raise ValueError("layer normalisation expects a 3-d or 4-d input")
 

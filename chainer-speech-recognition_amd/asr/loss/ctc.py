@@ -36,7 +36,7 @@ def _as_tbv(xs):
 
 class _CTCFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xs, label_unigram, label_bigram, input_length, label_length, blank, reduce):
+    def forward(ctx, xs, label_unigram, label_bigram, input_length, label_length, blank, reduce, box):
         lib = _lib.lib()
         if xs.dtype != torch.float32:
             raise TypeError("xs must be float32")                 # asr/loss/gram_ctc.py:241-244
@@ -62,6 +62,7 @@ class _CTCFunction(torch.autograd.Function):
         _lib.check(rc, "asr_ctc_forward")
         ctx.save_for_backward(xs, input_length, ws)
         ctx.dims = (T, B, V, Lmax, int(gram), reduce)
+        ctx.box = box if Lmax * (3 if gram else 2) + 1 <= 512 else None
         return loss_m if reduce == "mean" else loss_b
 
     @staticmethod
@@ -70,13 +71,20 @@ class _CTCFunction(torch.autograd.Function):
         xs, input_length, ws = ctx.saved_tensors
         T, B, V, Lmax, gram, reduce = ctx.dims
         gy = gy.contiguous().to(torch.float32)
-        grad = torch.empty_like(xs)
         scale = 1.0 / B if reduce == "mean" else 1.0
+        if ctx.box is not None:
+            # the logits come straight out of a per-frame LayerNormalization: leave the recipe there; its backward forms
+            # (softmax - occupancy) * scale * gy in registers instead of reading a (T, B, V) float32 gradient (functions._CtcBox)
+            from ..functions import _zero_token
+            first = ctx.box.post(dict(ws=ws, Lmax=Lmax, gram=gram, x_len=input_length, gy=gy, gy_per_utt=0 if reduce == "mean" else 1,
+                                      scale=scale))
+            return (_zero_token(xs.shape, xs.device) if first else None), None, None, None, None, None, None, None
+        grad = torch.empty_like(xs)
         rc = lib.asr_ctc_backward(_lib.stream(), _lib.ptr(xs), _lib.ptr(input_length), T, B, V, Lmax, gram,
                                   _lib.ptr(gy), 0 if reduce == "mean" else 1, scale, _lib.ptr(grad), _lib.ptr(ws),
                                   ws.numel())
         _lib.check(rc, "asr_ctc_backward")
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
 def _check_common(xs, blank_symbol, reduce):
@@ -93,11 +101,13 @@ def _check_common(xs, blank_symbol, reduce):
 def connectionist_temporal_classification(x, t, blank_symbol, input_length=None, label_length=None, reduce="mean"):
     """CTC loss with Chainer's conventions: mean over the batch of -log p (not divided by T)."""
     xs = _check_common(x, blank_symbol, reduce)
-    return _CTCFunction.apply(xs, t, None, input_length, label_length, blank_symbol, reduce)
+    from ..functions import ctc_box_of
+    return _CTCFunction.apply(xs, t, None, input_length, label_length, blank_symbol, reduce, ctc_box_of(xs))
 
 
 def gram_ctc(xs, label_unigram, label_bigram, blank_symbol, input_length=None, length_unigram=None, reduce="mean"):
     """Gram-CTC loss over the unigram + bigram lattice (asr/loss/gram_ctc.py:300-315)."""
     x = _check_common(xs, blank_symbol, reduce)
     assert label_unigram.shape[1] == label_bigram.shape[1]
-    return _CTCFunction.apply(x, label_unigram, label_bigram, input_length, length_unigram, blank_symbol, reduce)
+    from ..functions import ctc_box_of
+    return _CTCFunction.apply(x, label_unigram, label_bigram, input_length, length_unigram, blank_symbol, reduce, ctc_box_of(x))

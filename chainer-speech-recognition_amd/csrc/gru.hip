@@ -1332,7 +1332,6 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
     const uint16_t* lgp16 = gi16 + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 1) * 8 +
                             (size_t)(lane >> 4) * H;
     const long long lstride = tstep * (long long)B * 3 * (long long)hs;
-    constexpr int kIssueInstr = GI16 ? 1 : 2;          // LDS-DMA instructions per issued step (what vmcnt counts)
     auto issue = [&](int sq) {
         if (GI16) {
             if (sq < T && lane < 48 && lrow < Bl) {

@@ -468,6 +468,17 @@ extern "C" int asr_layernorm_bwd_rows(void* stream, const float* x, const float*
     return ASR_OK;
 }
 
+// dgamma / dbeta += the per-workgroup column sums of a one-sweep backward (also used by csrc/ctc_ln.hip)
+extern "C" int asr_layernorm_fold_partials(void* stream, const float* partial, int G, int D, int C, float* dgamma, float* dbeta) {
+    if (!partial || !dgamma || !dbeta || G <= 0 || D <= 0 || C <= 0 || D % C) return ASR_ERR_BAD_ARG;
+    int chunks = (G + 15) / 16;
+    if (chunks > 16) chunks = 16;
+    hipLaunchKernelGGL(asr::ln::fold_partials_kernel, dim3(cdiv(2 * D, 64), chunks), dim3(256), 0, (hipStream_t)stream, partial, G, D, C,
+                       dgamma, dbeta);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ weight normalisation
 // asr/nn/convolution_2d.py:21-25,62-64: W = g * V / (||V|| + 1e-9), norm over everything but the output channel.
 // One workgroup per output channel (rows of K = Ci*kh*kw floats).

@@ -122,3 +122,99 @@ def test_full_size_properties(device):
     lo, go = octc.ctc_loss_grad(xs[:, b:b + 1].numpy(), lab[b:b + 1].numpy(), 0, xl[b:b + 1].numpy(), tl[b:b + 1].numpy(), "no")
     np.testing.assert_allclose(loss[b].item(), lo[0], rtol=LOSS_RTOL)
     np.testing.assert_allclose(gr[:, b].cpu().numpy(), go[:, 0], rtol=GRAD_RTOL, atol=GRAD_ATOL)
+
+
+# ---------------------------------------------------------------------------------------------- fused LayerNorm + CTC backward
+def _ln_ctc_case(device, T, B, V, L, losses, seed, ragged=True):
+    """x (T*B, V) -> per-frame LayerNormalization -> one or two CTC-family losses.  Returns what the graph gives for dx,
+    dgamma, dbeta with the fused backward (recipes left at the normalisation) and with it switched off (the loss writes its
+    (T, B, V) gradient, the normalisation reads it)."""
+    from asr import functions as F
+    from asr.link import Parameter
+    from asr.loss import connectionist_temporal_classification, gram_ctc
+    rs = np.random.RandomState(seed)
+    x0 = torch.tensor((rs.randn(T * B, V) * 2.0 + 0.3).astype(np.float32)).to(device)
+    g0 = torch.tensor(rs.uniform(0.5, 1.5, V).astype(np.float32))
+    b0 = torch.tensor((rs.randn(V) * 0.2).astype(np.float32))
+    n_uni = min(V, 40)
+    uni = torch.tensor(rs.randint(1, n_uni, size=(B, L)).astype(np.int32)).to(device)
+    big = rs.randint(n_uni, V, size=(B, L)).astype(np.int32) if V > n_uni else np.full((B, L), -1, np.int32)
+    big[rs.rand(B, L) < 0.3] = -1
+    big[:, 0] = -1
+    big = torch.tensor(big).to(device)
+    tl = torch.tensor((rs.randint(max(1, L // 2), L + 1, size=B) if ragged else np.full(B, L)).astype(np.int32)).to(device)
+    xl = torch.tensor((rs.randint(max(3 * L + 2, T // 2), T + 1, size=B) if ragged else np.full(B, T)).astype(np.int32)).to(device)
+    gy_no = torch.tensor(rs.rand(B).astype(np.float32)).to(device)
+
+    def run(fused):
+        F.FUSE_CTC_INTO_LAYERNORM[0] = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            gamma, beta = Parameter(g0.clone().to(device)), Parameter(b0.clone().to(device))
+            # logical (B, V, 1, T) view of physical (T, B, 1, V) float32 rows, as the models hand it to LayerNormalization
+            xin = x.reshape(T, B, 1, V).permute(1, 3, 2, 0)
+            y = F.layer_normalization(xin, gamma, beta, out_f32=True)
+            tbv = y.permute(3, 0, 2, 1).squeeze(2)
+            total = None
+            for kind, reduce in losses:
+                if kind == "ctc":
+                    l = connectionist_temporal_classification(tbv, uni, 0, xl, tl, reduce)
+                else:
+                    l = gram_ctc(tbv, uni, big, 0, xl, tl, reduce)
+                l = l if reduce == "mean" else (l * gy_no).sum()
+                total = l if total is None else total + l
+            total.backward()
+            torch.cuda.synchronize()
+            return total.item(), x.grad.clone(), gamma.grad.clone(), beta.grad.clone()
+        finally:
+            F.FUSE_CTC_INTO_LAYERNORM[0] = True
+
+    return run(True), run(False)
+
+
+@pytest.mark.parametrize("T,B,V,L,losses", [(40, 3, 28, 5, [("ctc", "mean")]), (60, 4, 120, 7, [("gram", "mean")]),
+                                            (50, 2, 64, 6, [("ctc", "no")]), (70, 3, 200, 8, [("gram", "mean"), ("ctc", "mean")]),
+                                            (300, 8, 3000, 40, [("ctc", "mean")]), (200, 4, 3000, 30, [("gram", "no"), ("ctc", "mean")])])
+def test_layernorm_ctc_backward_fused_equals_unfused(device, T, B, V, L, losses):
+    """csrc/ctc_ln.hip: the gradient with respect to the normalised logits formed inside the normalisation's backward sweep
+    gives the dx / dgamma / dbeta of the two-kernel route (ctc::grad writes it, ln::bwd_rows_f32 reads it): same formulas,
+    float32 throughout; the joint Gram-CTC + CTC case posts two recipes"""
+    from asr import _ops
+    before = _ops.CALLS.get("layernorm_ctc_bwd", 0)
+    (lf, dxf, dgf, dbf), (lu, dxu, dgu, dbu) = _ln_ctc_case(device, T, B, V, L, losses, seed=T + V)
+    assert _ops.CALLS.get("layernorm_ctc_bwd", 0) == before + 1          # the fused sweep ran exactly once (in the fused run)
+    assert lf == lu
+    scale = float(dxu.abs().max()) + 1e-30
+    assert float((dxf - dxu).abs().max()) <= 2e-5 * scale + 1e-9, float((dxf - dxu).abs().max()) / scale
+    for a, r in ((dgf, dgu), (dbf, dbu)):
+        assert float((a - r).abs().max()) <= 1e-4 * (float(r.abs().max()) + 1e-30) + 1e-7
+
+
+def test_layernorm_ctc_fusion_with_another_consumer_of_the_logits(device):
+    """a second consumer of the normalised logits (here a plain torch expression) sends its gradient through autograd; the
+    normalisation then adds the recipe's sweep and the ordinary backward sweep"""
+    from asr import functions as F
+    from asr.link import Parameter
+    from asr.loss import connectionist_temporal_classification
+    rs = np.random.RandomState(3)
+    T, B, V, L = 30, 2, 36, 4
+    x0 = torch.tensor(rs.randn(T * B, V).astype(np.float32)).to(device)
+    uni = torch.tensor(rs.randint(1, V, size=(B, L)).astype(np.int32)).to(device)
+    w = torch.tensor(rs.randn(T, B, V).astype(np.float32)).to(device)
+
+    def run(fused):
+        F.FUSE_CTC_INTO_LAYERNORM[0] = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            gamma, beta = Parameter(torch.ones(V).to(device)), Parameter(torch.zeros(V).to(device))
+            y = F.layer_normalization(x.reshape(T, B, 1, V).permute(1, 3, 2, 0), gamma, beta, out_f32=True)
+            tbv = y.permute(3, 0, 2, 1).squeeze(2)
+            total = connectionist_temporal_classification(tbv, uni, 0) + (tbv * w).sum() * 0.01
+            total.backward()
+            torch.cuda.synchronize()
+            return x.grad.clone(), gamma.grad.clone()
+        finally:
+            F.FUSE_CTC_INTO_LAYERNORM[0] = True
+    (dxf, dgf), (dxu, dgu) = run(True), run(False)
+    assert float((dxf - dxu).abs().max()) <= 1e-4 * float(dxu.abs().max())
+    assert float((dgf - dgu).abs().max()) <= 1e-4 * float(dgu.abs().max()) + 1e-6

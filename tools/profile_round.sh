@@ -16,6 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o k -- python3 $R/
 echo "write pass done"
 cd $R
 python3 tools/prof_summary.py stats $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python3 tools/timeline.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/${TAG}_timeline.txt || true
 python3 tools/prof_summary.py pmc $(find $OUT/fetch -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_fetch_size.csv
 python3 tools/prof_summary.py pmc $(find $OUT/write -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_write_size.csv
 python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv $OUT/${TAG}_pmc_traffic.json
