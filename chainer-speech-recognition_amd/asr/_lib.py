@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libasr_hip.so")
+# ASR_HIP_LIB: another build of the same library (what-if builds of the timing tools); the default is the in-tree one
+LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libasr_hip.so")
 
 _lib = None
 

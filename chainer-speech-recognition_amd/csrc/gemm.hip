@@ -466,12 +466,12 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
 template <int N_>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
-template <typename OutT, bool CONV, int BKT, int STAGES>
-__global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
+template <typename OutT, bool CONV, int BKT, int STAGES, int WN_>
+__global__ __launch_bounds__(128 * WN_) void gemm_nt_wide_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
                                                            int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                            int M, int N, int K, int tiles_n, ConvDesc cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = 256, TNC = 256, THREADS = 512, MI = 8;
+    constexpr int TM = 256, TNC = 256, THREADS = 128 * WN_, MI = 8, NJ = 16 / WN_;        // waves 2 (M) x WN_ (N), wave tile 128 x (256 / WN_)
     constexpr int CH = BKT / 8;                         // 16-B chunks per LDS row
     constexpr int ROWB = BKT * 2;                       // bytes per LDS row
     constexpr int A_SLOTS = TM * CH / THREADS, B_SLOTS = TNC * CH / THREADS, P = A_SLOTS + B_SLOTS;
@@ -480,16 +480,16 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __res
     tile_of(blockIdx.x, (M + TM - 1) / TM, tiles_n, tm, tn);
     const int m0 = tm * TM, n0 = tn * TNC;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3;
+    const int wm = wid / WN_, wn = wid % WN_;
     char* As = smem;
     char* Bs = smem + STAGES * A_STAGE;
     auto swz = [](int row) { return BKT == 32 ? ((0x78 >> (((row >> 2) & 3) * 2)) & 3) : (row & 7); };
 
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const uint16_t* ga[A_SLOTS];
     const uint16_t* gb[B_SLOTS];
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __res
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb[i] + kt * BKT), (lds_ptr_t)(Bs + buf * B_STAGE + (i * THREADS + wid * 64) * 16), 16, 0, 0);
     };
     // fragment byte offsets inside a stage, per 32-wide K slice
-    int aoff[MI], boff[4];
+    int aoff[MI], boff[NJ];
     {
         const int q = lane >> 4, r = lane & 15;
 #pragma unroll
@@ -552,17 +552,18 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __res
             aoff[i] = row * ROWB + ((q ^ swz(row)) << 4);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wn * 64 + j * 16 + r;
+        for (int j = 0; j < NJ; ++j) {
+            const int row = wn * (16 * NJ) + j * 16 + r;
             boff[j] = row * ROWB + ((q ^ swz(row)) << 4);
         }
     }
     auto wait_tiles_in_flight = [](int tiles) {
-        if (tiles >= 2) wait_vmcnt<2 * P>();
+        if (tiles >= 3) wait_vmcnt<3 * P>();
+        else if (tiles == 2) wait_vmcnt<2 * P>();
         else if (tiles == 1) wait_vmcnt<P>();
         else wait_vmcnt<0>();
     };
-    static_assert(STAGES >= 2 && STAGES <= 3, "ring depth");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
     constexpr int S = STAGES;
     const int nk = K / BKT;
     for (int t = 0; t < S - 1 && t < nk; ++t) issue_tile(t, t);
@@ -578,15 +579,15 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __res
             // second 32-wide slice of a 128-B row: chunk index + 4, i.e. the position XORed with 4 (the swizzle only
             // touches the low bits it was given)
             const int kx = ks << 6;
-            Frag b[4];
+            Frag b[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j].u = *reinterpret_cast<const uint4*>(Bb + (boff[j] ^ kx));
+            for (int j = 0; j < NJ; ++j) b[j].u = *reinterpret_cast<const uint4*>(Bb + (boff[j] ^ kx));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 Frag a;
                 a.u = *reinterpret_cast<const uint4*>(Ab + (aoff[i] ^ kx));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
             }
         }
         wait_tiles_in_flight(min(S - 2, nk - 2 - kt));
@@ -603,11 +604,11 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const uint16_t* __res
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = ii * 16 + (lane >> 4) * 4 + r;
-                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        const int col = wn * (16 * NJ) + j * 16 + (lane & 15);
                         Cs[row * CP + col] = acc[(chunk & 3) * 2 + ii][j][r];
                     }
         }
@@ -824,7 +825,7 @@ static int nt_wide_mode() {
     if (mode == -2) {
         const char* e = getenv("ASR_NT_WIDE");
         mode = e ? atoi(e) : -1;
-        if (mode < -1 || mode > 2) mode = -1;
+        if (mode < -1 || mode > 4) mode = -1;
     }
     return mode;
 }
@@ -841,17 +842,18 @@ static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const 
                           int M, int N, int K, bool b_fits_l2, const ConvDesc& cd, int mode) {
     const int tm = cdiv(M, 256), tn = cdiv(N, 256);
     const int tn_arg = b_fits_l2 ? -tn : tn;
-    if (mode == 2) {
-        constexpr int LDS = 2 * 512 * 128;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, 64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, 64, 2>), dim3(tm * tn), dim3(512), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd);
-    } else {
-        constexpr int LDS = 3 * 512 * 64;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, 32, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, 32, 3>), dim3(tm * tn), dim3(512), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd);
-    }
+#define ASR_WIDE(BK, ST, WN, THREADS)                                                                                      \
+    do {                                                                                                                  \
+        constexpr int LDS = ST * 512 * BK * 2;                                                                            \
+        static bool attr = false;                                                                                         \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, BK, ST, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
+        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, BK, ST, WN>), dim3(tm * tn), dim3(THREADS), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd); \
+    } while (0)
+    if (mode == 2) ASR_WIDE(64, 2, 4, 512);
+    else if (mode == 3) ASR_WIDE(32, 4, 2, 256);      // four waves of 128 x 128 (256 accumulator registers), four-deep ring
+    else if (mode == 4) ASR_WIDE(64, 2, 2, 256);
+    else ASR_WIDE(32, 3, 4, 512);
+#undef ASR_WIDE
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -874,7 +876,7 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     const bool aligned = (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
     {
         const int wide = nt_wide_mode() > 0 ? nt_wide_mode() : 0;      // plain GEMMs: only on request
-        if (wide && aligned && (K % (wide == 2 ? 64 : 32)) == 0 && N >= 256 && ((long long)cdiv(M, 256) * cdiv(N, 256) >= 512 || nt_wide_force())) {
+        if (wide && aligned && (K % ((wide == 2 || wide == 4) ? 64 : 32)) == 0 && N >= 256 && ((long long)cdiv(M, 256) * cdiv(N, 256) >= 512 || nt_wide_force())) {
             if (out_bf16) return launch_nt_wide<uint16_t, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
             return launch_nt_wide<float, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
         }
@@ -973,7 +975,7 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, sgn, Hr};
     {
         const int wide = nt_wide_mode() == -1 ? 2 : nt_wide_mode();
-        const int bkt = wide == 2 ? 64 : 32;
+        const int bkt = (wide == 2 || wide == 4) ? 64 : 32;
         if (wide && N > 128 && (Cs % bkt) == 0 && (K % bkt) == 0 && (cdiv((int)M, 256) * cdiv(N, 256) >= 256 || nt_wide_force())) {
             const bool fits = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;
             if (out_bf16) return launch_nt_wide<uint16_t, true>(stream, (const uint16_t*)x, 0, (const uint16_t*)W, K, (uint16_t*)out, N, bias, (int)M, N, K, fits, cd, wide);
