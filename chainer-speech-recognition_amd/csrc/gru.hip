@@ -1283,6 +1283,293 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, partial sums
+// bwd_wide_kernel hands the 3H gate gradients of a step to every workgroup of the recurrence (12 KB per workgroup and step at
+// H = 512, 4 rows), each of which then forms ITS 32 columns of  dh = dgh . W_hh  -- and the time of a step grows by ~0.04 us
+// per KB a workgroup has to fetch through the L2 (what-if build fetching 8 KB: 1.80 -> 1.64 us per step).  Here the product
+// moves to the producer: a workgroup multiplies the 96 gate gradients it has just computed (its 32 units, gates r, z, q) by
+// its 96 ROWS of W_hh and publishes the H partial sums  P[p][h'][row] = sum_{g in p's 96} dgh[row][g] W_hh[g][h']  in bf16
+// (4 rows x H x 2 B = 4 KB written); a consumer fetches the 32 columns it owns from all H / 32 producers (256 B each: 4 KB
+// at H = 512) and adds them up (float32).  Same number of MFMAs, a third of the hand-off bytes, one more workgroup barrier:
+//   gate waves (2, 3):  poll-load P_{s-1} (sentinel 0xffff, as in bwd_wide_kernel) -> float32 in LDS -> barrier R ->
+//                       16-way sum -> gate math -> (ar, az, aq) as the MFMA A image in LDS + (ar, az, an, aq) for the storer
+//   all 8 compute waves: barrier A -> 3 K steps (gates) x H/128 column tiles of MFMA -> bf16 -> P_s (plain stores when the
+//                       recurrence sits on one XCD, write-through otherwise; polled with sc1 loads either way)
+//   loader / storer waves as in bwd_wide_kernel; the storer now also writes dgh (no longer the exchange medium, so it needs no
+//   sentinel fill: 196 MB of memset per launch less).
+// The exchange buffer is a ring of four steps (a producer re-arms the slot of step s - 2 with the sentinel once its loads of
+// step s - 1 have succeeded: every consumer has then finished with step s - 2), 4 x H/32 x H x 8 B per recurrence inside sync_ws.
+constexpr int PS_RING = 4;
+__host__ __device__ inline size_t ps_exchange_bytes(int nrec_pad, int H) { return (size_t)PS_RING * nrec_pad * (H / 32) * H * 8; }
+constexpr size_t kPsOffset = 4096 + kShardBytes;      // behind the control words and the sharded counters
+
+template <int NT, bool LOCAL>
+__global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
+                                                        const float* __restrict__ hseq, const uint16_t* __restrict__ whhT,
+                                                        uint16_t* __restrict__ dgi, uint16_t* __restrict__ dgh, float* __restrict__ db_ih,
+                                                        float* __restrict__ db_hh, unsigned* sync, int T, int B, int H, int ndir,
+                                                        int forge) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);                                      // [8 producer groups][4 rows][2][16] f32 = 4 KB
+    uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 4096);                         // [3 gates][4 rows][32 units] bf16 = 768 B
+    char* opring = smem + 4096 + 1024;                                                  // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
+    unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);         // [2][4: ar az an aq][4 rows][16 pairs]
+    int* s_abort = reinterpret_cast<int*>(oring + 2 * 4 * 4 * 16);
+    constexpr int rows = 4;
+    const int nwg = H / 32;
+    const int Gn = (B + rows - 1) / rows, nrec = Gn * ndir, nrec_pad = (nrec + 7) & ~7;
+    const int rec = LOCAL ? (int)(blockIdx.x % nrec_pad) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    const int slot = LOCAL ? (int)(blockIdx.x / nrec_pad) : (int)blockIdx.x;
+    if (LOCAL && rec >= nrec) return;
+    const int d = rec / Gn, g = rec % Gn;
+    const int j0 = slot * 32;
+    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const bool is_compute = w < 8, is_loader = w == 8, is_storer = w == 9;
+    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
+    unsigned* abort_word = sync + 1023;
+    // exchange ring of this recurrence: [PS_RING][nwg producers][H columns][4 rows] bf16
+    char* xbase = reinterpret_cast<char*>(sync) + kPsOffset + (size_t)rec * PS_RING * nwg * H * 8;
+    const unsigned xslot_bytes = (unsigned)(nwg * H * 8);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, (int)(PS_RING * xslot_bytes), 0x00020000);
+    const long long tstep = d == 0 ? -1 : 1;
+    const int tfirst = d == 0 ? T - 1 : 0;
+
+    // ---- loader (wave 8): as bwd_wide_kernel
+    const int lrow = (lane & 31) >> 3, lyrow = (lane - 32) >> 2;
+    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4 +
+                       (size_t)(lane >> 5) * H;
+    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
+                       (size_t)d * H + j0 + (lane & 7) * 4;
+    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lane >= 32 && lane < 48 && lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
+    const char* l2p = lane < 32 ? reinterpret_cast<const char*>(lhp) : reinterpret_cast<const char*>(lyp);
+    const long long lgs = tstep * (long long)B * ndir * 4 * H;
+    const long long l2s = lane < 32 ? tstep * (long long)B * (long long)hs * 4 : tstep * (long long)B * H * 2;      // bytes
+    auto issue = [&](int sq) {              // called with sq = 0, 1, 2, ... in order
+        if (sq < T) {
+            char* sl = opring + (sq % BIO_GD) * BIO_SLOT;
+            if (lrow < Bl) {
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)sl, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(sl + 1024), 16, 0, 0);
+            }
+            if (lane < 32 ? (lrow < Bl && sq < T - 1) : (lane < 48 && lyrow < Bl))
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)l2p, (lds_ptr_t)(sl + 2048), 16, 0, 0);
+        }
+        lgp += lgs; l2p += l2s;
+    };
+    // ---- storer (wave 9): dgi = (ar, az, an) and dgh = (ar, az, aq): 3 gates x 4 rows x 64 B = 48 pieces of 16 B each
+    auto store_step = [&](int sp) {
+        const long long tq = tfirst + tstep * sp;
+        const unsigned* src = oring + (size_t)(sp & 1) * 4 * 4 * 16;
+        const int gsel = lane >> 4, row = (lane & 15) >> 2, c = lane & 3;
+        if (lane < 48 && row < Bl) {
+            const size_t off = ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c * 8;
+            *reinterpret_cast<uint4*>(dgi + off) = *reinterpret_cast<const uint4*>(src + (gsel * 4 + row) * 16 + c * 4);
+            *reinterpret_cast<uint4*>(dgh + off) = *reinterpret_cast<const uint4*>(src + ((gsel == 2 ? 3 : gsel) * 4 + row) * 16 + c * 4);
+        }
+    };
+    if (is_loader) {
+        for (int s0 = 0; s0 < BIO_GD; ++s0) issue(s0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // ---- weights: wave w owns the dh columns [w H/8, (w + 1) H/8) = NT tiles of 16; K step gg = gate gg of this workgroup's units
+    Frag bb[3][NT];
+    const int ncol0 = w * (H / 8);
+    if (is_compute) {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                bb[gg][n].u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + ncol0 + n * 16 + (lane & 15)) * (3 * H) + (size_t)gg * H + j0 +
+                                                              8 * (lane >> 4));
+    }
+    // gate phase on waves 2 and 3: thread (row (tid - 128) / 32, unit tid % 32)
+    const int b = ((tid - 128) >> 5) & 3, u0 = tid & 31;
+    const bool gate_wave = tid >= 128 && tid < 256;
+    const bool act = gate_wave && b < Bl;
+    float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) {
+        *s_abort = 0;
+        s_abort[1] = 0;
+        if (LOCAL) {
+            const int v = decide_local(sync, rec, nwg, abort_word, (forge & 1) ? 2 + (slot & 1) : 0);
+            if (v < 0) *s_abort = 1; else s_abort[1] = v;
+        }
+    }
+    for (int i = tid; i < 384; i += 640) reinterpret_cast<unsigned*>(aimg)[i & 255] = 0u;       // (rows >= Bl stay zero)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    ASR_RAW_BARRIER();
+    const bool local = LOCAL && s_abort[1] != 0;
+
+    // hand-off loads of the gate waves: 128 lanes x 2 pieces of 16 B = H/32 (<= 16.. 32) producers x 256 B.  Piece q = gl + 128 i:
+    // producer q / 16, columns j0 + 2 (q % 16), + 1 (x 4 rows).  (H = 1024: 32 producers -> 4 pieces per lane.)
+    constexpr int NP = NT <= 4 ? 2 : 4;
+    const int gl = tid - 128;                                   // 0 .. 127 on the gate waves
+    unsigned poff[NP];
+    bool pon[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int q = gl + 128 * i, pp = q >> 4, seg = q & 15;
+        pon[i] = gate_wave && pp < nwg;
+        poff[i] = (unsigned)(((size_t)pp * H + j0 + 2 * seg) * 8);
+    }
+    uint4 pcur[NP], pahead[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { pcur[i] = make_uint4(0, 0, 0, 0); pahead[i] = make_uint4(0, 0, 0, 0); }
+    auto fetch_p = [&](uint4 (&f)[NP], int ring) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (pon[i]) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, poff[i] + (unsigned)ring * xslot_bytes, 0, 16 /* sc1 */);
+                f[i] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+    };
+    // this wave's stores into the ring: tile n, lanes 0..15 (column ncol0 + 16 n + lane), 4 rows = 8 B
+    const unsigned soff = (unsigned)(((size_t)slot * H + ncol0 + (lane & 15)) * 8);
+
+    for (int s = 0; s < T; ++s) {
+        float rcr = 0.f;
+        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f;
+        if (gate_wave) {
+            const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
+            const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
+            r = of[0]; z = of[128]; n = of[256]; qq = of[384];
+            hp = s < T - 1 ? of[512] : 0.f;
+            dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
+            if (s > 0) {
+                // P_{s-1}: the first attempt was issued right behind this wave's own stores of the previous step
+#pragma unroll
+                for (int i = 0; i < NP; ++i) pcur[i] = pahead[i];
+                unsigned spins = 0;
+                for (;;) {
+                    bool missing = false;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i)
+                        missing |= pcur[i].x == 0xffffffffu || pcur[i].y == 0xffffffffu || pcur[i].z == 0xffffffffu || pcur[i].w == 0xffffffffu;
+                    if (__ballot(missing) == 0ull) break;
+                    if ((++spins & 63u) == 0u) {
+                        if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
+                        if (spins > kSpinLimit) {
+                            if (lane == 0) { __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT); *s_abort = 1; }
+                            break;
+                        }
+                    }
+                    fetch_p(pcur, (s - 1) & (PS_RING - 1));
+                }
+                // lane-local sum over this lane's producers, then [group = gl / 16][row][unit parity][seg] float32 in LDS
+                float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const unsigned wds[4] = {pcur[i].x, pcur[i].y, pcur[i].z, pcur[i].w};      // unit e = word / 2: rows 2 (word % 2), + 1
+                    if (pon[i]) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc8[2 * k] += bf16_to_f32((uint16_t)(wds[k] & 0xffffu));
+                            acc8[2 * k + 1] += bf16_to_f32((uint16_t)(wds[k] >> 16));
+                        }
+                    }
+                }
+                float* rw = red + (gl >> 4) * 128 + (gl & 15);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) rw[rr * 32 + e * 16] = acc8[e * 4 + rr];
+            }
+        }
+        ASR_RAW_BARRIER();                  // (R) the partial sums of the eight lane groups are in LDS
+        if ((s & 15) == 0 && lds_peek(s_abort)) break;
+        if (is_loader) {
+            issue(s + BIO_GD);              // the slot step s read above (before barrier R); waits until step s + 2 has landed
+            const int left = T - 1 - (s + 2);
+            if (left >= BIO_GD - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (left == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (is_storer) {
+            if (s > 0) store_step(s - 1);
+        } else if (gate_wave) {
+            if (s > 0) {
+                const float* rr_ = red + b * 32 + (u0 & 1) * 16 + (u0 >> 1);
+#pragma unroll
+                for (int gq = 0; gq < 8; ++gq) rcr += rr_[gq * 128];
+            }
+            const float dh = dyy + carry + rcr;
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (hp - n);
+            const float dan = dn * (1.0f - n * n);
+            const float daz = dz * z * (1.0f - z);
+            const float dq = dan * r;
+            const float dar = dan * qq * r * (1.0f - r);
+            carry = dh * z;
+            const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
+            if (act) { sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq); }
+            if (act) {
+                // MFMA A image [gate][row][unit] and the storer's [array][row][unit] (pairs of units per dword)
+                aimg[(0 * 4 + b) * 32 + u0] = ar; aimg[(1 * 4 + b) * 32 + u0] = az; aimg[(2 * 4 + b) * 32 + u0] = aq;
+                uint16_t* od = reinterpret_cast<uint16_t*>(oring + (size_t)(s & 1) * 4 * 4 * 16) + b * 32 + u0;
+                od[0] = ar; od[128] = az; od[256] = an; od[384] = aq;
+            }
+        }
+        ASR_RAW_BARRIER();                  // (A) the gate gradients of this step are in LDS
+        if (is_compute && s + 1 < T) {
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gg = 0; gg < 3; ++gg) {
+                Frag a;
+                a.u = make_uint4(0, 0, 0, 0);
+                if ((lane & 15) < 4) a.u = *reinterpret_cast<const uint4*>(aimg + (gg * 4 + (lane & 15)) * 32 + 8 * (lane >> 4));
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb[gg][nn].v, acc[nn], 0, 0, 0);
+            }
+            const unsigned ring_off = (unsigned)(s & (PS_RING - 1)) * xslot_bytes, rearm_off = (unsigned)((s + 2) & (PS_RING - 1)) * xslot_bytes;
+            if (lane < 16) {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) {
+                    unsigned lo = (unsigned)f32_to_bf16(acc[nn][0]) | ((unsigned)f32_to_bf16(acc[nn][1]) << 16);
+                    unsigned hi = (unsigned)f32_to_bf16(acc[nn][2]) | ((unsigned)f32_to_bf16(acc[nn][3]) << 16);
+                    if (lo == 0xffffffffu) lo = 0x7fc07fc0u;            // (NaN pairs of a diverged run) never the sentinel
+                    if (hi == 0xffffffffu) hi = 0x7fc07fc0u;
+                    const unsigned o = soff + (unsigned)nn * 128u + ring_off;
+                    if (local) {
+                        __builtin_amdgcn_raw_buffer_store_b32(lo, xrsrc, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(hi, xrsrc, o + 4u, 0, 0);
+                    } else {
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), lo, ASR_RLX_AGENT);
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), hi, ASR_RLX_AGENT);
+                    }
+                }
+            }
+            if (gate_wave) fetch_p(pahead, s & (PS_RING - 1));       // P_s, asked for right behind this wave's own stores
+            // re-arm the slot of step s - 2 (every consumer finished with it before it could produce the P_{s-1} this workgroup
+            // has just consumed); the slots of steps s + 1, s + 3 are armed (launch fill / earlier re-arm)
+            if (lane < 16 && s >= 2) {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) {
+                    const unsigned o = soff + (unsigned)nn * 128u + rearm_off;
+                    if (local) {
+                        __builtin_amdgcn_raw_buffer_store_b32(0xffffffffu, xrsrc, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(0xffffffffu, xrsrc, o + 4u, 0, 0);
+                    } else {
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), 0xffffffffu, ASR_RLX_AGENT);
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), 0xffffffffu, ASR_RLX_AGENT);
+                    }
+                }
+            }
+        }
+    }
+    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ASR_RAW_BARRIER();
+    if (is_storer && !*s_abort) store_step(T - 1);
+    if (act && db_ih && db_hh) {
+        float* bi = db_ih + (size_t)d * 3 * H + j0 + u0;
+        float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0;
+        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
+        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
+    }
+}
+
 // Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
 // most 8 rows, 4 compute waves (K = H split in 4) + loader (gi ring) + storer (f32 state and the four saved gate arrays,
 // one step behind).  The exchanged payload is the bf16 h row (hseq16), written sc1 by the gate threads themselves.
@@ -2478,7 +2765,9 @@ using namespace asr::gru;
 extern "C" size_t asr_gru_sync_bytes(int B, int H, int ndir) {
     const size_t G = (size_t)(B + RG - 1) / RG;
     const size_t exch = (size_t)ndir * G * 2 * RG * (3 * (size_t)H / 2) * 8;       // granule exchange area of the grouped kernels
-    return 4096 + (exch > kShardBytes ? exch : kShardBytes);                      // or the sharded step counters
+    const int nrec_pad = (ndir * ((B + 3) / 4) + 7) & ~7;
+    const size_t ps = kShardBytes + ps_exchange_bytes(nrec_pad, H);                // sharded counters + the partial-sum ring (bwd_ps_kernel)
+    return 4096 + (exch > ps ? exch : ps);
 }
 
 static int check_dims(int T, int B, int H, int ndir) {
@@ -2556,6 +2845,7 @@ static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_
 
 extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode) {
     if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
+    if (mode == 9 || mode == 10) mode = 0;
     static int dummy;
     return fwd_family(T, B, H, ndir, mode, &dummy) == 2 ? 1 : 0;
 }
@@ -2566,6 +2856,7 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
     if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
+    if (mode == 9 || mode == 10) mode = 0;      // (those select backward kernels)
     const float* gi = reinterpret_cast<const float*>(gi_any);
     if (gi_bf16 && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
     hipStream_t st = (hipStream_t)stream;
@@ -2707,6 +2998,33 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
             default: return ASR_ERR_UNSUPPORTED;
         }
 #undef ASR_BWDG
+        return ASR_OK;
+    }
+    // partial-sum exchange (bwd_ps_kernel): the default where it applies (modes 0 / 8; 9 asks for it, 10 forges a split
+    // placement so that its placement-free stores are exercised); measured 1.78 -> 1.59 us per step at T=1000, B=32, H=512
+    if (persist && (mode == 0 || mode == 8 || mode == 9 || mode == 10) && db_ih && db_hh && H % 128 == 0 && H <= 1024 &&
+        ndir * ((B + 3) / 4) <= 16) {
+        const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
+        if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
+        if (hipMemsetAsync((char*)sync_ws + kPsOffset, 0xff, ps_exchange_bytes(nrec_pad, H), st) != hipSuccess) return ASR_ERR_LAUNCH;
+        const dim3 wgrid(nrec_pad * (H / 32)), wblock(640);
+#define ASR_BWDPS(NT_)                                                                                                    \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)bwd_ps_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kExclusiveLds); \
+        hipLaunchKernelGGL((bwd_ps_kernel<NT_, true>), wgrid, wblock, kExclusiveLds, st, (const uint16_t*)dy_bf16, gates, hseq,    \
+                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh, (unsigned*)sync_ws, \
+                           T, B, H, ndir, mode == 10 ? 1 : 0);                                                            \
+    } while (0)
+        switch (H / 128) {
+            case 1: ASR_BWDPS(1); break;
+            case 2: ASR_BWDPS(2); break;
+            case 3: ASR_BWDPS(3); break;
+            case 4: ASR_BWDPS(4); break;
+            case 8: ASR_BWDPS(8); break;
+            default: return ASR_ERR_UNSUPPORTED;
+        }
+#undef ASR_BWDPS
+        ASR_LAUNCH_CHECK();
         return ASR_OK;
     }
     // wide form (32 units x 4-row recurrences): mode 5 keeps the 16-unit x 8-row kernels for comparison

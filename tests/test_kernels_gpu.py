@@ -259,7 +259,8 @@ def test_layer_stack_fuses_maxout_and_pooling(device):
 # 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
 # 4: persistent with the XCD-local hand-off where placement allows, signalled by flags; 8: the same with the payload as its
 # own signal (= automatic); 7: 4 with a forged split placement
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7, 8])
+# 9: backward with the partial-sum exchange (bwd_ps_kernel; H % 128 == 0, else the wide kernel serves); 10: 9 with a forged split placement
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7, 8, 9, 10])
 @pytest.mark.parametrize("T,B,I,H,ndir", [(12, 4, 64, 64, 2), (9, 5, 96, 128, 1), (20, 32, 64, 512, 2), (7, 40, 32, 64, 2),
                                           (150, 32, 32, 256, 2), (40, 19, 48, 128, 2), (30, 7, 32, 384, 1)])
 def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
@@ -423,7 +424,7 @@ def test_gru_full_size_forms_agree(device):
     dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
     res = {}
     try:
-        for mode in (1, 2, 0, 4, 7):
+        for mode in (1, 2, 0, 4, 7, 10):
             _ops.GRU_MODE[0] = mode
             y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir)
             dbi = torch.zeros(ndir * 3 * H, device=device)
@@ -435,7 +436,7 @@ def test_gru_full_size_forms_agree(device):
     finally:
         _ops.GRU_MODE[0] = 0
     ref = res[1]
-    for mode in (2, 0, 4, 7):
+    for mode in (2, 0, 4, 7, 10):
         for name, a, r, tol in zip(("y", "hseq", "gates", "dgi", "dgh", "db_ih", "db_hh"), res[mode], ref,
                                    (2e-2, 2e-3, 2e-3, 2e-2, 2e-2, 1e-2, 1e-2)):
             err = float((a - r).abs().max()) / (float(r.abs().max()) + 1e-12)
@@ -444,9 +445,15 @@ def test_gru_full_size_forms_agree(device):
     # hand-off differs): bit-identical (bias gradients excepted: their float atomics land in any order).  Mode 2 runs the
     # wide forward kernel (another K split), so it agrees to rounding only.
     # (mode 0 = payload polled as its own signal, mode 4 = flag line, mode 7 = counters after a forged split placement)
-    for other in (4, 7):
-        for a, b_ in zip(res[0][:5], res[other][:5]):
+    # (backward: mode 0 runs the partial-sum exchange kernel, mode 10 the same with a forged split placement; modes 4 / 7 the
+    # wide kernel and its forged fall-back)
+    for other in (4, 7, 10):
+        for a, b_ in zip(res[0][:3], res[other][:3]):
             assert torch.equal(a, b_)
+    for a, b_ in zip(res[0][3:5], res[10][3:5]):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(res[4][3:5], res[7][3:5]):
+        assert torch.equal(a, b_)
 
 def test_non_finite_step_is_skipped(device):
     """a NaN / Inf gradient norm leaves parameters and optimiser state untouched (run/ctc/cnn/train.py:193-197)"""
