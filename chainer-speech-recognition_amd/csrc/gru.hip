@@ -1533,8 +1533,8 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                     if (hi == 0xffffffffu) hi = 0x7fc07fc0u;
                     const unsigned o = soff + (unsigned)nn * 128u + ring_off;
                     if (local) {
-                        __builtin_amdgcn_raw_buffer_store_b32(lo, xrsrc, o, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(hi, xrsrc, o + 4u, 0, 0);
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, xrsrc, o, 0, 0);
                     } else {
                         __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), lo, ASR_RLX_AGENT);
                         __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), hi, ASR_RLX_AGENT);
@@ -1549,8 +1549,8 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                 for (int nn = 0; nn < NT; ++nn) {
                     const unsigned o = soff + (unsigned)nn * 128u + rearm_off;
                     if (local) {
-                        __builtin_amdgcn_raw_buffer_store_b32(0xffffffffu, xrsrc, o, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(0xffffffffu, xrsrc, o + 4u, 0, 0);
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){0xffffffffu, 0xffffffffu}, xrsrc, o, 0, 0);
                     } else {
                         __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), 0xffffffffu, ASR_RLX_AGENT);
                         __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), 0xffffffffu, ASR_RLX_AGENT);
