@@ -483,11 +483,13 @@ def main():
         per_launch_s = gru_ms * 1e-3 / launches
         # algorithmic HBM bytes of a launch, per (t, b) row and both directions:
         #   forward : gi bf16 in (6H*2), h bf16 out + in again by the next step (2H*2*2), f32 state out (2H*4), gates out (8H*4)
-        #   backward: dy bf16 in (H*2), gates in (8H*4), f32 state in (2H*4), dgi out (6H*2), dgh out + in again (6H*2*2)
+        #   backward: dy bf16 in (H*2), gates in (8H*4), f32 state in (2H*4), dgi out (6H*2), dgh out (6H*2)
         # plus the W_hh slice once per launch (2*3H*H*2)
         gi_bytes = 2 if _ops.gru_gi_dtype(T, B, H, 2) == torch.bfloat16 else 4
         fwd_bytes = T * B * (6 * H * gi_bytes + 2 * H * 2 * 2 + 2 * H * 4 + 8 * H * 4) + 2 * 3 * H * H * 2
-        bwd_bytes = T * B * (H * 2 + 8 * H * 4 + 2 * H * 4 + 6 * H * 2 + 6 * H * 2 * 2) + 2 * 3 * H * H * 2
+        # (backward, partial-sum exchange: dgh is written once for the weight-gradient GEMM and not read back; the partial sums
+        # travel through the L2 only)
+        bwd_bytes = T * B * (H * 2 + 8 * H * 4 + 2 * H * 4 + 6 * H * 2 + 6 * H * 2) + 2 * 3 * H * H * 2
         alg = 0.5 * (fwd_bytes + bwd_bytes)
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
@@ -495,11 +497,11 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(pmc_path):
             ks = json.load(open(pmc_path))["kernels"]
-            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k]
+            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k or "gru::bwd_ps_kernel" in k]
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
                 traffic_src = "profiles/r02_pmc_traffic.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_wide_kernel (one launch per layer)",
+        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
                            "fwd_us_per_time_step": tot["gru_fwd"][0] * 1e3 / tot["gru_fwd"][1] / T, "bwd_us_per_time_step": tot["gru_bwd"][0] * 1e3 / tot["gru_bwd"][1] / T,
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -19,7 +19,8 @@ step = rows[a + 1:b + 1]
 t0, t1 = rows[a][1], rows[b][1]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 print("step: %.3f ms, %d kernels" % ((t1 - t0) / 1e6, len(step)), file=out)
-gru = [(s, e) for s, e, n, q in step if "persistent" in n or "wide_kernel" in n]
+REC = ("persistent", "wide_kernel", "bwd_ps_kernel")
+gru = [(s, e) for s, e, n, q in step if any(k in n for k in REC)]
 print("recurrence kernels: %d, %.3f ms" % (len(gru), sum(e - s for s, e in gru) / 1e6), file=out)
 # segments outside the recurrence kernels
 edges = [t0] + [x for s, e in gru for x in (s, e)] + [t1]
@@ -28,7 +29,7 @@ tot = collections.Counter()
 for k, (s0, s1) in enumerate(segs):
     print("\n-- segment %d: %.3f ms" % (k, (s1 - s0) / 1e6), file=out)
     cur = s0
-    inside = [r for r in step if r[1] > s0 and r[0] < s1 and not ("persistent" in r[2] or "wide_kernel" in r[2])]
+    inside = [r for r in step if r[1] > s0 and r[0] < s1 and not any(k in r[2] for k in REC)]
     for s, e, n, q in inside:
         s_, e_ = max(s, s0), min(e, s1)
         if s_ > cur:
