@@ -74,10 +74,10 @@ SIGNATURES = {
                                   c_longlong, c_int, c_int]),
     "asr_layernorm_bwd_rows_ws_bytes": (c_longlong, [c_longlong, c_int]),
     "asr_layernorm_bwd_rows": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_longlong]),
-    "asr_layernorm_fold_partials": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "asr_layernorm_fold_partials": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "asr_layernorm_ctc_bwd_ws_bytes": (c_longlong, [c_int, c_int, c_int]),
     "asr_layernorm_ctc_bwd": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_longlong, c_int] +
-                              [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float] * 2),
+                              [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float] * 2 + [c_void_p]),
     "asr_weightnorm_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int]),
     "asr_weightnorm_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int]),
     "asr_channel_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),

@@ -271,7 +271,7 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, C, dx_dtype, dgamma=None, dbeta=None
 CALLS = {}          # call counters of a few entry points (tests check which path ran)
 
 
-def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta, need_dx, recipes):
+def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta, need_dx, recipes, dxsum=None):
     """asr_layernorm_ctc_bwd: `recipes` = one or two dicts left by CTC-family losses on the normalised rows (asr/loss/ctc.py):
     ws, Lmax, gram, x_len, gy, gy_per_utt, scale"""
     rows, V = x.shape
@@ -285,7 +285,7 @@ def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta,
     for r in (recipes + recipes)[:2]:
         args += [ptr(r["ws"]), int(r["Lmax"]), int(r["gram"]), ptr(r["x_len"]), ptr(r["gy"]), int(r["gy_per_utt"]), float(r["scale"])]
     rc = lib.asr_layernorm_ctc_bwd(stream(), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), _is_bf16(dx) if need_dx else 0,
-                                   ptr(dgamma), ptr(dbeta), T, B, V, ptr(ws), nbytes, len(recipes), *args)
+                                   ptr(dgamma), ptr(dbeta), T, B, V, ptr(ws), nbytes, len(recipes), *args, ptr(dxsum))
     check(rc, "asr_layernorm_ctc_bwd")
     return dx
 

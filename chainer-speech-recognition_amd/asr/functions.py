@@ -81,10 +81,12 @@ class _OnSide(object):
 # autograd an all-zero stride-0 token instead.  The producer adds mailbox + whatever autograd delivered, so the result is
 # right with any number of consumers; with the usual single consumer the token is recognised and nothing is added.
 class _GradMailbox(object):
-    __slots__ = ("ptr", "numel", "value")
+    """`bias`: the producer's bias parameter; a consumer that forms the gradient of the producer's output inside its own sweep
+    may add its column sums to that bias gradient there and then (`bias_done`), sparing the producer a pass over the rows"""
+    __slots__ = ("ptr", "numel", "value", "bias", "bias_done")
 
-    def __init__(self, y):
-        self.ptr, self.numel, self.value = y.data_ptr(), y.numel(), None
+    def __init__(self, y, bias=None):
+        self.ptr, self.numel, self.value, self.bias, self.bias_done = y.data_ptr(), y.numel(), None, bias, False
 
     def post(self, g):
         self.value = g if self.value is None else _ops.add_bf16(self.value, g.reshape(self.value.shape))
@@ -268,7 +270,7 @@ class _Conv2D(torch.autograd.Function):
             ctx.params = (W, b)
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, False, 2)
             if out_f32:
-                ctx._asr_mailbox = _GradMailbox(y)
+                ctx._asr_mailbox = _GradMailbox(y, b)
             return y.reshape(Tout, B, Hout, Co)
         # implicit GEMM (asr_conv_nt): no column matrix when the input is already physical bf16 and every 16-B chunk of a
         # virtual im2col row stays inside one tap
@@ -281,7 +283,7 @@ class _Conv2D(torch.autograd.Function):
             ctx.params = (W, b)
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, ctx.needs_input_grad[0], True)
             if out_f32:
-                ctx._asr_mailbox = _GradMailbox(y)
+                ctx._asr_mailbox = _GradMailbox(y, b)
             return y.reshape(Tout, B, Hout, Co)
         if pointwise:
             xp = x.permute(3, 0, 2, 1)
@@ -306,6 +308,7 @@ class _Conv2D(torch.autograd.Function):
         col, w16t, wbwd = ctx.saved_tensors
         W, b = ctx.params
         B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx, implicit = ctx.meta
+        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False)
         gy = _incoming_bf16(ctx, gy, Co)
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
@@ -344,7 +347,7 @@ class _Conv2D(torch.autograd.Function):
                 _ops.fill_(scratch, 0.0)
                 _ops.gemm_tn_acc(g2, col, scratch)
                 _ops.conv_weight_grad_unpack(scratch, gW)
-            if gb is not None:
+            if gb is not None and not bias_done:
                 _ops.colsum_acc(g2, gb)
         if w_is_param:
             with _OnSide(g2, col):
@@ -417,20 +420,21 @@ class _Dense(torch.autograd.Function):
         ctx.params = (W, b)
         ctx.need_dx = ctx.needs_input_grad[0]
         if out_f32:
-            ctx._asr_mailbox = _GradMailbox(y)
+            ctx._asr_mailbox = _GradMailbox(y, b)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x2, w16t = ctx.saved_tensors
         W, b = ctx.params
+        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False)
         gy = _incoming_bf16(ctx, gy, W.shape[0])
         gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         gW = grad_buffer(W).reshape(W.shape[0], -1)
         gb = grad_buffer(b) if b is not None else None
         with _OnSide(gy, x2):
             _ops.gemm_tn_acc(gy, x2, gW)
-            if gb is not None:
+            if gb is not None and not bias_done:
                 _ops.colsum_acc(gy, gb)
         grads_queued(W, b)
         return gx, None, None, None, None, None
@@ -660,8 +664,14 @@ class _LayerNorm(torch.autograd.Function):
         dx = None
         if recipes:
             T, B, _ = box.shape
+            # the whole gradient of x2 is formed in this sweep: its column sums are the bias gradient of the projection in front
+            dxsum = None
+            if handover and _is_zero_token(gy) and mailbox.bias is not None and isinstance(mailbox.bias, torch.nn.Parameter) \
+                    and mailbox.bias.numel() == C:
+                dxsum = grad_buffer(mailbox.bias).reshape(-1)
+                mailbox.bias_done = True
             dx = _ops.layernorm_ctc_bwd(x2, gamma.detach(), beta.detach(), mean, rstd, T, B, dx_dtype, grad_buffer(gamma),
-                                        grad_buffer(beta), need_dx, recipes)
+                                        grad_buffer(beta), need_dx, recipes, dxsum)
         if not recipes or not _is_zero_token(gy):       # a gradient that did arrive through autograd
             dx2 = _ops.layernorm_bwd(x2, gy.contiguous(), gamma.detach(), mean, rstd, C, dx_dtype, grad_buffer(gamma),
                                      grad_buffer(beta), need_dx)

@@ -32,7 +32,8 @@ struct Loss {               // one CTC-family loss on the normalised row (up to 
     int Sp;
 };
 
-template <typename DT, int NV, int NL>
+// XS: also carry the plain column sums of dx (third plane of `partial`): the bias gradient of the projection in front
+template <typename DT, int NV, int NL, bool XS>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const float* __restrict__ mean_in,
                                                   const float* __restrict__ rstd_in, DT* __restrict__ dx, float* __restrict__ partial,
@@ -42,7 +43,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x, c
     __shared__ float red[2][2][4];
     const int n4 = D >> 2, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const long long rows = (long long)T * B;
-    float4 gm[NV], bt[NV], ag[NV], ab[NV], v[NV], vn[NV];
+    float4 gm[NV], bt[NV], ag[NV], ab[NV], v[NV], vn[NV], ax[XS ? NV : 1];
+#pragma unroll
+    for (int k = 0; k < (XS ? NV : 1); ++k) ax[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int i = tid + 256 * k;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x, c
     int par = 0;
     const float invD = 1.0f / (float)D;
     for (; row < rows; row += gridDim.x) {
-        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        const int t = (int)(row / B);
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = vn[k];
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -211,17 +214,20 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x, c
                 }
                 ag[k].x += gy[k].x * v[k].x; ag[k].y += gy[k].y * v[k].y; ag[k].z += gy[k].z * v[k].z; ag[k].w += gy[k].w * v[k].w;
                 ab[k].x += gy[k].x; ab[k].y += gy[k].y; ab[k].z += gy[k].z; ab[k].w += gy[k].w;
+                if (XS) { ax[k].x += d0; ax[k].y += d1; ax[k].z += d2; ax[k].w += d3; }
             }
         }
     }
     if (partial) {
-        float* pg = partial + (size_t)blockIdx.x * 2 * D;
+        constexpr int PL = XS ? 3 : 2;
+        float* pg = partial + (size_t)blockIdx.x * PL * D;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int i = tid + 256 * k;
             if (i < n4) {
                 reinterpret_cast<float4*>(pg)[i] = ag[k];
                 reinterpret_cast<float4*>(pg + D)[i] = ab[k];
+                if (XS) reinterpret_cast<float4*>(pg + 2 * D)[i] = ax[k];
             }
         }
     }
@@ -249,18 +255,20 @@ static int ctcln_grid(long long rows, int B, int V) {
 
 extern "C" long long asr_layernorm_ctc_bwd_ws_bytes(int T, int B, int V) {
     if (T <= 0 || B <= 0 || V <= 0 || (V & 3) || V > 4096) return 0;
-    return (long long)ctcln_grid((long long)T * B, B, V) * 2 * V * (long long)sizeof(float);
+    return (long long)ctcln_grid((long long)T * B, B, V) * 3 * V * (long long)sizeof(float);
 }
 
 extern "C" int asr_layernorm_ctc_bwd(void* stream, const float* x, const float* gamma, const float* beta, const float* mean,
                                      const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta, int T, int B, int V,
                                      void* ws, long long ws_bytes, int nloss, const void* ctc_ws0, int Lmax0, int gram0,
                                      const int32_t* x_len0, const float* gy0, int gy_per_utt0, float scale0, const void* ctc_ws1,
-                                     int Lmax1, int gram1, const int32_t* x_len1, const float* gy1, int gy_per_utt1, float scale1) {
+                                     int Lmax1, int gram1, const int32_t* x_len1, const float* gy1, int gy_per_utt1, float scale1,
+                                     float* dxsum) {
     if (!x || !gamma || !beta || !mean || !rstd || T <= 0 || B <= 0 || V <= 0 || nloss < 1 || nloss > 2 || !ctc_ws0 || (nloss == 2 && !ctc_ws1))
         return ASR_ERR_BAD_ARG;
     if ((V & 3) || V > 4096 || ((((uintptr_t)x) | ((uintptr_t)dx)) & 15)) return ASR_ERR_UNSUPPORTED;
     const bool params = dgamma && dbeta;
+    if (dxsum && !params) return ASR_ERR_BAD_ARG;
     const long long need = asr_layernorm_ctc_bwd_ws_bytes(T, B, V);
     if (params && (!ws || ws_bytes < need)) return ASR_ERR_BAD_ARG;
     if (!dx && !params) return ASR_OK;
@@ -279,12 +287,16 @@ extern "C" int asr_layernorm_ctc_bwd(void* stream, const float* x, const float* 
     float* partial = params ? (float*)ws : nullptr;
     const int nv = (V / 4 + 255) / 256;
     const size_t lds = sizeof(float) * 2 * (size_t)nloss * V;
-#define ASR_CL(DT, NV, NL)                                                                                                \
+#define ASR_CL_(DT, NV, NL, XS)                                                                                           \
     do {                                                                                                                  \
         if (lds > 48 * 1024)                                                                                              \
-            (void)hipFuncSetAttribute((const void*)ctcln::bwd_kernel<DT, NV, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((ctcln::bwd_kernel<DT, NV, NL>), dim3(G), dim3(256), lds, s, x, gamma, beta, mean, rstd, (DT*)dx, partial, \
+            (void)hipFuncSetAttribute((const void*)ctcln::bwd_kernel<DT, NV, NL, XS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((ctcln::bwd_kernel<DT, NV, NL, XS>), dim3(G), dim3(256), lds, s, x, gamma, beta, mean, rstd, (DT*)dx, partial, \
                            T, B, V, l0, l1);                                                                              \
+    } while (0)
+#define ASR_CL(DT, NV, NL)                                                                                                \
+    do {                                                                                                                  \
+        if (dxsum) ASR_CL_(DT, NV, NL, true); else ASR_CL_(DT, NV, NL, false);                                            \
     } while (0)
 #define ASR_CLN(NV)                                                                                                       \
     do {                                                                                                                  \
@@ -299,9 +311,10 @@ extern "C" int asr_layernorm_ctc_bwd(void* stream, const float* x, const float* 
     }
 #undef ASR_CLN
 #undef ASR_CL
+#undef ASR_CL_
     ASR_LAUNCH_CHECK();
     if (params) {
-        const int rc = asr_layernorm_fold_partials(stream, partial, G, V, V, dgamma, dbeta);
+        const int rc = asr_layernorm_fold_partials(stream, partial, G, V, V, dgamma, dbeta, dxsum);
         if (rc != ASR_OK) return rc;
     }
     return ASR_OK;

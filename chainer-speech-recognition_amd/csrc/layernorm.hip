@@ -258,21 +258,25 @@ __global__ __launch_bounds__(256) void bwd_rows_f32_kernel(const float* __restri
     }
 }
 // dgamma[c] += sum over workgroups and positions of partial[.][0][i], i % C == c; dbeta likewise from partial[.][1][i]
+// (planes = 3: a third plane of plain column sums goes to `extra` -- the bias gradient of the layer in front, csrc/ctc_ln.hip)
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partial, int G, int D, int C,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int planes,
+                                                            float* __restrict__ extra) {
     __shared__ float acc[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const int chunk = (G + gridDim.y - 1) / gridDim.y;
     const int g0 = blockIdx.y * chunk, g1 = min(G, g0 + chunk);
     float s = 0.f;
-    if (col < 2 * D)
-        for (int g = g0 + w; g < g1; g += 4) s += partial[(size_t)g * 2 * D + col];
+    if (col < planes * D)
+        for (int g = g0 + w; g < g1; g += 4) s += partial[(size_t)g * planes * D + col];
     acc[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && col < 2 * D) {
+    if (w == 0 && col < planes * D) {
         const int t = threadIdx.x;
         const float total = (acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t]);
-        if (col < D) atomicAdd(dgamma + col % C, total); else atomicAdd(dbeta + (col - D) % C, total);
+        if (col < D) atomicAdd(dgamma + col % C, total);
+        else if (col < 2 * D) atomicAdd(dbeta + (col - D) % C, total);
+        else atomicAdd(extra + (col - 2 * D), total);
     }
 }
 
@@ -462,19 +466,21 @@ extern "C" int asr_layernorm_bwd_rows(void* stream, const float* x, const float*
     if (params) {
         int chunks = (G + 15) / 16;
         if (chunks > 16) chunks = 16;
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * D, 64), chunks), dim3(256), 0, s, partial, G, D, C, dgamma, dbeta);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * D, 64), chunks), dim3(256), 0, s, partial, G, D, C, dgamma, dbeta, 2, (float*)nullptr);
         ASR_LAUNCH_CHECK();
     }
     return ASR_OK;
 }
 
 // dgamma / dbeta += the per-workgroup column sums of a one-sweep backward (also used by csrc/ctc_ln.hip)
-extern "C" int asr_layernorm_fold_partials(void* stream, const float* partial, int G, int D, int C, float* dgamma, float* dbeta) {
+extern "C" int asr_layernorm_fold_partials(void* stream, const float* partial, int G, int D, int C, float* dgamma, float* dbeta,
+                                           float* extra) {
     if (!partial || !dgamma || !dbeta || G <= 0 || D <= 0 || C <= 0 || D % C) return ASR_ERR_BAD_ARG;
     int chunks = (G + 15) / 16;
     if (chunks > 16) chunks = 16;
-    hipLaunchKernelGGL(asr::ln::fold_partials_kernel, dim3(cdiv(2 * D, 64), chunks), dim3(256), 0, (hipStream_t)stream, partial, G, D, C,
-                       dgamma, dbeta);
+    const int planes = extra ? 3 : 2;
+    hipLaunchKernelGGL(asr::ln::fold_partials_kernel, dim3(cdiv(planes * D, 64), chunks), dim3(256), 0, (hipStream_t)stream, partial, G, D, C,
+                       dgamma, dbeta, planes, extra);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

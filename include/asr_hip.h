@@ -217,21 +217,23 @@ int asr_channel_affine(void* stream, const float* x, const float* scale, const f
                        int C);
 int asr_weightnorm_init(void* stream, const float* mean, const float* stdv, float* g, float* b, int C);
 
-/* dgamma / dbeta += column sums of partial (G, 2, D) written by a one-sweep backward (channel = index % C) */
-int asr_layernorm_fold_partials(void* stream, const float* partial, int G, int D, int C, float* dgamma, float* dbeta);
+/* dgamma / dbeta += column sums of partial (G, 2, D) written by a one-sweep backward (channel = index % C); with `extra`
+ * the buffer is (G, 3, D) and extra[D] += the column sums of the third plane */
+int asr_layernorm_fold_partials(void* stream, const float* partial, int G, int D, int C, float* dgamma, float* dbeta, float* extra);
 /* Backward of [LayerNormalization over the vocabulary of each frame] -> [one or two CTC-family losses] in one sweep: the
  * gradient with respect to the normalised logits, (softmax - occupancy) * scale * gy summed over the losses
  * (asr/loss/gram_ctc.py:284-297), is formed in registers from the pre-normalisation rows x (T*B, V) f32, the row
  * statistics of asr_layernorm_fwd and the workspaces asr_ctc_forward left behind (ctc_ws: same T, B, Lmax, gram as that
  * call; x_len / gy / gy_per_utt / scale as for asr_ctc_backward), and goes straight into the layer-norm backward
  * (asr/nn/layernorm.py:50-61): dx (f32 or bf16, may be NULL) and dgamma / dbeta ACCUMULATED (both or neither).  V % 4 == 0,
- * V <= 4096, 3*Lmax+1 <= 512.  ws: asr_layernorm_ctc_bwd_ws_bytes(T, B, V) bytes. */
+ * V <= 4096, 3*Lmax+1 <= 512.  ws: asr_layernorm_ctc_bwd_ws_bytes(T, B, V) bytes.  dxsum (V floats, or NULL; needs dgamma / dbeta):
+ * ACCUMULATES the column sums of dx -- the bias gradient of the projection that produced x. */
 long long asr_layernorm_ctc_bwd_ws_bytes(int T, int B, int V);
 int asr_layernorm_ctc_bwd(void* stream, const float* x, const float* gamma, const float* beta, const float* mean,
                           const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta, int T, int B, int V, void* ws,
                           long long ws_bytes, int nloss, const void* ctc_ws0, int Lmax0, int gram0, const int32_t* x_len0,
                           const float* gy0, int gy_per_utt0, float scale0, const void* ctc_ws1, int Lmax1, int gram1,
-                          const int32_t* x_len1, const float* gy1, int gy_per_utt1, float scale1);
+                          const int32_t* x_len1, const float* gy1, int gy_per_utt1, float scale1, float* dxsum);
 
 /* ---------------------------------------------------------------------------------------- batch normalisation
  * chainer.links.BatchNormalization reaches the reference API through `from chainer.links import *` (asr/nn/nn.py:3);

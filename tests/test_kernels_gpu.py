@@ -589,3 +589,21 @@ def test_wide_nt_kernels_in_a_forced_process(mode):
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
                           "-k", "test_gemm_nt or test_implicit_conv or test_conv_as_im2col"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("rows,cols,dtype,ld", [(1000, 640, BF16, 640), (32000, 3000, BF16, 3000), (777, 29, BF16, 29), (500, 64, F32, 64),
+                                                (3000, 128, BF16, 256), (4097, 2048, BF16, 2048), (257, 8192, BF16, 8192), (100, 8200, BF16, 8200)])
+def test_colsum_acc(device, rows, cols, dtype, ld):
+    """asr_colsum_acc (bias gradients): out[c] += sum_r x[r][c] on every code path (16-byte rows up to 2048 columns, wide rows,
+    scalar fall-back, float32, strided rows), accumulated on top of what is there"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(rows + cols)
+    full = torch.randn(rows, ld, generator=g)
+    if dtype == BF16:
+        full = _bf(full)
+    xd = full.to(device, dtype)[:, :cols]
+    out = torch.ones(cols, device=device)
+    _ops.colsum_acc(xd, out)
+    ref = 1.0 + full[:, :cols].double().sum(dim=0)
+    tol = 2e-4 * float(full[:, :cols].abs().sum(dim=0).max())
+    assert float((out.cpu().double() - ref).abs().max()) <= tol

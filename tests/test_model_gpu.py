@@ -483,3 +483,36 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         assert c > (0.95 if p.numel() >= 256 else 0.90), (name, c)
         ratio = p.grad.cpu().norm().item() / (g_ref.norm().item() + 1e-30)
         assert 0.85 < ratio < 1.15, (name, ratio)
+
+
+def test_fused_logit_region_gives_the_gradients_of_the_unfused_one(device):
+    """model level: with the CTC gradient formed inside LayerNormalization's backward (and the projection's bias gradient taken
+    from the same sweep) every parameter gradient equals the one of the three-kernel route up to float32 summation order /
+    one bf16 rounding of dx"""
+    from asr import functions as F, _ops
+    from asr.loss import connectionist_temporal_classification
+    B, T, V = 4, 48, 40
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=9, ragged=True)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+
+    def run(fused):
+        F.FUSE_CTC_INTO_LAYERNORM[0] = fused
+        try:
+            cfg, model = _build(device, V=V, seed=31)
+            before = _ops.CALLS.get("layernorm_ctc_bwd", 0)
+            loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+            loss.backward()
+            F.join_side_stream()
+            torch.cuda.synchronize()
+            assert (_ops.CALLS.get("layernorm_ctc_bwd", 0) - before) == (1 if fused else 0)
+            return loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}
+        finally:
+            F.FUSE_CTC_INTO_LAYERNORM[0] = True
+    (lf, gf), (lu, gu) = run(True), run(False)
+    assert lf == lu
+    for name in gu:
+        err = float((gf[name] - gu[name]).norm() / (gu[name].norm() + 1e-30))
+        assert err < 1e-2, (name, err)
+    # the logit projection's bias gradient comes out of the fused sweep in float32 (no bf16 rounding of dx in between)
+    name = "dense_blocks._sequential_6.b"
+    assert float((gf[name] - gu[name]).norm() / gu[name].norm()) < 5e-3
