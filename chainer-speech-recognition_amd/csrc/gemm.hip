@@ -803,6 +803,174 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
             }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, 256 x 128 tile
+// The 128 x 128 TN kernel above stages its operands through registers (global load -> VGPR -> ds_write) and runs 16 MFMAs per
+// barrier.  This one is the NT 256 x 128 kernel's structure on k-strided operands: LDS-DMA straight into a two-stage ring (no
+// staging registers: 3 workgroups per CU), four waves of 128 x 64 (32 MFMAs per wave and barrier), fragments by
+// ds_read_b64_tr_b16.  LDS image of a k row: its 16-B chunks in order, chunk c of row k stored at position c ^ ((k & 7) << 1) --
+// the 32 lanes a transposing read services together (8 k rows x 32 B) then cover all 64 banks; LDS-DMA writes lane-linear, so
+// the swizzle is applied to the SOURCE address (as in the NT kernels).  Rows beyond the K split and columns beyond M / N read a
+// page of zeros.  Split-K with float atomics and the XCD-aware order of the kernel above.  CONV: B = virtual im2col matrix.
+constexpr int T2M = 256, T2N = 128;
+constexpr int TN2_STAGES = 2;
+constexpr int TN2_LDS_BYTES = TN2_STAGES * (T2M + T2N) * TK * 2;      // 2 x 24 KiB
+
+template <bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_tn256_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
+                                                            int ldb, float* __restrict__ C, int ldc, int M, int N, int K, int tiles_n,
+                                                            int k_per_split, ConvDesc cd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_STAGE = TK * T2M * 2, B_STAGE = TK * T2N * 2;          // 16 KiB, 8 KiB
+    char* As = smem;
+    char* Bs = smem + TN2_STAGES * A_STAGE;
+    const int tiles = ((M + T2M - 1) / T2M) * tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int round = slot / tiles, bid = slot - round * tiles;
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * T2M, n0 = tn * T2N;
+    const int kbeg = (round * 8 + xcd) * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    if (kbeg >= kend) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS-DMA slots.  A image: 32 k rows x 32 chunks = 1024 slots, slot = i * 256 + tid: k row slot / 32, position slot % 32;
+    // B image: 32 x 16 = 512 slots: k row slot / 16, position slot % 16.
+    const uint16_t* ga[4];
+    const uint16_t* gb[2];
+    int ka[4], kb[2];                      // k row of the slot inside the tile
+    bool oka[4], okb[2];                   // the slot's columns exist
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sl = i * 256 + tid, kr = sl >> 5, c = (sl & 31) ^ ((kr & 7) << 1);
+        ka[i] = kr;
+        oka[i] = m0 + c * 8 < M;           // (M % 8 == 0: a chunk is inside or outside as a whole)
+        ga[i] = A + (size_t)(kbeg + kr) * lda + m0 + c * 8;
+    }
+    // CONV: a slot's chunk never changes -> tap and channel are loop invariant; its row (t, b, h) steps by the k tile
+    int cv_dt[2] = {0, 0}, cv_dh[2] = {0, 0}, cv_ci[2] = {0, 0}, cv_t[2] = {0, 0}, cv_b[2] = {0, 0}, cv_h[2] = {0, 0};
+    int inc_h = 0, inc_b = 0, inc_t = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sl = i * 256 + tid, kr = sl >> 4, c = (sl & 15) ^ ((kr & 7) << 1);
+        kb[i] = kr;
+        const int n = n0 + c * 8;
+        okb[i] = n < N;
+        if (CONV) {
+            const int tap = n / cd.Cs, kh = tap / cd.KW, kw = tap - kh * cd.KW;
+            cv_ci[i] = n - tap * cd.Cs;
+            cv_dt[i] = kw - cd.pt;
+            cv_dh[i] = kh - cd.ph;
+            okb[i] = okb[i] && kh < cd.KH;
+            const int gk = kbeg + kr;
+            cv_h[i] = gk % cd.Hr;
+            const int tb = gk / cd.Hr;
+            cv_b[i] = tb % cd.B;
+            cv_t[i] = tb / cd.B;
+            gb[i] = B;
+        } else {
+            gb[i] = B + (size_t)(kbeg + kr) * ldb + n;
+        }
+    }
+    if (CONV) {
+        inc_h = TK % cd.Hr;
+        const int inc_tb = TK / cd.Hr;
+        inc_b = inc_tb % cd.B;
+        inc_t = inc_tb / cd.B;
+    }
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+    auto issue_tile = [&](int kt, int buf) {            // called with kt = 0, 1, 2, ... in order (the CONV row walk relies on it)
+        const int k0 = kbeg + kt * TK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint16_t* src = (oka[i] && k0 + ka[i] < kend) ? ga[i] + (size_t)kt * TK * lda : zero;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint16_t* src;
+            if (CONV) {
+                const int t = cv_t[i], b = cv_b[i], h = cv_h[i];
+                {   // advance to the same slot of the next k tile
+                    int hh = h + inc_h;
+                    const int c1 = hh >= cd.Hr;
+                    hh -= c1 ? cd.Hr : 0;
+                    int bb = b + inc_b + c1;
+                    const int c2 = bb >= cd.B;
+                    bb -= c2 ? cd.B : 0;
+                    cv_h[i] = hh; cv_b[i] = bb; cv_t[i] = t + inc_t + c2;
+                }
+                const int ti = t + cv_dt[i], hi = h + cv_dh[i];
+                const bool ok = okb[i] && k0 + kb[i] < kend && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                src = ok ? B + (((size_t)ti * cd.B + b) * cd.Hs + hi) * cd.Cs + cv_ci[i] : zero;
+            } else {
+                src = (okb[i] && k0 + kb[i] < kend) ? gb[i] + (size_t)kt * TK * ldb : zero;
+            }
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+    };
+    // transposing reads: 16-lane group g = lane >> 4, lane 4 q + p of the group points at k row 4 g + q (second read: 16 + 4 g + q),
+    // columns 4 p .. 4 p + 3 of the 16-column tile (k slots permuted identically for A and B: see the 128 x 128 kernel)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int k0r = 4 * g + q, k1r = 16 + 4 * g + q;
+    const int sw0 = (k0r & 7) << 1;                                    // (k1r & 7 == k0r & 7: the second read is a constant 16 rows further)
+    (void)k1r;
+    int aoff0[8], boff0[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = wm * 16 + i * 2 + (pp >> 1);                     // 16-B chunk of columns wm*128 + i*16 + 4 pp ..
+        aoff0[i] = k0r * (T2M * 2) + ((c ^ sw0) << 4) + (pp & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = wn * 8 + j * 2 + (pp >> 1);
+        boff0[j] = k0r * (T2N * 2) + ((c ^ sw0) << 4) + (pp & 1) * 8;
+    }
+    constexpr int A16 = 16 * T2M * 2, B16 = 16 * T2N * 2;
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    issue_tile(0, 0);
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_tile(kt + 1, buf ^ 1);
+        const char* Ab = As + buf * A_STAGE;
+        const char* Bb = Bs + buf * B_STAGE;
+        Frag b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j].h[0] = lds_tr16(reinterpret_cast<const uint16_t*>(Bb + boff0[j]));
+            b[j].h[1] = lds_tr16(reinterpret_cast<const uint16_t*>(Bb + boff0[j] + B16));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            Frag a;
+            a.h[0] = lds_tr16(reinterpret_cast<const uint16_t*>(Ab + aoff0[i]));
+            a.h[1] = lds_tr16(reinterpret_cast<const uint16_t*>(Ab + aoff0[i] + A16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+        }
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = n0 + wn * 64 + j * 16 + (lane & 15);
+                if (gm < M && gn < N) atomicAdd(C + (size_t)gm * ldc + gn, acc[i][j][r]);
+            }
+}
+
 }  // namespace gemm
 }  // namespace asr
 
@@ -911,8 +1079,8 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
 
 // split K so that about 3 workgroups per CU are in flight: a multiple of 8 splits (one set per XCD) where K allows, each
 // split a multiple of the k tile
-static int tn_splits(int tiles, int K, int& k_per_split) {
-    int splits = cdiv(768, tiles);      // (3 workgroups per CU; 1024 was 5..17 % slower on the step's shapes, 512 hurt M = 3000)
+static int tn_splits(int tiles, int K, int& k_per_split, int target = 768) {
+    int splits = cdiv(target, tiles);   // (3 workgroups per CU; 1024 was 5..17 % slower on the step's shapes, 512 hurt M = 3000)
     splits = cdiv(splits, 8) * 8;
     const int max_splits = cdiv(K, 8 * TK);
     if (splits > max_splits) splits = max_splits;
@@ -921,11 +1089,35 @@ static int tn_splits(int tiles, int K, int& k_per_split) {
     return cdiv(K, k_per_split);
 }
 
+// the 256 x 128 LDS-DMA kernel wants whole 16-B chunks (M, lda, ldb multiples of 8, aligned bases) and at least one full tile
+// of rows; ASR_TN256=0 keeps the 128 x 128 kernel (tests, comparison)
+// Measured (tools/time_nt.py, TFLOP/s, 256 x 128 LDS-DMA kernel at two workgroups per CU against the 128 x 128 kernel at four):
+// convolution weight gradients 128->256: 668 / 638, 128->512: 783 / 745, 256->512: 823 / 737 -- but 3072 x 512 x 32000: 541 / 680,
+// 1536 x 512: 387 / 555 (half the workgroups in flight and twice the atomics per workgroup behind a K split of the same depth).
+// So it serves the implicit convolutions only; ASR_TN256=2 sends the plain products there as well (tests), 0 switches it off.
+static bool tn256_ok(int M, int lda, int ldb, const void* A, const void* B, bool conv) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_TN256"); on = e ? atoi(e) : 1; }
+    if (!on || (!conv && on != 2)) return false;
+    return M >= T2M && (M & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
+}
+
 extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M,
                                int N, int K) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
     if (lda < M || ldb < N || ldc < N) return ASR_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
+    if (tn256_ok(M, lda, ldb, A, B, false) && (N & 7) == 0) {
+        const int t2m = cdiv(M, T2M), t2n = cdiv(N, T2N);
+        int kps;
+        const int sp = tn_splits(t2m * t2n, K, kps);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TN2_LDS_BYTES); attr = true; }
+        hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(8 * t2m * t2n * cdiv(sp, 8)), dim3(256), TN2_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, t2n, kps, ConvDesc{});
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
@@ -944,10 +1136,21 @@ extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void
     if (ldg < Co || ldc < N) return ASR_ERR_BAD_ARG;
     if ((Cs & 7) || K > 0x7fffffffLL || (((uintptr_t)x) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
+    const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
+    if (tn256_ok(Co, ldg, 8, g, x, true)) {
+        const int t2m = cdiv(Co, T2M), t2n = cdiv(N, T2N);
+        int kps;
+        const int sp = tn_splits(t2m * t2n, (int)K, kps);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TN2_LDS_BYTES); attr = true; }
+        hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(8 * t2m * t2n * cdiv(sp, 8)), dim3(256), TN2_LDS_BYTES, stream,
+                           (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, t2n, kps, cd);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     const int tiles_m = cdiv(Co, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, (int)K, k_per_split);
-    const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
                        (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd);
     ASR_LAUNCH_CHECK();

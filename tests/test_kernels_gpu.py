@@ -607,3 +607,15 @@ def test_colsum_acc(device, rows, cols, dtype, ld):
     ref = 1.0 + full[:, :cols].double().sum(dim=0)
     tol = 2e-4 * float(full[:, :cols].abs().sum(dim=0).max())
     assert float((out.cpu().double() - ref).abs().max()) <= tol
+
+
+def test_tn256_kernel_in_a_forced_process():
+    """the 256 x 128 LDS-DMA TN kernel normally serves the convolution weight gradients with >= 256 output channels; ASR_TN256=2
+    (read once per process) routes the plain TN products of this file through it as well"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_TN256="2")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gemm_tn_acc or test_implicit_conv or test_gru_step_kernels"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
