@@ -454,6 +454,145 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256 x 128, persistent
+// The K = 512 / 1024 projections of the model spend half of a tile's life outside its K loop: 16 K steps of fill + MFMA between a
+// cold prologue (nothing to compute until the first stage lands) and an epilogue that moves 64 KB of results through LDS behind
+// eight workgroup barriers -- and the three workgroups of a CU, launched together with equal work, go through those phases together
+// (the same kernel reaches 1010 TFLOP/s at K = 8192 and 510-540 at K = 512).  Here a workgroup walks over its tiles (bid, bid + grid,
+// ...) in ONE software pipeline: the K loop runs across tile boundaries (stage 0 of the next tile is asked for during the last K step
+// of this one), and the epilogue goes from the accumulators straight to memory, without LDS (which by then belongs to the next tile)
+// and without a barrier.  Stores and LDS-DMA loads share vmcnt: the wait at the end of the next tile's first K step covers both.
+//
+// Register epilogue with whole-line stores.  A wave owns 64 rows x all 128 columns (4 x 8 MFMA tiles).  Column index c of MFMA tile j
+// stands for the ACTUAL column 8 c + j: the loader puts global row n0 + 8 (rho & 15) + (rho >> 4) of B at LDS row rho (an LDS-DMA lane
+// chooses its source freely), so the fragment reads are the plain ones, and lane (q, c) ends up with columns 8 c .. 8 c + 7 of rows
+// 4 q + reg: one 16-B bf16 store per row, 16 adjacent lanes = 256 contiguous bytes.  (What-if timings on 32000 x 3072 x 512: no stores
+// 0.106 ms, stores alone 0.073 ms when every lane wrote 8 B with the rows of a lane quad 6 KB apart: a request-rate bound.)
+template <typename OutT>
+__global__ __launch_bounds__(256, 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
+                                                             OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                             int K, int tiles_m, int tiles_n_signed, int total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = B2N * B2K * 2;
+    char* As = smem;
+    char* Bs = smem + 2 * A_STAGE;
+    auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
+    const int nk = K / B2K;
+    const int stride = gridDim.x;
+
+    // loader: slot sl = i * 256 + tid = (LDS row i * 64 + tid / 4, position tid % 4); the chunk it holds does not depend on i
+    const int lrow = tid >> 2, lchunk = ((tid & 3) ^ g4(lrow)) * 8;
+    unsigned oa[4], ob[2];                 // element offsets of this lane's rows in the tile being ISSUED
+    int it_tile = blockIdx.x, it_k = 0;
+    auto set_issue = [&](int t) {
+        int tm, tn;
+        tile_of(t, tiles_m, tiles_n_signed, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oa[i] = (unsigned)min(tm * B2M + i * 64 + lrow, M - 1) * (unsigned)lda + lchunk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rho = i * 64 + lrow;
+            ob[i] = (unsigned)min(tn * B2N + 8 * (rho & 15) + (rho >> 4), N - 1) * (unsigned)ldb + lchunk;
+        }
+    };
+    auto issue_next = [&](int buf) {
+        const int k0 = it_k * B2K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(A + oa[i] + k0), (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(B + ob[i] + k0), (lds_ptr_t)(Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        if (++it_k == nk) {
+            it_k = 0;
+            it_tile += stride;
+            if (it_tile < total) set_issue(it_tile);
+        }
+    };
+    // fragment addresses: row = (wave base) + i * 16 + r, and the swizzle key (row >> 2) & 3 does not depend on i: one register per
+    // operand, the tile index is an immediate offset of the ds_read
+    const int q = lane >> 4, r = lane & 15;
+    const int aoff0 = (wid * 64 + r) * 64 + ((q ^ g4(r)) << 4);
+    const int boff0 = r * 64 + ((q ^ g4(r)) << 4);
+    if (it_tile >= total) return;
+    set_issue(it_tile);
+    issue_next(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < total; tile += stride) {
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            if (it_tile < total) issue_next(buf ^ 1);
+            const char* Ab = As + buf * A_STAGE;
+            const char* Bb = Bs + buf * B_STAGE;
+            Frag a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i].u = *reinterpret_cast<const uint4*>(Ab + aoff0 + i * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                Frag b;
+                b.u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b.v, acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            buf ^= 1;
+        }
+        // epilogue: acc[i][j][reg] = C[m0 + wid * 64 + i * 16 + 4 q + reg][n0 + 8 r + j]
+        int tm, tn;
+        tile_of(tile, tiles_m, tiles_n_signed, tm, tn);
+        const int col = tn * B2N + 8 * r;
+        const int row0 = tm * B2M + wid * 64 + 4 * q;
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+        if (bias) {
+            if (col + 7 < N) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (col + j < N) bv[j] = bias[col + j];
+            }
+        }
+        OutT* d0 = C + (size_t)row0 * ldc + col;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                if (row0 + i * 16 + reg >= M) continue;
+                OutT* dst = d0 + (size_t)(i * 16 + reg) * ldc;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = acc[i][j][reg] + bv[j];
+                if (col + 7 < N) {
+                    if (sizeof(OutT) == 4) {
+                        reinterpret_cast<float4*>(dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
+                        reinterpret_cast<float4*>(dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
+                    } else {
+                        uint4 pk;
+                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+                        pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+                        *reinterpret_cast<uint4*>(dst) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (col + j < N) store_out<OutT>(dst + j, v[j]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the conversion temporaries of 16 rows from piling up
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ NT, 256 x 256 tile
 // The 256 x 128 kernel above is bound by operand fill, not by the matrix pipes (SQ counters on the model's projections:
 // waves parked on vmcnt / barriers half of their life, MFMA pipes 22 % busy): a 256 x 128 x 32 step moves 24 KB from L2
@@ -1048,6 +1187,29 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
             if (out_bf16) return launch_nt_wide<uint16_t, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
             return launch_nt_wide<float, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
         }
+    }
+    // persistent form of the 256 x 128 kernel: vector stores want ldc % 8 == 0 and an aligned C (bias: 16-B aligned), 32-bit element
+    // offsets want operands below 2^32 elements; ASR_NT_PERSIST=0 keeps the one-tile-per-workgroup kernel (tests, comparison)
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
+    if (persist && aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024 && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
+        (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 32) && (unsigned long long)N * ldb < (1ull << 32)) {
+        static bool attrp = false;
+        if (!attrp) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            attrp = true;
+        }
+        const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N), total = t2m * t2n;
+        const int grid = total < 768 * persist ? total : 768 * persist;      // three workgroups per CU; a multiple of 8 keeps bid % 8 = XCD for every tile of a workgroup
+        if (out_bf16)
+            hipLaunchKernelGGL(gemm_nt256p_kernel<uint16_t>, dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                               (uint16_t*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total);
+        else
+            hipLaunchKernelGGL(gemm_nt256p_kernel<float>, dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                               (float*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
     }
     if (aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024) {      // at least two rounds of 2 workgroups per CU
         static bool attr2 = false;

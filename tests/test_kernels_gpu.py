@@ -37,6 +37,23 @@ def test_gemm_nt(device, M, N, K, out_dtype):
     assert _rel(out2, a.double() @ b.double().T) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,bias_on", [(8000, 3072, 512, True), (7777, 3000, 320, True), (8192, 4100, 64, False), (5000, 6400, 96, True)])
+@pytest.mark.parametrize("out_dtype", [BF16, F32])
+def test_gemm_nt_many_tiles(device, M, N, K, bias_on, out_dtype):
+    """>= 1024 tiles of 256 x 128: the persistent kernel (several tiles per workgroup, K pipeline across tile boundaries, register
+    epilogue); ragged M, N not a multiple of the tile or of 16, one K step only"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g))
+    b = _bf(torch.randn(N, K, generator=g))
+    bias = torch.randn(N, generator=g) if bias_on else None
+    out = _ops.gemm_nt(a.to(device, BF16), b.to(device, BF16), None if bias is None else bias.to(device), out_dtype)
+    ref = torch.addmm(bias.to(device), a.to(device), b.to(device).T) if bias_on else a.to(device) @ b.to(device).T      # f32 on the GPU
+    tol = 2e-5 if out_dtype == F32 else 4e-3
+    assert _rel(out.float().cpu(), ref.cpu()) < tol
+    assert (out.float() - ref).abs().max().item() < (1e-3 if out_dtype == F32 else 0.02 * ref.abs().max().item())      # no stray tile
+
+
 def test_gemm_nt_asymmetric_identity(device):
     """A = I with an asymmetric B catches a transposed accumulator write (row/col swap)."""
     from asr import _ops
