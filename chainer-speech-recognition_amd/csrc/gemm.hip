@@ -454,6 +454,12 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
     }
 }
 
+// (a plain device function: called directly from a lambda of the kernel template, the builtin made the host pass drop the kernel's
+// stub without a diagnostic)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voffset, soffset, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ NT, 256 x 128, persistent
 // The K = 512 / 1024 projections of the model spend half of a tile's life outside its K loop: 16 K steps of fill + MFMA between a
 // cold prologue (nothing to compute until the first stage lands) and an epilogue that moves 64 KB of results through LDS behind
@@ -466,15 +472,25 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
 // Register epilogue with whole-line stores.  A wave owns 64 rows x all 128 columns (4 x 8 MFMA tiles).  Column index c of MFMA tile j
 // stands for the ACTUAL column 8 c + j: the loader puts global row n0 + 8 (rho & 15) + (rho >> 4) of B at LDS row rho (an LDS-DMA lane
 // chooses its source freely), so the fragment reads are the plain ones, and lane (q, c) ends up with columns 8 c .. 8 c + 7 of rows
-// 4 q + reg: one 16-B bf16 store per row, 16 adjacent lanes = 256 contiguous bytes.  (What-if timings on 32000 x 3072 x 512: no stores
+// 4 q + reg: one 16-B bf16 store per row, 16 adjacent lanes = 256 contiguous bytes (f32: runs of four columns, two stores).  (What-if timings on 32000 x 3072 x 512: no stores
 // 0.106 ms, stores alone 0.073 ms when every lane wrote 8 B with the rows of a lane quad 6 KB apart: a request-rate bound.)
-template <typename OutT>
-__global__ __launch_bounds__(256, 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
-                                                             OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
-                                                             int K, int tiles_m, int tiles_n_signed, int total) {
+// CONV: operand A is the activation tensor of an implicit convolution (ConvDesc; Cs % 32 == 0, so a K step lies inside one tap
+// and the tap walk is scalar state of the issuing side); a row outside the tensor or an empty tap gets a voffset beyond the
+// buffer's num_records -- the buffer load then writes zeros, no zero page and no select between pointers.
+// NJ: column tiles per wave = tile width / 16: 8 -> 256 x 128, 4 -> 256 x 64 (N <= 64: no MFMA work on columns that do not exist).
+template <typename OutT, bool CONV, int NJ>
+__global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
+                                                                       int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                                                       int M, int N, int K, int tiles_m, int tiles_n_signed, int total,
+                                                                       unsigned a_bytes, ConvDesc cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = B2N * B2K * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int TNW = 16 * NJ;                                        // tile width
+    constexpr int A_STAGE = B2M * B2K * 2, B_STAGE = TNW * B2K * 2;
+    constexpr int BP = NJ / 4;                                          // LDS-DMA pieces of the B tile per thread
+    // a lane's run of consecutive columns: 16 B of the output type (f32: two runs of four, 64 columns apart, so that the 16 lanes
+    // of a row still write 256 contiguous bytes per store)
+    constexpr int G = (sizeof(OutT) == 4 && NJ == 8) ? 4 : NJ;
     char* As = smem;
     char* Bs = smem + 2 * A_STAGE;
     auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
@@ -482,28 +498,58 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256p_kernel(const uint16_t* __r
     const int stride = gridDim.x;
 
     // loader: slot sl = i * 256 + tid = (LDS row i * 64 + tid / 4, position tid % 4); the chunk it holds does not depend on i
-    const int lrow = tid >> 2, lchunk = ((tid & 3) ^ g4(lrow)) * 8;
-    unsigned oa[4], ob[2];                 // element offsets of this lane's rows in the tile being ISSUED
+    const int lrow = tid >> 2, lchunk = ((tid & 3) ^ g4(lrow)) * 16;
+    unsigned oa[4], ob[BP];                // BYTE offsets of this lane's rows in the tile being ISSUED (uniform base + 32-bit lane offset)
+    int cth[4];                            // CONV: (t << 8) | h of the row; rows beyond M get a t far below zero
     int it_tile = blockIdx.x, it_k = 0;
+    int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // CONV: tap of the next K step to issue
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
     auto set_issue = [&](int t) {
         int tm, tn;
         tile_of(t, tiles_m, tiles_n_signed, tm, tn);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) oa[i] = (unsigned)min(tm * B2M + i * 64 + lrow, M - 1) * (unsigned)lda + lchunk;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rho = i * 64 + lrow;
-            ob[i] = (unsigned)min(tn * B2N + 8 * (rho & 15) + (rho >> 4), N - 1) * (unsigned)ldb + lchunk;
+        for (int i = 0; i < 4; ++i) {
+            if (CONV) {
+                const int rr = tm * B2M + i * 64 + lrow;
+                const int rc = rr < M ? rr : 0;
+                const int h = rc % cd.Hr, tb = rc / cd.Hr, b = tb % cd.B, t0 = rr < M ? tb / cd.B : -(1 << 20);
+                cth[i] = t0 * 256 + h;
+                oa[i] = (unsigned)(((tb / cd.B) * cd.B + b) * cd.Hs + h) * (unsigned)(cd.Cs * 2) + lchunk;
+            } else {
+                oa[i] = __umul24((unsigned)min(tm * B2M + i * 64 + lrow, M - 1), (unsigned)(lda * 2)) + lchunk;      // (24-bit factors: a 32-bit multiply-add, no 64-bit pair)
+            }
         }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            const int rho = i * 64 + lrow;
+            const int jj = rho >> 4;                                     // LDS row 16 j + c holds column (j / G) 16 G + G c + j % G
+            ob[i] = __umul24((unsigned)min(tn * TNW + (jj / G) * (16 * G) + G * (rho & 15) + (jj % G), N - 1), (unsigned)(ldb * 2)) + lchunk;
+        }
+        tw_kh = tw_kw = tw_ci = 0;
     };
     auto issue_next = [&](int buf) {
-        const int k0 = it_k * B2K;
+        const int koff = it_k * (B2K * 2);      // scalar offset of the buffer instruction: no per-lane address arithmetic at all
+        if (CONV) {
+            const int dt = cd.sgn * (tw_kw - cd.pt), dh = cd.sgn * (tw_kh - cd.ph);
+            const int delta = ((dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci) * 2;
+            const bool tap_ok = tw_kh < cd.KH;                        // (K may be padded with empty taps)
+            tw_ci += B2K;
+            if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(A + oa[i] + k0), (lds_ptr_t)(As + buf * A_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                const int ti = (cth[i] >> 8) + dt, hi = (cth[i] & 255) + dh;
+                const bool ok = tap_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                lds_dma16(rsrc_a, As + buf * A_STAGE + (i * 256 + wid * 64) * 16, ok ? oa[i] + delta : 0xfffffff0u, 0);
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(B + ob[i] + k0), (lds_ptr_t)(Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16), 16, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                lds_dma16(rsrc_a, As + buf * A_STAGE + (i * 256 + wid * 64) * 16, oa[i], koff);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            lds_dma16(rsrc_b, Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16, ob[i], koff);
         if (++it_k == nk) {
             it_k = 0;
             it_tile += stride;
@@ -521,45 +567,46 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256p_kernel(const uint16_t* __r
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int buf = 0;
     for (int tile = blockIdx.x; tile < total; tile += stride) {
-        f32x4 acc[4][8];
+        f32x4 acc[4][NJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
             if (it_tile < total) issue_next(buf ^ 1);
             const char* Ab = As + buf * A_STAGE;
             const char* Bb = Bs + buf * B_STAGE;
-            Frag a[4];
+            // B fragment j + 1 is read BEFORE the four MFMAs of fragment j are issued (the sched_group_barriers pin that order: left
+            // alone, the register-starved schedule reuses one fragment register and every read waits out its full LDS latency)
+            Frag a[4], b[2];
+            b[0].u = *reinterpret_cast<const uint4*>(Bb + boff0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i].u = *reinterpret_cast<const uint4*>(Ab + aoff0 + i * 1024);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                Frag b;
-                b.u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) b[(j + 1) & 1].u = *reinterpret_cast<const uint4*>(Bb + boff0 + (j + 1) * 1024);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b.v, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j & 1].v, acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // b0, a0..a3, b1
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (j + 2 < NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             buf ^= 1;
         }
-        // epilogue: acc[i][j][reg] = C[m0 + wid * 64 + i * 16 + 4 q + reg][n0 + 8 r + j]
+        // epilogue: acc[i][j][reg] = C[m0 + wid * 64 + i * 16 + 4 q + reg][n0 + (j / G) 16 G + G r + j % G]
         int tm, tn;
         tile_of(tile, tiles_m, tiles_n_signed, tm, tn);
-        const int col = tn * B2N + 8 * r;
+        const int col = tn * TNW + G * r;
         const int row0 = tm * B2M + wid * 64 + 4 * q;
-        float bv[8];
+        float bv[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-        if (bias) {
-            if (col + 7 < N) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
-                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (col + j < N) bv[j] = bias[col + j];
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int cj = col + (j / G) * (16 * G) + (j % G);
+            bv[j] = (bias && cj < N) ? bias[cj] : 0.f;
         }
         OutT* d0 = C + (size_t)row0 * ldc + col;
 #pragma unroll
@@ -568,25 +615,33 @@ __global__ __launch_bounds__(256, 3) void gemm_nt256p_kernel(const uint16_t* __r
             for (int reg = 0; reg < 4; ++reg) {
                 if (row0 + i * 16 + reg >= M) continue;
                 OutT* dst = d0 + (size_t)(i * 16 + reg) * ldc;
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = acc[i][j][reg] + bv[j];
-                if (col + 7 < N) {
-                    if (sizeof(OutT) == 4) {
-                        reinterpret_cast<float4*>(dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
-                        reinterpret_cast<float4*>(dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
+                for (int g = 0; g < NJ / G; ++g) {
+                    float v[G];
+#pragma unroll
+                    for (int j = 0; j < G; ++j) v[j] = acc[i][g * G + j][reg] + bv[g * G + j];
+                    const int cg = col + g * (16 * G);
+                    if (cg + G - 1 < N) {
+                        if (sizeof(OutT) == 4) {
+                            *reinterpret_cast<float4*>(dst + g * (16 * G)) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else if (G == 8) {
+                            uint4 pk;
+                            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                            pk.z = (uint32_t)f32_to_bf16(v[G == 8 ? 4 : 0]) | ((uint32_t)f32_to_bf16(v[G == 8 ? 5 : 0]) << 16);
+                            pk.w = (uint32_t)f32_to_bf16(v[G == 8 ? 6 : 0]) | ((uint32_t)f32_to_bf16(v[G == 8 ? 7 : 0]) << 16);
+                            *reinterpret_cast<uint4*>(dst) = pk;
+                        } else {
+                            uint2 pk;
+                            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                            *reinterpret_cast<uint2*>(dst) = pk;
+                        }
                     } else {
-                        uint4 pk;
-                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        pk.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-                        pk.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-                        *reinterpret_cast<uint4*>(dst) = pk;
-                    }
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (col + j < N) store_out<OutT>(dst + j, v[j]);
+                        for (int j = 0; j < G; ++j)
+                            if (cg + j < N) store_out<OutT>(dst + g * (16 * G) + j, v[j]);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the conversion temporaries of 16 rows from piling up
             }
@@ -1165,6 +1220,24 @@ static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const 
     return ASR_OK;
 }
 
+// Grid of the persistent kernels: a multiple of 256 workgroups (whole CUs; a multiple of 8 keeps bid % 8 = XCD for every tile a
+// workgroup walks over), chosen for the fewest rounds x the time of a tile when k workgroups share a CU (measured on 8192^3 and
+// 32000 x 1024 x 3072: a tile takes ~0.87 of the three-per-CU time at two per CU; one per CU leaves the fill latency bare).
+// ASR_NT_PERSIST_GRID overrides (experiments).
+static int nt_persist_grid(int total, int max_per_cu) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("ASR_NT_PERSIST_GRID"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) return total < forced ? total : forced;
+    const float tile_time[4] = {0.f, 0.80f, 0.87f, 1.0f};
+    int best = 256 * max_per_cu;
+    float best_cost = 1e30f;
+    for (int k = max_per_cu; k >= 2; --k) {
+        const float cost = (float)cdiv(total, 256 * k) * tile_time[k];
+        if (cost < best_cost - 1e-6f) { best_cost = cost; best = 256 * k; }
+    }
+    return total < best ? total : best;
+}
+
 extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                            const float* bias, int M, int N, int K, int out_bf16) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
@@ -1188,26 +1261,29 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
             return launch_nt_wide<float, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);
         }
     }
-    // persistent form of the 256 x 128 kernel: vector stores want ldc % 8 == 0 and an aligned C (bias: 16-B aligned), 32-bit element
-    // offsets want operands below 2^32 elements; ASR_NT_PERSIST=0 keeps the one-tile-per-workgroup kernel (tests, comparison)
+    // persistent form of the 256 x 128 kernel: vector stores want ldc % 8 == 0 and an aligned C (bias: 16-B aligned), 32-bit byte
+    // offsets want operands below 4 GB; ASR_NT_PERSIST=0 keeps the one-tile-per-workgroup kernel (tests, comparison)
     static int persist = -1;
     if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
-    if (persist && aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= 1024 && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
-        (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 32) && (unsigned long long)N * ldb < (1ull << 32)) {
+    static int pmin = -1;
+    if (pmin < 0) { const char* e = getenv("ASR_NT_PERSIST_MIN"); pmin = e ? atoi(e) : 400; }
+    if (persist && aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= pmin && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
+        (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldb < (1ull << 31) && M < (1 << 24) && N < (1 << 24) &&
+        lda < (1 << 23) && ldb < (1 << 23)) {
         static bool attrp = false;
         if (!attrp) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
             attrp = true;
         }
         const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N), total = t2m * t2n;
-        const int grid = total < 768 * persist ? total : 768 * persist;      // three workgroups per CU; a multiple of 8 keeps bid % 8 = XCD for every tile of a workgroup
+        const int grid = nt_persist_grid(total, 3);
         if (out_bf16)
-            hipLaunchKernelGGL(gemm_nt256p_kernel<uint16_t>, dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
-                               (uint16_t*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total);
+            hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, false, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                               (uint16_t*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
         else
-            hipLaunchKernelGGL(gemm_nt256p_kernel<float>, dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
-                               (float*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total);
+            hipLaunchKernelGGL((gemm_nt256p_kernel<float, false, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                               (float*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
         ASR_LAUNCH_CHECK();
         return ASR_OK;
     }
@@ -1351,6 +1427,32 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     const int t2m = cdiv((int)M, B2M), t2n = cdiv(N, narrow ? 64 : B2N);
     const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;
     const int tn_arg = b_fits_l2 ? -t2n : t2n;
+    // persistent form (K pipeline across tiles, register epilogue): channels a multiple of the K step, whole 16-B stores
+    {
+        static int persist = -1;
+        if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
+        const unsigned long long xbytes = (unsigned long long)Ts * B * Hs * Cs * 2;
+        if (persist && (Cs % B2K) == 0 && (N % 8) == 0 && Hs < 256 && xbytes < 0xfffffff0ull && (((uintptr_t)out) & 15) == 0 &&
+            (!bias || (((uintptr_t)bias) & 15) == 0) && (long long)t2m * t2n >= 400 && N < (1 << 24) && K < (1 << 23)) {
+            static bool attrc = false;
+            if (!attrc) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                attrc = true;
+            }
+            const int total = t2m * t2n, grid = nt_persist_grid(total, 2);
+#define ASR_CONVP(T, NJ_, CT)                                                                                              \
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, true, NJ_>), dim3(grid), dim3(256), 2 * (B2M + 16 * NJ_) * B2K * 2, stream, (const uint16_t*)x, 0, \
+                       (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, t2m, tn_arg, total, (unsigned)xbytes, cd)
+            if (out_bf16) { if (narrow) ASR_CONVP(uint16_t, 4, uint16_t); else ASR_CONVP(uint16_t, 8, uint16_t); }
+            else          { if (narrow) ASR_CONVP(float, 4, float); else ASR_CONVP(float, 8, float); }
+#undef ASR_CONVP
+            ASR_LAUNCH_CHECK();
+            return ASR_OK;
+        }
+    }
 #define ASR_CONV(T, W_, CT)                                                                                               \
     hipLaunchKernelGGL((gemm_nt256_kernel<T, true, W_>), dim3(t2m * t2n), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)x, 0, \
                        (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, tn_arg, cd)

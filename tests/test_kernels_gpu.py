@@ -495,7 +495,9 @@ def test_non_finite_step_is_skipped(device):
                                                           (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
                                                           # > 128 output (or, for backward-data, input) channels: 256 x 256 tiles
                                                           (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),
-                                                          (12, 2, 6, 256, 64, 3, 5, 1, True)])
+                                                          (12, 2, 6, 256, 64, 3, 5, 1, True),
+                                                          # >= 400 tiles of 256 rows: the persistent kernels (128- and 64-wide)
+                                                          (600, 16, 13, 64, 128, 3, 5, 0, True), (600, 16, 13, 32, 64, 3, 5, 1, True)])
 def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
     """asr_conv_nt (no column matrix) against the im2col + GEMM path it replaces, forward and backward-data: the same
     products in the same bf16 operands, so they agree to accumulation order"""
