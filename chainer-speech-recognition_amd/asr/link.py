@@ -97,13 +97,15 @@ class Link(torch.nn.Module):
 
 
 def _made_copy(stamp, value):
-    """cache entry (stamp, value, event, streams that have it): a copy made on one stream may be wanted on another one
-    (asr/pipeline.py runs two half batches on two streams)"""
+    """cache entry (stamp, value, origin, streams that have it): a copy made on one stream may be wanted on another one
+    (asr/pipeline.py runs two half batches on two streams).  No event is recorded when the copy is made -- every record is a
+    marker packet the GPU spends 2-3 us on, forty of them behind the optimiser's refresh launch were a 115 us hole at the
+    start of each step -- but only when a second stream first asks for the copy: an event recorded THEN on the stream of
+    origin still lies behind the launch that made the copy."""
     if not value.is_cuda:
         return (stamp, value, None, None)
-    ev = torch.cuda.Event()
-    ev.record()
-    return (stamp, value, ev, {torch.cuda.current_stream().cuda_stream})
+    cur = torch.cuda.current_stream()
+    return (stamp, value, {"stream": cur, "event": None}, {cur.cuda_stream})
 
 
 def _await_copy(entry):
@@ -111,7 +113,11 @@ def _await_copy(entry):
         return
     cur = torch.cuda.current_stream()
     if cur.cuda_stream not in entry[3]:
-        cur.wait_event(entry[2])
+        origin = entry[2]
+        if origin["event"] is None:
+            origin["event"] = torch.cuda.Event()
+            origin["event"].record(origin["stream"])
+        cur.wait_event(origin["event"])
         entry[1].record_stream(cur)
         entry[3].add(cur.cuda_stream)
 

@@ -478,7 +478,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 // and the tap walk is scalar state of the issuing side); a row outside the tensor or an empty tap gets a voffset beyond the
 // buffer's num_records -- the buffer load then writes zeros, no zero page and no select between pointers.
 // NJ: column tiles per wave = tile width / 16: 8 -> 256 x 128, 4 -> 256 x 64 (N <= 64: no MFMA work on columns that do not exist).
-template <typename OutT, bool CONV, int NJ>
+template <typename OutT, int CONV, int NJ>
 __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
                                                                        int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                                        int M, int N, int K, int tiles_m, int tiles_n_signed, int total,
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
     unsigned oa[4], ob[BP];                // BYTE offsets of this lane's rows in the tile being ISSUED (uniform base + 32-bit lane offset)
     int cth[4];                            // CONV: (t << 8) | h of the row; rows beyond M get a t far below zero
     int it_tile = blockIdx.x, it_k = 0;
-    int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // CONV: tap of the next K step to issue
+    int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // CONV: tap of the next K step to issue (CONV == 2: of this lane's chunk of that step)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
     auto set_issue = [&](int t) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
                 const int rc = rr < M ? rr : 0;
                 const int h = rc % cd.Hr, tb = rc / cd.Hr, b = tb % cd.B, t0 = rr < M ? tb / cd.B : -(1 << 20);
                 cth[i] = t0 * 256 + h;
-                oa[i] = (unsigned)(((tb / cd.B) * cd.B + b) * cd.Hs + h) * (unsigned)(cd.Cs * 2) + lchunk;
+                oa[i] = (unsigned)(((tb / cd.B) * cd.B + b) * cd.Hs + h) * (unsigned)(cd.Cs * 2) + (CONV == 2 ? 0 : lchunk);
             } else {
                 oa[i] = __umul24((unsigned)min(tm * B2M + i * 64 + lrow, M - 1), (unsigned)(lda * 2)) + lchunk;      // (24-bit factors: a 32-bit multiply-add, no 64-bit pair)
             }
@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
             ob[i] = __umul24((unsigned)min(tn * TNW + (jj / G) * (16 * G) + G * (rho & 15) + (jj % G), N - 1), (unsigned)(ldb * 2)) + lchunk;
         }
         tw_kh = tw_kw = tw_ci = 0;
+        if (CONV == 2) { const int c = lchunk >> 4; tw_kh = c / cd.KW; tw_kw = c - tw_kh * cd.KW; }
     };
     auto issue_next = [&](int buf) {
         const int koff = it_k * (B2K * 2);      // scalar offset of the buffer instruction: no per-lane address arithmetic at all
@@ -534,8 +535,13 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
             const int dt = cd.sgn * (tw_kw - cd.pt), dh = cd.sgn * (tw_kh - cd.ph);
             const int delta = ((dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci) * 2;
             const bool tap_ok = tw_kh < cd.KH;                        // (K may be padded with empty taps)
-            tw_ci += B2K;
-            if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } }
+            if (CONV == 2) {                                          // this lane's chunk moves on by the four taps of a K step
+                tw_kw += 4;
+                while (tw_kw >= cd.KW) { tw_kw -= cd.KW; ++tw_kh; }
+            } else {
+                tw_ci += B2K;
+                if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ti = (cth[i] >> 8) + dt, hi = (cth[i] & 255) + dh;
@@ -1272,17 +1278,17 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         lda < (1 << 23) && ldb < (1 << 23)) {
         static bool attrp = false;
         if (!attrp) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
             attrp = true;
         }
         const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N), total = t2m * t2n;
         const int grid = nt_persist_grid(total, 3);
         if (out_bf16)
-            hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, false, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+            hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, 0, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
                                (uint16_t*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
         else
-            hipLaunchKernelGGL((gemm_nt256p_kernel<float, false, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+            hipLaunchKernelGGL((gemm_nt256p_kernel<float, 0, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
                                (float*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
         ASR_LAUNCH_CHECK();
         return ASR_OK;
@@ -1432,22 +1438,32 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
         static int persist = -1;
         if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
         const unsigned long long xbytes = (unsigned long long)Ts * B * Hs * Cs * 2;
-        if (persist && (Cs % B2K) == 0 && (N % 8) == 0 && Hs < 256 && xbytes < 0xfffffff0ull && (((uintptr_t)out) & 15) == 0 &&
+        const int cmode = (Cs % B2K) == 0 ? 1 : (Cs == 8 ? 2 : 0);
+        if (persist && cmode && (N % 8) == 0 && Hs < 256 && xbytes < 0xfffffff0ull && (((uintptr_t)out) & 15) == 0 &&
             (!bias || (((uintptr_t)bias) & 15) == 0) && (long long)t2m * t2n >= 400 && N < (1 << 24) && K < (1 << 23)) {
             static bool attrc = false;
             if (!attrc) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
                 attrc = true;
             }
             const int total = t2m * t2n, grid = nt_persist_grid(total, 2);
-#define ASR_CONVP(T, NJ_, CT)                                                                                              \
-    hipLaunchKernelGGL((gemm_nt256p_kernel<T, true, NJ_>), dim3(grid), dim3(256), 2 * (B2M + 16 * NJ_) * B2K * 2, stream, (const uint16_t*)x, 0, \
+#define ASR_CONVP(T, C_, NJ_, CT)                                                                                          \
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, C_, NJ_>), dim3(grid), dim3(256), 2 * (B2M + 16 * NJ_) * B2K * 2, stream, (const uint16_t*)x, 0, \
                        (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, t2m, tn_arg, total, (unsigned)xbytes, cd)
-            if (out_bf16) { if (narrow) ASR_CONVP(uint16_t, 4, uint16_t); else ASR_CONVP(uint16_t, 8, uint16_t); }
-            else          { if (narrow) ASR_CONVP(float, 4, float); else ASR_CONVP(float, 8, float); }
+            if (cmode == 1) {
+                if (out_bf16) { if (narrow) ASR_CONVP(uint16_t, 1, 4, uint16_t); else ASR_CONVP(uint16_t, 1, 8, uint16_t); }
+                else          { if (narrow) ASR_CONVP(float, 1, 4, float); else ASR_CONVP(float, 1, 8, float); }
+            } else {
+                if (out_bf16) { if (narrow) ASR_CONVP(uint16_t, 2, 4, uint16_t); else ASR_CONVP(uint16_t, 2, 8, uint16_t); }
+                else          { if (narrow) ASR_CONVP(float, 2, 4, float); else ASR_CONVP(float, 2, 8, float); }
+            }
 #undef ASR_CONVP
             ASR_LAUNCH_CHECK();
             return ASR_OK;

@@ -497,7 +497,9 @@ def test_non_finite_step_is_skipped(device):
                                                           (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),
                                                           (12, 2, 6, 256, 64, 3, 5, 1, True),
                                                           # >= 400 tiles of 256 rows: the persistent kernels (128- and 64-wide)
-                                                          (600, 16, 13, 64, 128, 3, 5, 0, True), (600, 16, 13, 32, 64, 3, 5, 1, True)])
+                                                          (600, 16, 13, 64, 128, 3, 5, 0, True), (600, 16, 13, 32, 64, 3, 5, 1, True),
+                                                          # 8 input channels (a padded first layer): one tap per 16-B chunk
+                                                          (600, 16, 13, 8, 128, 3, 5, 0, True), (500, 16, 20, 8, 64, 3, 3, 1, False)])
 def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
     """asr_conv_nt (no column matrix) against the im2col + GEMM path it replaces, forward and backward-data: the same
     products in the same bf16 operands, so they agree to accumulation order"""
@@ -512,9 +514,10 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     w16 = _ops.conv_weight_pack(W)
     col = _ops.im2col(x, (x.stride(0), x.stride(1), x.stride(2), x.stride(3)), T, B, Hin, Ci, KH, KW, ph, pt, Tout)
     ref = _ops.gemm_nt(col, w16, bias, torch.float32)
-    got = _ops.conv_nt(x, w16, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
+    w16c = w16 if (KH * KW * Ci) % 32 == 0 else _ops.conv_weight_pack(W, Kp=(KH * KW * Ci + 31) // 32 * 32)      # K step of the kernels
+    got = _ops.conv_nt(x, w16c, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
     assert _rel(got.cpu(), ref.cpu()) < 1e-5
-    got16 = _ops.conv_nt(x, w16, bias, torch.bfloat16, KH, KW, ph, pt, +1, Tout, Hout)
+    got16 = _ops.conv_nt(x, w16c, bias, torch.bfloat16, KH, KW, ph, pt, +1, Tout, Hout)
     assert _rel(got16.float().cpu(), ref.cpu()) < 1e-2
     # backward-data: dx = col2im(gy . W)
     gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(torch.bfloat16)
