@@ -65,6 +65,8 @@ SIGNATURES = {
     "asr_maxout2_bwd": (c_int, [c_void_p] * 4 + [c_longlong]),
     "asr_maxout2_pool_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
     "asr_maxout2_pool_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int, c_int, c_int]),
+    "asr_maxout2_pool_bwd_db": (c_int, [c_void_p] * 5 + [c_longlong, c_int, c_int, c_int]),
+    "asr_maxout2_pool_bwd_db_ok": (c_int, [c_int]),
     "asr_maxpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
     "asr_maxpool_h_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int, c_int, c_int]),
     "asr_add_bf16": (c_int, [c_void_p] * 4 + [c_longlong]),

@@ -195,11 +195,19 @@ def maxout2_pool_fwd(x, k):
     return y
 
 
-def maxout2_pool_bwd(x, dy, k):
+def maxout2_pool_bwd(x, dy, k, db=None):
+    """dx of maxout(2) + max pooling over (k, 1); db (2 C floats, optional) += column sums of dx (bias gradient of the producer)"""
     T, B, H, C2 = x.shape
     dx = torch.empty_like(x)
-    check(_lib.lib().asr_maxout2_pool_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), T * B, H, C2 // 2, k), "asr_maxout2_pool_bwd")
+    if db is not None:
+        assert db.dtype == F32 and db.numel() == C2 and db.is_contiguous()
+    check(_lib.lib().asr_maxout2_pool_bwd_db(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), ptr(db), T * B, H, C2 // 2, k),
+          "asr_maxout2_pool_bwd_db")
     return dx
+
+
+def maxout2_pool_bwd_db_ok(C):
+    return bool(_lib.lib().asr_maxout2_pool_bwd_db_ok(int(C)))
 
 
 def maxpool_h_fwd(x, k):

@@ -96,6 +96,16 @@ class _GradMailbox(object):
         return v
 
 
+class _BiasBox(object):
+    """hung on a convolution's graph node: the consumer that forms the WHOLE gradient of the convolution's output (the fused
+    maxout + pooling backward, when the layer stack guarantees it is the only consumer) adds its column sums to the bias gradient
+    in the same pass and says so here"""
+    __slots__ = ("ptr", "numel", "bias", "bias_done")
+
+    def __init__(self, y, bias):
+        self.ptr, self.numel, self.bias, self.bias_done = y.data_ptr(), y.numel(), bias, False
+
+
 _ZERO = {}
 _VIEW_NODES = ("ViewBackward", "ReshapeAliasBackward", "UnsafeViewBackward", "PermuteBackward", "TransposeBackward",
                "SqueezeBackward", "UnsqueezeBackward", "AliasBackward")
@@ -113,9 +123,9 @@ def _is_zero_token(t):
     return z is not None and t.data_ptr() == z.data_ptr()
 
 
-def _producer_box(x2, attr="_asr_mailbox", hops=12):
+def _producer_box(x2, attr="_asr_mailbox", hops=12, dtype=F32):
     """the box (attribute `attr`) of the node that produced the buffer `x2` is a contiguous re-view of, or None"""
-    if x2.dtype != F32 or not x2.is_contiguous():
+    if x2.dtype != dtype or not x2.is_contiguous():
         return None
     node = x2.grad_fn
     for _ in range(hops):
@@ -271,6 +281,7 @@ class _Conv2D(torch.autograd.Function):
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, False, 2)
             if out_f32:
                 ctx._asr_mailbox = _GradMailbox(y, b)
+            ctx._asr_biasbox = _BiasBox(y, b)
             return y.reshape(Tout, B, Hout, Co)
         # implicit GEMM (asr_conv_nt): no column matrix when the input is already physical bf16 and every 16-B chunk of a
         # virtual im2col row stays inside one tap
@@ -284,6 +295,7 @@ class _Conv2D(torch.autograd.Function):
             ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, False, x.dtype, ctx.needs_input_grad[0], True)
             if out_f32:
                 ctx._asr_mailbox = _GradMailbox(y, b)
+            ctx._asr_biasbox = _BiasBox(y, b)
             return y.reshape(Tout, B, Hout, Co)
         if pointwise:
             xp = x.permute(3, 0, 2, 1)
@@ -301,6 +313,7 @@ class _Conv2D(torch.autograd.Function):
         ctx.meta = (B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, x.dtype, ctx.needs_input_grad[0], False)
         if out_f32:
             ctx._asr_mailbox = _GradMailbox(y)
+        ctx._asr_biasbox = _BiasBox(y, b)
         return y.reshape(Tout, B, Hout, Co)
 
     @staticmethod
@@ -308,7 +321,10 @@ class _Conv2D(torch.autograd.Function):
         col, w16t, wbwd = ctx.saved_tensors
         W, b = ctx.params
         B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx, implicit = ctx.meta
-        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False)
+        bbox = getattr(ctx, "_asr_biasbox", None)
+        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False) or (bbox is not None and bbox.bias_done)
+        if bbox is not None:
+            bbox.bias_done = False          # consumed: a second backward pass over the same graph starts afresh
         gy = _incoming_bf16(ctx, gy, Co)
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
@@ -496,24 +512,35 @@ class _MaxPoolH(torch.autograd.Function):
 
 class _Maxout2PoolH(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, k):
+    def forward(ctx, p, k, sole):
         ctx.save_for_backward(p)
         ctx.k = k
+        # the only consumer of a convolution's output: its backward pass forms that output's whole gradient, so the bias gradient
+        # (the column sums) comes out of the same pass
+        box = _producer_box(p, "_asr_biasbox", 12, BF16) if sole else None
+        if box is not None and not (isinstance(box.bias, torch.nn.Parameter) and box.bias.numel() == p.shape[3]
+                                    and _ops.maxout2_pool_bwd_db_ok(p.shape[3] // 2)):
+            box = None
+        ctx.biasbox = box
         return _ops.maxout2_pool_fwd(p, k)
 
     @staticmethod
     def backward(ctx, gy):
         (p,) = ctx.saved_tensors
-        return _ops.maxout2_pool_bwd(p, gy.contiguous(), ctx.k), None
+        db = None
+        if ctx.biasbox is not None and not ctx.biasbox.bias_done:
+            db = grad_buffer(ctx.biasbox.bias).reshape(-1)
+            ctx.biasbox.bias_done = True
+        return _ops.maxout2_pool_bwd(p, gy.contiguous(), ctx.k, db), None, None
 
 
-def maxout_max_pooling(x, k):
+def maxout_max_pooling(x, k, sole_consumer=False):
     """maxout(x, 2) followed by max_pooling_2d(., (k, 1)) -- the tail of every conv block of the recipes -- as one pass
     over the convolution output (asr.nn containers use it when the two layers follow each other); falls back to the two
     functions when the layout does not allow the fused kernels."""
     p = phys4(x)
     if _ops.maxout2_pool_ok(p):
-        return logical4(_Maxout2PoolH.apply(p, int(k)))
+        return logical4(_Maxout2PoolH.apply(p, int(k), bool(sole_consumer)))
     return max_pooling_2d(maxout(x, 2), (k, 1))
 
 

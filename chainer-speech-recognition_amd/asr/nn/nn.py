@@ -228,7 +228,9 @@ def _apply_layers(layers, x):
         j = _fusable_pool(layers, i) if x.dim() == 4 else -1
         if j > 0:
             ks = layers[j].ksize
-            x = functions.maxout_max_pooling(x, ks[0] if isinstance(ks, (tuple, list)) else ks)
+            # x was produced by the previous layer of THIS sequence and nothing else holds it: the fused backward may take over
+            # the bias gradient of a convolution in front (functions._BiasBox)
+            x = functions.maxout_max_pooling(x, ks[0] if isinstance(ks, (tuple, list)) else ks, sole_consumer=i > 0)
             i = j + 1
             continue
         y = layer(x)

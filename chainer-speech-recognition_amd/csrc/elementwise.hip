@@ -596,10 +596,18 @@ __global__ void maxout2_pool_fwd_kernel(const uint16_t* __restrict__ x, uint16_t
         *reinterpret_cast<uint4*>(y + ((r * Hout + ho) * C + c8 * 8)) = o;
     }
 }
+// db (optional, 2 C floats, accumulated): column sums of dx = the bias gradient of the convolution in front.  dx is a scatter of dy
+// (every element goes to one of the 2 k inputs of its window), so the sums come from dy and the winners' channel bits while both are
+// in registers -- the separate column-sum pass read all of dx again (311 MB for the first block of the BASELINE model).  Needs
+// 256 % (C / 8) == 0: then a thread meets the same eight channel pairs in every round of its grid-stride loop.
 __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
-                                        uint16_t* __restrict__ dx, long long R, int Hin, int Hout, int C, int k) {
+                                        uint16_t* __restrict__ dx, float* __restrict__ db, long long R, int Hin, int Hout, int C, int k) {
+    __shared__ float red[256 * 16];
     const int c8n = C >> 3;
     const long long n = R * Hout * c8n;
+    float bsum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bsum[e] = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int c8 = (int)(i % c8n);
         const int ho = (int)((i / c8n) % Hout);
@@ -624,6 +632,14 @@ __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const ui
         }
         const uint4 g = *reinterpret_cast<const uint4*>(dy + ((r * Hout + ho) * C + c8 * 8));
         const uint32_t gg[4] = {g.x, g.y, g.z, g.w};
+        if (db) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gv = bf16_to_f32((uint16_t)((gg[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+                bsum[2 * e] += (win[e] & 1) ? 0.f : gv;
+                bsum[2 * e + 1] += (win[e] & 1) ? gv : 0.f;
+            }
+        }
         for (int j = 0; j < k; ++j) {
             const int h = ho * k + j;
             if (h >= Hin) break;
@@ -636,6 +652,18 @@ __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const ui
             uint4* dst = reinterpret_cast<uint4*>(dx + ((r * Hin + h) * 2 * C + c8 * 16));
             dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
             dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+        }
+    }
+    if (db) {       // threads tid, tid + c8n, ... hold the same channels: one atomic per channel and workgroup
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[threadIdx.x * 16 + e] = bsum[e];
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < c8n * 16) {
+            const int c8 = t >> 4, e = t & 15;
+            float s = 0.f;
+            for (int u = c8; u < 256; u += c8n) s += red[u * 16 + e];
+            atomicAdd(db + c8 * 16 + e, s);
         }
     }
 }
@@ -880,15 +908,22 @@ extern "C" int asr_maxout2_pool_fwd(void* stream, const void* x, void* y, long l
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
-extern "C" int asr_maxout2_pool_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k) {
+extern "C" int asr_maxout2_pool_bwd_db(void* stream, const void* x, const void* dy, void* dx, float* db, long long R, int Hin, int C, int k) {
     if (!x || !dy || !dx || R <= 0 || Hin <= 0 || C <= 0 || k <= 0) return ASR_ERR_BAD_ARG;
     if ((C & 7) || ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15)) return ASR_ERR_UNSUPPORTED;
+    if (db && (kThreads != 256 || (256 % (C >> 3)) != 0)) return ASR_ERR_UNSUPPORTED;
     const int Hout = (Hin + k - 1) / k;
-    hipLaunchKernelGGL(maxout2_pool_bwd_kernel, dim3(grid_for(R * Hout * (C >> 3))), dim3(kThreads), 0, (hipStream_t)stream,
-                       (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, R, Hin, Hout, C, k);
+    int grid = grid_for(R * Hout * (C >> 3));
+    if (db && grid > 768) grid = 768;       // one atomic per channel and workgroup, ~12 ns each on one address: keep that tail short
+    hipLaunchKernelGGL(maxout2_pool_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, db, R, Hin, Hout, C, k);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
+extern "C" int asr_maxout2_pool_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k) {
+    return asr_maxout2_pool_bwd_db(stream, x, dy, dx, nullptr, R, Hin, C, k);
+}
+extern "C" int asr_maxout2_pool_bwd_db_ok(int C) { return kThreads == 256 && (C & 7) == 0 && (256 % (C >> 3)) == 0; }
 
 extern "C" int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k) {
     if (!x || !y || R <= 0 || Hin <= 0 || C <= 0 || k <= 0) return ASR_ERR_BAD_ARG;

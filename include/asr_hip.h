@@ -175,6 +175,11 @@ int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long 
  * ASR_ERR_UNSUPPORTED: use the two calls).  Same results and tie rules as asr_maxout2_* followed by asr_maxpool_h_*. */
 int asr_maxout2_pool_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
 int asr_maxout2_pool_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
+/* The same with the bias gradient of the convolution in front: db (2 C floats, accumulated; may be NULL) += column sums of dx, formed
+ * from dy and the winners while both are in registers (replaces the chainer Convolution2D backward's gy.sum over (N, H, W),
+ * asr/nn/convolution_2d.py:76-90 through chainer.functions.convolution_2d).  asr_maxout2_pool_bwd_db_ok(C): 1 if db may be given. */
+int asr_maxout2_pool_bwd_db(void* stream, const void* x, const void* dy, void* dx, float* db, long long R, int Hin, int C, int k);
+int asr_maxout2_pool_bwd_db_ok(int C);
 int asr_maxpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
 int asr_maxpool_h_bwd(void* stream, const void* x, const void* dy, void* dx, long long R, int Hin, int C, int k);
 int asr_add_bf16(void* stream, const void* a, const void* b, void* y, long long n);

@@ -231,7 +231,8 @@ def test_layernorm_one_sweep_backward(device, rows, D, C):
     np.testing.assert_allclose(db2.cpu().numpy() - 1.0, dbeta.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
 
 
-@pytest.mark.parametrize("T,B,H,C,k", [(7, 3, 38, 64, 3), (5, 2, 13, 16, 2), (4, 2, 11, 24, 3), (3, 1, 4, 8, 2), (6, 2, 6, 32, 1)])
+@pytest.mark.parametrize("T,B,H,C,k", [(7, 3, 38, 64, 3), (5, 2, 13, 16, 2), (4, 2, 11, 24, 3), (3, 1, 4, 8, 2), (6, 2, 6, 32, 1),
+                                       (300, 16, 38, 64, 3)])
 def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
     """asr_maxout2_pool_fwd / _bwd against asr_maxout2_* followed by asr_maxpool_h_* (cover_all windows, ties included):
     bit-identical outputs and input gradients"""
@@ -249,6 +250,15 @@ def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
     dx_ref = _ops.maxout2_bwd(xd, _ops.maxpool_h_bwd(mid, gy, k))
     dx = _ops.maxout2_pool_bwd(xd, gy, k)
     assert torch.equal(dx, dx_ref)
+    # with the bias gradient of the producer: the column sums of dx, accumulated on top of what is there
+    if _ops.maxout2_pool_bwd_db_ok(C):
+        db = torch.ones(2 * C, device=device)
+        dx2 = _ops.maxout2_pool_bwd(xd, gy, k, db)
+        assert torch.equal(dx2, dx_ref)
+        ref = 1.0 + dx_ref.float().reshape(-1, 2 * C).sum(0)
+        assert torch.allclose(db, ref, rtol=1e-5, atol=1e-4)
+    else:
+        assert C == 24
 
 
 def test_layer_stack_fuses_maxout_and_pooling(device):
@@ -271,6 +281,29 @@ def test_layer_stack_fuses_maxout_and_pooling(device):
     assert torch.equal(xa.grad, xb.grad)
     assert _fusable_pool([nn.Maxout(2), nn.Dropout(0.5), nn.MaxPooling2D(ksize=(3, 1))], 0) == -1
     assert _fusable_pool([nn.Maxout(2), nn.MaxPooling2D(ksize=(3, 1), stride=2)], 0) == -1
+
+
+def test_conv_bias_gradient_from_the_fused_maxout_pool_backward(device):
+    """Convolution2D -> Maxout(2) -> MaxPooling2D in one layer stack: the fused backward forms the convolution's bias gradient (column
+    sums of the gradient it scatters); it must equal what the convolution's own backward computes when the layers run one by one,
+    also on a later pass over a fresh graph"""
+    from asr import nn, functions as F
+    from asr import _ops
+    torch.manual_seed(5)
+    x = torch.randn(3, 3, 20, 31, device=device)                      # (B, C, H, T) float32 input of a first layer
+    conv = nn.Convolution2D(3, 32, (3, 5), stride=1, pad=(0, 4), causal=True).to(device)
+    stack = nn.Module(conv, nn.Maxout(2), nn.Dropout(0), nn.MaxPooling2D(ksize=(3, 1)))
+    grads = []
+    for fused in (True, False, True):
+        conv.cleargrads()
+        y = stack(x) if fused else F.max_pooling_2d(F.maxout(conv(x), 2), (3, 1))
+        gy = torch.ones_like(y) * 0.5
+        y.backward(gy)
+        F.join_side_stream()                # the weight-gradient products run on the side stream (the optimisers join it)
+        grads.append((conv.b.grad.clone(), conv.W.grad.clone()))
+    for gb, gW in grads[1:]:
+        assert torch.allclose(gb, grads[0][0], rtol=1e-4, atol=1e-3) and torch.allclose(gW, grads[0][1], rtol=1e-4, atol=1e-3)
+    assert grads[0][0].abs().max().item() > 0
 
 
 # 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
