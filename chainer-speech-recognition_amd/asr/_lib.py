@@ -24,6 +24,7 @@ SIGNATURES = {
     "asr_occupy_cus": (c_int, [c_void_p, c_int, c_int, c_int]),
     "asr_ctc_workspace_bytes": (c_size_t, [c_int] * 5),
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
+    "asr_ctc_forward_lse": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t, c_void_p]),
     "asr_ctc_backward": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int, c_float, c_void_p, c_void_p, c_size_t]),
     "asr_ctc_loss_grad": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float] + [c_void_p] * 4 + [c_size_t]),
     "asr_specgram": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_int,
@@ -72,6 +73,8 @@ SIGNATURES = {
     "asr_add_bf16": (c_int, [c_void_p] * 4 + [c_longlong]),
     "asr_colsum_acc": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_void_p]),
     "asr_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_int]),
+    "asr_layernorm_fwd_lse": (c_int, [c_void_p] * 8 + [c_longlong, c_int]),
+    "asr_layernorm_fwd_lse_ok": (c_int, [c_int, c_int]),
     "asr_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 3 + [c_void_p, c_int, c_void_p, c_void_p,
                                   c_longlong, c_int, c_int]),
     "asr_layernorm_bwd_rows_ws_bytes": (c_longlong, [c_longlong, c_int]),

@@ -241,13 +241,20 @@ def colsum_acc(x, out):
     return out
 
 
-def layernorm_fwd(x, gamma, beta, C, out_dtype):
-    """x (rows, D) f32/bf16; statistics per row; channel = index % C."""
+def layernorm_fwd(x, gamma, beta, C, out_dtype, want_lse=False):
+    """x (rows, D) f32/bf16; statistics per row; channel = index % C.  want_lse (float32 rows normalised over their whole width only):
+    also the log-sum-exp of every output row, formed while the row is in registers -> (y, mean, rstd, lse)"""
     assert x.dim() == 2 and x.is_contiguous()
     rows, D = x.shape
     y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
+    if want_lse:
+        assert x.dtype == F32 and out_dtype == F32 and _lib.lib().asr_layernorm_fwd_lse_ok(D, C)
+        lse = torch.empty(rows, dtype=F32, device=x.device)
+        rc = _lib.lib().asr_layernorm_fwd_lse(stream(), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(lse), rows, D)
+        check(rc, "asr_layernorm_fwd_lse")
+        return y, mean, rstd, lse
     rc = _lib.lib().asr_layernorm_fwd(stream(), ptr(x), _is_bf16(x), ptr(y), _is_bf16(y), ptr(gamma), ptr(beta),
                                       ptr(mean), ptr(rstd), rows, D, C)
     check(rc, "asr_layernorm_fwd")

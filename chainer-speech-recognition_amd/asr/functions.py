@@ -155,10 +155,11 @@ FUSE_CTC_INTO_LAYERNORM = [True]
 
 
 class _CtcBox(object):
-    __slots__ = ("ptr", "numel", "shape", "recipes")
+    """`lse`: log-sum-exp of every (t, b) row of the logits (float32, T * B), or None"""
+    __slots__ = ("ptr", "numel", "shape", "recipes", "lse")
 
-    def __init__(self, y, T, B, V):
-        self.ptr, self.numel, self.shape, self.recipes = y.data_ptr(), y.numel(), (T, B, V), []
+    def __init__(self, y, T, B, V, lse=None):
+        self.ptr, self.numel, self.shape, self.recipes, self.lse = y.data_ptr(), y.numel(), (T, B, V), [], lse
 
     def post(self, recipe):
         self.recipes.append(recipe)
@@ -510,6 +511,9 @@ class _MaxPoolH(torch.autograd.Function):
         return _ops.maxpool_h_bwd(p, gy.contiguous(), ctx.k), None
 
 
+BIAS_FROM_POOL_MIN_NUMEL = [1 << 26]
+
+
 class _Maxout2PoolH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, k, sole):
@@ -517,7 +521,9 @@ class _Maxout2PoolH(torch.autograd.Function):
         ctx.k = k
         # the only consumer of a convolution's output: its backward pass forms that output's whole gradient, so the bias gradient
         # (the column sums) comes out of the same pass
-        box = _producer_box(p, "_asr_biasbox", 12, BF16) if sole else None
+        # (worth it on a large output only: 141 us against 128 + 146 us for the first block of the BASELINE model, but 73 against
+        # 32 + 32 us for the second -- the sums end in one atomic per channel and workgroup on one address each)
+        box = _producer_box(p, "_asr_biasbox", 12, BF16) if (sole and p.numel() >= BIAS_FROM_POOL_MIN_NUMEL[0]) else None
         if box is not None and not (isinstance(box.bias, torch.nn.Parameter) and box.bias.numel() == p.shape[3]
                                     and _ops.maxout2_pool_bwd_db_ok(p.shape[3] // 2)):
             box = None
@@ -669,14 +675,18 @@ def add(a, b):
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, gamma, beta, C, out_f32, mailbox, tb):
-        y, mean, rstd = _ops.layernorm_fwd(x2, gamma.detach(), beta.detach(), C, F32 if out_f32 else BF16)
+        # float32 rows normalised over their whole width = logits normalised over the vocabulary of each (t, b) frame: a
+        # CTC-family loss on them may leave a recipe instead of a gradient (see _CtcBox), and finds the log-sum-exp of every row
+        # already there (formed by the normalisation while it had the row in registers)
+        per_frame = out_f32 and tb is not None and x2.dtype == F32 and C == x2.shape[1] and C % 4 == 0 and C <= 4096
+        want_lse = per_frame and FUSE_CTC_INTO_LAYERNORM[0] and x2.data_ptr() % 16 == 0
+        res = _ops.layernorm_fwd(x2, gamma.detach(), beta.detach(), C, F32 if out_f32 else BF16, want_lse)
+        y, mean, rstd = res[:3]
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params = (gamma, beta)
         ctx.meta = (C, ctx.needs_input_grad[0], mailbox)
-        # float32 rows normalised over their whole width = logits normalised over the vocabulary of each (t, b) frame: a
-        # CTC-family loss on them may leave a recipe instead of a gradient (see _CtcBox)
-        if out_f32 and tb is not None and x2.dtype == F32 and C == x2.shape[1] and C % 4 == 0 and C <= 4096:
-            ctx._asr_ctc_box = _CtcBox(y, tb[0], tb[1], C)
+        if per_frame:
+            ctx._asr_ctc_box = _CtcBox(y, tb[0], tb[1], C, res[3] if want_lse else None)
         return y
 
     @staticmethod

@@ -56,10 +56,12 @@ class _CTCFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xs.device)
         loss_b = torch.empty(B, dtype=torch.float32, device=xs.device)
         loss_m = torch.empty((), dtype=torch.float32, device=xs.device)
-        rc = lib.asr_ctc_forward(_lib.stream(), _lib.ptr(xs), _lib.ptr(label_unigram), _lib.ptr(label_bigram),
-                                 _lib.ptr(input_length), _lib.ptr(label_length), T, B, V, Lmax, int(blank),
-                                 _lib.ptr(loss_b), _lib.ptr(loss_m), _lib.ptr(ws), nbytes)
-        _lib.check(rc, "asr_ctc_forward")
+        # logits straight out of a per-frame LayerNormalization come with the log-sum-exp of every row (functions._CtcBox.lse)
+        row_lse = box.lse if (box is not None and box.lse is not None and box.lse.numel() == T * B) else None
+        rc = lib.asr_ctc_forward_lse(_lib.stream(), _lib.ptr(xs), _lib.ptr(label_unigram), _lib.ptr(label_bigram),
+                                     _lib.ptr(input_length), _lib.ptr(label_length), T, B, V, Lmax, int(blank),
+                                     _lib.ptr(loss_b), _lib.ptr(loss_m), _lib.ptr(ws), nbytes, _lib.ptr(row_lse))
+        _lib.check(rc, "asr_ctc_forward_lse")
         ctx.save_for_backward(xs, input_length, ws)
         ctx.dims = (T, B, V, Lmax, int(gram), reduce)
         ctx.box = box if Lmax * (3 if gram else 2) + 1 <= 512 else None

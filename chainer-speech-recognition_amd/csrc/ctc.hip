@@ -79,13 +79,24 @@ __global__ void prep_kernel(const int* __restrict__ uni, const int* __restrict__
 // One workgroup per (t, b) row of logits: lse = log sum exp, then lp[b][t][s] = x[label_s] - lse.
 __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ xs, const int* __restrict__ x_len,
                                                    const int* __restrict__ path_label, int T, int B, int V, int Sp,
-                                                   float* __restrict__ lse_out, float* __restrict__ lp) {
+                                                   float* __restrict__ lse_out, float* __restrict__ lp, const float* __restrict__ lse_in) {
     __shared__ float scratch[32];
     const int row = blockIdx.x;            // row = t * B + b
     const int t = row / B, b = row - t * B;
     const int xl = x_len ? min(x_len[b], T) : T;
     if (t >= xl) return;
     const float* x = xs + (size_t)row * V;
+    if (lse_in) {       // the producer of the logits formed the row's log-sum-exp while it had the row in registers: gather only
+        const float lse = lse_in[row];
+        if (threadIdx.x == 0) lse_out[row] = lse;
+        const int* pl = path_label + (size_t)b * Sp;
+        float* out = lp + ((size_t)b * T + t) * Sp;
+        for (int s = threadIdx.x; s < Sp; s += blockDim.x) {
+            const int l = pl[s];
+            out[s] = l >= 0 ? x[l] - lse : -INFINITY;
+        }
+        return;
+    }
     float m = -INFINITY;
     const bool vec = ((V & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
     if (vec) {
@@ -393,10 +404,10 @@ extern "C" size_t asr_ctc_workspace_bytes(int T, int B, int V, int Lmax, int gra
     return carve(nullptr, T, B, Lmax, gram).bytes;
 }
 
-extern "C" int asr_ctc_forward(void* stream_, const float* xs, const int32_t* label_unigram,
-                               const int32_t* label_bigram, const int32_t* x_len, const int32_t* l_len, int T, int B,
-                               int V, int Lmax, int blank, float* loss_per_utt, float* loss_mean, void* workspace,
-                               size_t workspace_bytes) {
+extern "C" int asr_ctc_forward_lse(void* stream_, const float* xs, const int32_t* label_unigram,
+                                   const int32_t* label_bigram, const int32_t* x_len, const int32_t* l_len, int T, int B,
+                                   int V, int Lmax, int blank, float* loss_per_utt, float* loss_mean, void* workspace,
+                                   size_t workspace_bytes, const float* row_lse) {
     if (!xs || !label_unigram || !loss_per_utt || !workspace) return ASR_ERR_BAD_ARG;
     if (T <= 0 || B <= 0 || V <= 0 || Lmax <= 0 || blank < 0 || blank >= V) return ASR_ERR_BAD_ARG;
     const int gram = label_bigram != nullptr;
@@ -413,7 +424,7 @@ extern "C" int asr_ctc_forward(void* stream_, const float* xs, const int32_t* la
         hipLaunchKernelGGL(prep_kernel<false>, dim3(B), dim3(256), 0, stream, label_unigram, label_bigram, l_len, Lmax,
                            Sp, V, blank, w.path_label, w.path_mask, w.path_len);
     ASR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_kernel, dim3(T * B), dim3(256), 0, stream, xs, x_len, w.path_label, T, B, V, Sp, w.lse, w.lp);
+    hipLaunchKernelGGL(rows_kernel, dim3(T * B), dim3(row_lse ? 64 : 256), 0, stream, xs, x_len, w.path_label, T, B, V, Sp, w.lse, w.lp, row_lse);
     ASR_LAUNCH_CHECK();
     const int threads = Sp < 1024 ? Sp : 1024;
     if (gram) {
@@ -433,6 +444,14 @@ extern "C" int asr_ctc_forward(void* stream_, const float* xs, const int32_t* la
         ASR_LAUNCH_CHECK();
     }
     return ASR_OK;
+}
+
+extern "C" int asr_ctc_forward(void* stream_, const float* xs, const int32_t* label_unigram,
+                               const int32_t* label_bigram, const int32_t* x_len, const int32_t* l_len, int T, int B,
+                               int V, int Lmax, int blank, float* loss_per_utt, float* loss_mean, void* workspace,
+                               size_t workspace_bytes) {
+    return asr_ctc_forward_lse(stream_, xs, label_unigram, label_bigram, x_len, l_len, T, B, V, Lmax, blank, loss_per_utt, loss_mean,
+                               workspace, workspace_bytes, nullptr);
 }
 
 extern "C" int asr_ctc_backward(void* stream_, const float* xs, const int32_t* x_len, int T, int B, int V, int Lmax,

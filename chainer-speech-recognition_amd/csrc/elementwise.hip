@@ -914,7 +914,9 @@ extern "C" int asr_maxout2_pool_bwd_db(void* stream, const void* x, const void* 
     if (db && (kThreads != 256 || (256 % (C >> 3)) != 0)) return ASR_ERR_UNSUPPORTED;
     const int Hout = (Hin + k - 1) / k;
     int grid = grid_for(R * Hout * (C >> 3));
-    if (db && grid > 768) grid = 768;       // one atomic per channel and workgroup, ~12 ns each on one address: keep that tail short
+    // one atomic per channel and workgroup, ~12 ns each on one address: 2048 workgroups (eight per CU, all resident) keep that tail at
+    // ~25 us; 768 starved the streaming part (three workgroups per CU: 289 us for the 311 MB of the first block instead of 166)
+    if (db && grid > 2048) grid = 2048;
     hipLaunchKernelGGL(maxout2_pool_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, db, R, Hin, Hout, C, k);
     ASR_LAUNCH_CHECK();

@@ -131,6 +131,70 @@ __global__ __launch_bounds__(256) void fwd_f32x4_kernel(const float* __restrict_
                             (v.w - mean) * rstd * g.w + b.w);
     }
 }
+// The logits path again, one WAVE per row and the row in registers (D <= 256 NV floats): one read of x, the two statistics and --
+// optionally -- the row's log-sum-exp of y by wave shuffles, no workgroup barrier, one write of y.  gamma / beta stay in registers
+// over the rows a wave walks (C == D: a lane always owns the same columns).  lse (may be null): what a CTC-family loss on y needs
+// first (asr_ctc_forward_lse), formed here while y is in registers instead of by two more passes over the 384 MB of logits.
+// Replaces three passes over x behind three barriers (fwd_f32x4_kernel: 0.22 ms and 1.07 GB of traffic on (32000, 3000)).
+template <int NV>
+__global__ __launch_bounds__(256) void fwd_rows_f32_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, float* __restrict__ lse_out, long long rows, int D) {
+    const int n4 = D >> 2, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 g[NV], b[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = lane + 64 * k;
+        g[k] = i < n4 ? *reinterpret_cast<const float4*>(gamma + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[k] = i < n4 ? *reinterpret_cast<const float4*>(beta + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_d = 1.0f / (float)D;
+    for (long long row = (long long)blockIdx.x * 4 + wid; row < rows; row += (long long)gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+        float4 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + 64 * k;
+            v[k] = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (lane + 64 * k < n4) {
+                const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d);
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        float4* yr = reinterpret_cast<float4*>(y + row * D);
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < n4) {
+                v[k] = make_float4((v[k].x - mean) * rstd * g[k].x + b[k].x, (v[k].y - mean) * rstd * g[k].y + b[k].y,
+                                   (v[k].z - mean) * rstd * g[k].z + b[k].z, (v[k].w - mean) * rstd * g[k].w + b[k].w);
+                yr[i] = v[k];
+                m = fmaxf(m, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+            }
+        }
+        if (lse_out) {
+            m = wave_max(m);
+            float e = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (lane + 64 * k < n4) e += (__expf(v[k].x - m) + __expf(v[k].y - m)) + (__expf(v[k].z - m) + __expf(v[k].w - m));
+            e = wave_sum(e);
+            if (lane == 0) lse_out[row] = m + __logf(e);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void bwd_f32x4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                         const float* __restrict__ rstd_in, float* __restrict__ dx, int D,
@@ -362,10 +426,37 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sgy, const doubl
 using namespace asr;
 using namespace asr::ln;
 
+// rows in registers: float32 in and out, one parameter per column (C == D), whole float4s
+static bool fwd_rows_ok(const void* x, const void* y, const float* gamma, const float* beta, int D, int C) {
+    return C == D && (D & 3) == 0 && D <= 4096 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
+}
+static int launch_fwd_rows(hipStream_t s, const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                           float* lse, long long rows, int D) {
+    long long blocks = (rows + 3) / 4;
+    if (blocks > 256 * 3) blocks = 256 * 3;
+    const int nv = cdiv(D >> 2, 64);
+#define ASR_LNF(NV) hipLaunchKernelGGL(fwd_rows_f32_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, gamma, beta, mean, rstd, lse, rows, D)
+    if (nv <= 4) ASR_LNF(4); else if (nv <= 8) ASR_LNF(8); else if (nv <= 12) ASR_LNF(12); else ASR_LNF(16);
+#undef ASR_LNF
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_layernorm_fwd_lse_ok(int D, int C) { return C == D && (D & 3) == 0 && D <= 4096; }
+
+extern "C" int asr_layernorm_fwd_lse(void* stream, const float* x, float* y, const float* gamma, const float* beta, float* mean,
+                                     float* rstd, float* lse, long long rows, int D) {
+    if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || D <= 0) return ASR_ERR_BAD_ARG;
+    if (!fwd_rows_ok(x, y, gamma, beta, D, D)) return ASR_ERR_UNSUPPORTED;
+    return launch_fwd_rows((hipStream_t)stream, x, y, gamma, beta, mean, rstd, lse, rows, D);
+}
+
 extern "C" int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* y, int y_bf16, const float* gamma,
                                  const float* beta, float* mean, float* rstd, long long rows, int D, int C) {
     if (!x || !y || !gamma || !beta || !mean || !rstd || rows <= 0 || D <= 0 || C <= 0 || D % C) return ASR_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (!x_bf16 && !y_bf16 && fwd_rows_ok(x, y, gamma, beta, D, C))
+        return launch_fwd_rows(s, (const float*)x, (float*)y, gamma, beta, mean, rstd, nullptr, rows, D);
     const dim3 g((unsigned)rows), b(256);
     if (!x_bf16 && !y_bf16 && (D & 3) == 0 && (C & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
         hipLaunchKernelGGL(fwd_f32x4_kernel, g, b, 0, s, (const float*)x, (float*)y, gamma, beta, mean, rstd, D, C);

@@ -41,6 +41,11 @@ size_t asr_ctc_workspace_bytes(int T, int B, int V, int Lmax, int gram);
 int asr_ctc_forward(void* stream, const float* xs, const int32_t* label_unigram, const int32_t* label_bigram,
                     const int32_t* x_len, const int32_t* l_len, int T, int B, int V, int Lmax, int blank,
                     float* loss_per_utt, float* loss_mean, void* workspace, size_t workspace_bytes);
+/* The same with the log-sum-exp of every (t, b) row of xs handed in (row_lse[t * B + b], e.g. from asr_layernorm_fwd_lse; NULL: as
+ * asr_ctc_forward): the rows pass then only gathers the label entries instead of reading the logits twice. */
+int asr_ctc_forward_lse(void* stream, const float* xs, const int32_t* label_unigram, const int32_t* label_bigram,
+                        const int32_t* x_len, const int32_t* l_len, int T, int B, int V, int Lmax, int blank, float* loss_per_utt,
+                        float* loss_mean, void* workspace, size_t workspace_bytes, const float* row_lse);
 int asr_ctc_backward(void* stream, const float* xs, const int32_t* x_len, int T, int B, int V, int Lmax, int gram,
                      const float* gy, int gy_per_utt, float scale, float* grad, const void* workspace,
                      size_t workspace_bytes);
@@ -199,6 +204,12 @@ int asr_colsum_acc(void* stream, const void* x, int x_bf16, long long rows, int 
  */
 int asr_layernorm_fwd(void* stream, const void* x, int x_bf16, void* y, int y_bf16, const float* gamma,
                       const float* beta, float* mean, float* rstd, long long rows, int D, int C);
+/* float32 rows normalised over their whole width (C == D, D % 4 == 0, D <= 4096: the logits of a frame over the vocabulary,
+ * asr/nn/layernorm.py:33-48 as used by run/ctc/model.py on the output layer): one wave per row, the row in registers, and --
+ * lse != NULL -- the log-sum-exp of every output row for asr_ctc_forward_lse.  asr_layernorm_fwd_lse_ok(D, C): 1 if it applies. */
+int asr_layernorm_fwd_lse(void* stream, const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                          float* lse, long long rows, int D);
+int asr_layernorm_fwd_lse_ok(int D, int C);
 int asr_layernorm_bwd(void* stream, const void* x, int x_bf16, const void* dy, int dy_bf16, const float* gamma,
                       const float* mean, const float* rstd, void* dx, int dx_bf16, float* dgamma, float* dbeta,
                       long long rows, int D, int C);

@@ -195,6 +195,26 @@ def test_layernorm(device, B, C, H, T):
     np.testing.assert_allclose(dbeta.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("rows,D", [(37, 3000), (1000, 120), (5, 4096), (130, 1024), (64, 260)])
+def test_layernorm_rows_in_registers_with_lse(device, rows, D):
+    """float32 rows normalised over their whole width (the logits path): the wave-per-row forward against float64, plain and with the
+    log-sum-exp of every output row (what asr_ctc_forward_lse takes over)"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(rows + D)
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    var = ((xd - mu) ** 2).mean(1, keepdim=True)
+    ref = (xd - mu) / var.sqrt() * gamma.double() + beta.double()
+    y, mean, rstd = _ops.layernorm_fwd(x.to(device), gamma.to(device), beta.to(device), D, F32)
+    y2, mean2, rstd2, lse = _ops.layernorm_fwd(x.to(device), gamma.to(device), beta.to(device), D, F32, want_lse=True)
+    assert torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert _rel(y.cpu(), ref) < 2e-6
+    assert torch.allclose(mean.cpu().double(), mu[:, 0], atol=1e-5) and torch.allclose(rstd.cpu().double(), 1 / var.sqrt()[:, 0], rtol=1e-5)
+    assert torch.allclose(lse.cpu().double(), torch.logsumexp(ref, 1), rtol=0, atol=2e-5)
+
+
 @pytest.mark.parametrize("rows,D,C", [(20000, 120, 120), (700, 3000, 3000), (33, 4096, 1024), (257, 1028, 4), (1, 8, 8)])
 def test_layernorm_one_sweep_backward(device, rows, D, C):
     """asr_layernorm_bwd_rows (dx + column sums in one pass, many rows per workgroup) against the float64 oracle and,
@@ -294,6 +314,7 @@ def test_conv_bias_gradient_from_the_fused_maxout_pool_backward(device):
     conv = nn.Convolution2D(3, 32, (3, 5), stride=1, pad=(0, 4), causal=True).to(device)
     stack = nn.Module(conv, nn.Maxout(2), nn.Dropout(0), nn.MaxPooling2D(ksize=(3, 1)))
     grads = []
+    F.BIAS_FROM_POOL_MIN_NUMEL[0], keep = 0, F.BIAS_FROM_POOL_MIN_NUMEL[0]       # (the layer stack fuses on large outputs only)
     for fused in (True, False, True):
         conv.cleargrads()
         y = stack(x) if fused else F.max_pooling_2d(F.maxout(conv(x), 2), (3, 1))
@@ -301,6 +322,7 @@ def test_conv_bias_gradient_from_the_fused_maxout_pool_backward(device):
         y.backward(gy)
         F.join_side_stream()                # the weight-gradient products run on the side stream (the optimisers join it)
         grads.append((conv.b.grad.clone(), conv.W.grad.clone()))
+    F.BIAS_FROM_POOL_MIN_NUMEL[0] = keep
     for gb, gW in grads[1:]:
         assert torch.allclose(gb, grads[0][0], rtol=1e-4, atol=1e-3) and torch.allclose(gW, grads[0][1], rtol=1e-4, atol=1e-3)
     assert grads[0][0].abs().max().item() > 0
