@@ -481,7 +481,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 template <typename OutT, int CONV, int NJ>
 __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
                                                                        int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
-                                                                       int M, int N, int K, int tiles_m, int tiles_n_signed, int total,
+                                                                       int M, int N, int K, int tiles_m, int tiles_n, int total,
                                                                        unsigned a_bytes, ConvDesc cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,19 +495,27 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
     char* Bs = smem + 2 * A_STAGE;
     auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
     const int nk = K / B2K;
-    const int stride = gridDim.x;
+    // Tile walk: XCD x (= bid % 8 under round-robin dispatch; only a locality hint) owns the CONTIGUOUS tiles [x chunk, (x + 1) chunk),
+    // its workgroups stride through them together: ~64-96 consecutive row panels in flight per L2.  For the implicit convolutions that
+    // is what keeps the taps' re-reads of the activations (rows of neighbouring time steps = the neighbouring panels) inside one L2:
+    // dealt panel by panel over the XCDs, every L2 fetched nearly the whole tensor (PMC FETCH_SIZE of the 64 -> 128 convolution of the
+    // BASELINE model: 710 MB for a 53 MB input, backward-data 1333 MB for 106 MB).  Plain products: a row panel of A and all its column
+    // tiles stay on one XCD as before.
+    const int chunk = (total + 7) >> 3, stride = gridDim.x >> 3;
+    const int limit = min(total, ((int)(blockIdx.x & 7) + 1) * chunk), first = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
 
     // loader: slot sl = i * 256 + tid = (LDS row i * 64 + tid / 4, position tid % 4); the chunk it holds does not depend on i
     const int lrow = tid >> 2, lchunk = ((tid & 3) ^ g4(lrow)) * 16;
     unsigned oa[4], ob[BP];                // BYTE offsets of this lane's rows in the tile being ISSUED (uniform base + 32-bit lane offset)
     int cth[4];                            // CONV: (t << 8) | h of the row; rows beyond M get a t far below zero
-    int it_tile = blockIdx.x, it_k = 0;
+    int it_tile = first, it_k = 0;
     int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // CONV: tap of the next K step to issue (CONV == 2: of this lane's chunk of that step)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
     auto set_issue = [&](int t) {
         int tm, tn;
-        tile_of(t, tiles_m, tiles_n_signed, tm, tn);
+        tm = t / tiles_n;
+        tn = t - tm * tiles_n;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (CONV) {
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
         if (++it_k == nk) {
             it_k = 0;
             it_tile += stride;
-            if (it_tile < total) set_issue(it_tile);
+            if (it_tile < limit) set_issue(it_tile);
         }
     };
     // fragment addresses: row = (wave base) + i * 16 + r, and the swizzle key (row >> 2) & 3 does not depend on i: one register per
@@ -567,19 +575,19 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
     const int q = lane >> 4, r = lane & 15;
     const int aoff0 = (wid * 64 + r) * 64 + ((q ^ g4(r)) << 4);
     const int boff0 = r * 64 + ((q ^ g4(r)) << 4);
-    if (it_tile >= total) return;
+    if (it_tile >= limit) return;
     set_issue(it_tile);
     issue_next(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     int buf = 0;
-    for (int tile = blockIdx.x; tile < total; tile += stride) {
+    for (int tile = first; tile < limit; tile += stride) {
         f32x4 acc[4][NJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
-            if (it_tile < total) issue_next(buf ^ 1);
+            if (it_tile < limit) issue_next(buf ^ 1);
             const char* Ab = As + buf * A_STAGE;
             const char* Bb = Bs + buf * B_STAGE;
             // B fragment j + 1 is read BEFORE the four MFMAs of fragment j are issued (the sched_group_barriers pin that order: left
@@ -604,8 +612,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
             buf ^= 1;
         }
         // epilogue: acc[i][j][reg] = C[m0 + wid * 64 + i * 16 + 4 q + reg][n0 + (j / G) 16 G + G r + j % G]
-        int tm, tn;
-        tile_of(tile, tiles_m, tiles_n_signed, tm, tn);
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
         const int col = tn * TNW + G * r;
         const int row0 = tm * B2M + wid * 64 + 4 * q;
         float bv[NJ];
@@ -677,7 +684,17 @@ __global__ __launch_bounds__(128 * WN_) void gemm_nt_wide_kernel(const uint16_t*
     constexpr int A_SLOTS = TM * CH / THREADS, B_SLOTS = TNC * CH / THREADS, P = A_SLOTS + B_SLOTS;
     constexpr int A_STAGE = TM * ROWB, B_STAGE = TNC * ROWB;
     int tm, tn;
-    tile_of(blockIdx.x, (M + TM - 1) / TM, tiles_n, tm, tn);
+    if (CONV) {
+        // contiguous tile ranges per XCD (bid % 8), walked in dispatch order: the taps' re-reads of neighbouring time steps stay in
+        // one L2 (see gemm_nt256p_kernel); the grid is 8 x ceil(tiles / 8), the surplus workgroups leave here
+        const int tn_ = tiles_n < 0 ? -tiles_n : tiles_n, total = ((M + TM - 1) / TM) * tn_, chunk = (total + 7) >> 3;
+        const int x = blockIdx.x & 7, t = x * chunk + (int)(blockIdx.x >> 3);
+        if (t >= min(total, (x + 1) * chunk)) return;
+        tm = t / tn_;
+        tn = t - tm * tn_;
+    } else {
+        tile_of(blockIdx.x, (M + TM - 1) / TM, tiles_n, tm, tn);
+    }
     const int m0 = tm * TM, n0 = tn * TNC;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN_, wn = wid % WN_;
@@ -1215,7 +1232,7 @@ static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const 
         constexpr int LDS = ST * 512 * BK * 2;                                                                            \
         static bool attr = false;                                                                                         \
         if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<OutT, CONV, BK, ST, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
-        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, BK, ST, WN>), dim3(tm * tn), dim3(THREADS), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd); \
+        hipLaunchKernelGGL((gemm_nt_wide_kernel<OutT, CONV, BK, ST, WN>), dim3(CONV ? 8 * cdiv(tm * tn, 8) : tm * tn), dim3(THREADS), LDS, stream, A, lda, B, ldb, C, ldc, bias, M, N, K, tn_arg, cd); \
     } while (0)
     if (mode == 2) ASR_WIDE(64, 2, 4, 512);
     else if (mode == 3) ASR_WIDE(32, 4, 2, 256);      // four waves of 128 x 128 (256 accumulator registers), four-deep ring
@@ -1233,7 +1250,7 @@ static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const 
 static int nt_persist_grid(int total, int max_per_cu) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("ASR_NT_PERSIST_GRID"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) return total < forced ? total : forced;
+    if (forced > 0) return ((total < forced ? total : forced) + 7) & ~7;
     const float tile_time[4] = {0.f, 0.80f, 0.87f, 1.0f};
     int best = 256 * max_per_cu;
     float best_cost = 1e30f;
@@ -1241,7 +1258,7 @@ static int nt_persist_grid(int total, int max_per_cu) {
         const float cost = (float)cdiv(total, 256 * k) * tile_time[k];
         if (cost < best_cost - 1e-6f) { best_cost = cost; best = 256 * k; }
     }
-    return total < best ? total : best;
+    return total < best ? ((total + 7) & ~7) : best;       // (a multiple of 8: the kernels deal tile ranges to bid % 8)
 }
 
 extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -1286,10 +1303,10 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         const int grid = nt_persist_grid(total, 3);
         if (out_bf16)
             hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, 0, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
-                               (uint16_t*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
+                               (uint16_t*)C, ldc, bias, M, N, K, t2m, t2n, total, 0xffffffffu, ConvDesc{});
         else
             hipLaunchKernelGGL((gemm_nt256p_kernel<float, 0, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
-                               (float*)C, ldc, bias, M, N, K, t2m, b_fits_l2 ? -t2n : t2n, total, 0xffffffffu, ConvDesc{});
+                               (float*)C, ldc, bias, M, N, K, t2m, t2n, total, 0xffffffffu, ConvDesc{});
         ASR_LAUNCH_CHECK();
         return ASR_OK;
     }
@@ -1456,7 +1473,7 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
             const int total = t2m * t2n, grid = nt_persist_grid(total, 2);
 #define ASR_CONVP(T, C_, NJ_, CT)                                                                                          \
     hipLaunchKernelGGL((gemm_nt256p_kernel<T, C_, NJ_>), dim3(grid), dim3(256), 2 * (B2M + 16 * NJ_) * B2K * 2, stream, (const uint16_t*)x, 0, \
-                       (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, t2m, tn_arg, total, (unsigned)xbytes, cd)
+                       (const uint16_t*)W, K, (CT*)out, N, bias, (int)M, N, K, t2m, t2n, total, (unsigned)xbytes, cd)
             if (cmode == 1) {
                 if (out_bf16) { if (narrow) ASR_CONVP(uint16_t, 1, 4, uint16_t); else ASR_CONVP(uint16_t, 1, 8, uint16_t); }
                 else          { if (narrow) ASR_CONVP(float, 1, 4, float); else ASR_CONVP(float, 1, 8, float); }
