@@ -262,6 +262,23 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // recurrence is queued) starts milliseconds late at worst -- but a launch that can NEVER be fully resident (partitioned
 // device, another process holding CUs for good) still ends, raises the abort word and costs one dropped step.
 constexpr unsigned kSpinLimit = 1u << 22;
+// When to ask for the other workgroups' payload (s_sleep units of 64 cycles after this wave's own store / after the workgroup's
+// store flag).  A poll issued at once is always too early in this symmetric machine -- the other producers' stores are still on
+// their way to the L2 -- and the retry queues BEHIND it in the CU's memory pipeline: the hand-off then costs two round trips.  A
+// poll timed to pass the L2 just after the stores land usually succeeds at once.  Forward kernel, T=1000, B=32, H=512, us per step:
+// 0: 1.487, 3: 1.433, 6: 1.384, 10: 1.345, 11-12: 1.340, 14: 1.369, 18: 1.448, 26: 1.658 (three staggered polls in flight: 1.83).
+// The partial-sum backward kernel does not gain (0: 1.541, 6: 1.545, 10: 1.639): its first attempt already follows the re-arm stores
+// and the next step's LDS prologue.
+#ifndef ASR_FIRST_POLL_DELAY
+#define ASR_FIRST_POLL_DELAY 11
+#endif
+#ifndef ASR_COMP_POLL_DELAY
+#define ASR_COMP_POLL_DELAY ASR_FIRST_POLL_DELAY
+#endif
+#ifndef ASR_BWD_POLL_DELAY
+#define ASR_BWD_POLL_DELAY 0
+#endif
+constexpr int kFirstPollDelay = ASR_FIRST_POLL_DELAY, kCompPollDelay = ASR_COMP_POLL_DELAY, kBwdPollDelay = ASR_BWD_POLL_DELAY;
 constexpr int kPersistLds = 96 * 1024;
 // The wide backward kernel asks for so much LDS that no GEMM workgroup (36..64 KB) fits beside it on a CU.  Sharing the
 // CU paid while the recurrence waited on memory ("Co-residency"); once its step had become an
@@ -1541,7 +1558,6 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                     }
                 }
             }
-            if (gate_wave) fetch_p(pahead, s & (PS_RING - 1));       // P_s, asked for right behind this wave's own stores
             // re-arm the slot of step s - 2 (every consumer finished with it before it could produce the P_{s-1} this workgroup
             // has just consumed); the slots of steps s + 1, s + 3 are armed (launch fill / earlier re-arm)
             if (lane < 16 && s >= 2) {
@@ -1556,6 +1572,11 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                         __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), 0xffffffffu, ASR_RLX_AGENT);
                     }
                 }
+            }
+            // P_s: the first attempt, kBwdPollDelay after this wave's own stores (see kFirstPollDelay)
+            if (gate_wave) {
+                if (kBwdPollDelay > 0) __builtin_amdgcn_s_sleep(kBwdPollDelay);
+                fetch_p(pahead, s & (PS_RING - 1));
             }
         }
     }
@@ -1604,6 +1625,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
     const long long tstep = d == 0 ? 1 : -1;
     const int tfirst = d == 0 ? 0 : T - 1;
+    const size_t row_bytes_ = (size_t)B * hs * 2;           // one time step of hseq16
 
     // loader (wave 4), LDS-DMA straight into the ring slot (lane-linear image = [3 gates][8 rows][16 units] f32), no data
     // registers: TWO instructions per step -- all 64 lanes fetch gates r | z (lane / 32), lanes 0..31 gate n; lane % 32 =
@@ -1779,11 +1801,27 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         } else if (is_storer) {
+            // Pre-touch: the payload lines of step s + 2 (still all sentinel) are pulled into this XCD's L2 two steps before their
+            // producers write them, so that partial-line stores and polls find the line resident instead of fetching the sentinel
+            // line from memory (the launch's 65 MB sentinel fill does not stay in the L2s, and lines written from another XCD never
+            // were in this one): 1.491 -> 1.469 us per step.  Two lines per workgroup (64 lines per row group and step); the load's
+            // result is never used and never waited for inside the loop: inline asm, so that no waitcnt is scheduled around it.
+            unsigned touched = 0;
+            const int wg = j0 >> 4, tl = 2 * wg + (lane & 1), trow = tl >> 3;
+            const char* tbase = reinterpret_cast<const char*>(hseq16) + (((size_t)b0 + (trow < Bl ? trow : 0)) * hs + (size_t)d * H) * 2 + (size_t)(tl & 7) * 128;
+            const bool toucher = lane < 2 && trow < Bl && (size_t)(tl & 7) * 128 < (size_t)H * 2;
             for (int s = 0; s < T; ++s) {
                 ASR_RAW_BARRIER();
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
+                if (toucher && s + 2 < T) {
+                    const int t2 = d == 0 ? s + 2 : T - 3 - s;
+                    const char* tp_ = tbase + (size_t)t2 * row_bytes_;
+                    asm volatile("global_load_dword %0, %1, off sc1" : "+v"(touched) : "v"(tp_) : "memory");
+                }
                 if (s > 0) store_step(s - 1);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (touched == 0x12345678u && lane == 63) lds_poke(s_abort + 3, 0);      // (keeps the register alive; never true for bf16 pairs of a GRU state)
         } else {
             const bool gate_wave = w >= 2;
             int slot = 0;
@@ -1803,6 +1841,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         unsigned nap = 0;
                         while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
+                        if (kCompPollDelay > 0) __builtin_amdgcn_s_sleep(kCompPollDelay);
                         fetch_row(acur, tp);
                     }
                     unsigned spins = 0;
@@ -1865,13 +1904,14 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         if (packed == 0xffffffffu) packed = 0x7fc07fc0u;
                         __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, store_off + (unsigned)t * row_bytes, 0, 0);
                     }
-                    if (s + 1 < T) {
-                        if (lane == 0) lds_poke(s_abort + w, s + 1);
-                        fetch_row(ahead, t);
-                    }
+                    if (s + 1 < T && lane == 0) lds_poke(s_abort + w, s + 1);
                     if (act) {
                         float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
                         od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh2;
+                    }
+                    if (s + 1 < T) {
+                        if (kFirstPollDelay > 0) __builtin_amdgcn_s_sleep(kFirstPollDelay);
+                        fetch_row(ahead, t);
                     }
                 }
             }
