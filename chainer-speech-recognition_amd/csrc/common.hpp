@@ -65,6 +65,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return *reinterpret_cast<uint16_t*>(&b);
 }
 
+// two floats -> packed bf16 pair (lo in bits 0..15), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

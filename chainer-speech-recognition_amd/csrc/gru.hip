@@ -1328,8 +1328,11 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                                                         int forge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);                                      // [8 producer groups][4 rows][2][16] f32 = 4 KB
-    uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 4096);                         // [3 gates][4 rows][32 units] bf16 = 768 B
-    char* opring = smem + 4096 + 1024;                                                  // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
+    // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB: rows 4 .. 15 exist and stay zero, so that every lane reads its
+    // fragment unconditionally -- three ds_reads back to back and ONE wait (with 4-row images the reads sat behind exec-mask
+    // branches, each followed by its own wait: two LDS round trips more on the chain of every compute wave)
+    uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 4096);
+    char* opring = smem + 4096 + 3072;                                                  // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
     unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);         // [2][4: ar az an aq][4 rows][16 pairs]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 4 * 4 * 16);
     constexpr int rows = 4;
@@ -1414,7 +1417,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
         }
     }
-    for (int i = tid; i < 384; i += 640) reinterpret_cast<unsigned*>(aimg)[i & 255] = 0u;       // (rows >= Bl stay zero)
+    for (int i = tid; i < 768; i += 640) reinterpret_cast<unsigned*>(aimg)[i] = 0u;              // (rows >= Bl stay zero)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
@@ -1522,7 +1525,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             if (act) { sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq); }
             if (act) {
                 // MFMA A image [gate][row][unit] and the storer's [array][row][unit] (pairs of units per dword)
-                aimg[(0 * 4 + b) * 32 + u0] = ar; aimg[(1 * 4 + b) * 32 + u0] = az; aimg[(2 * 4 + b) * 32 + u0] = aq;
+                aimg[(0 * 16 + b) * 32 + u0] = ar; aimg[(1 * 16 + b) * 32 + u0] = az; aimg[(2 * 16 + b) * 32 + u0] = aq;
                 uint16_t* od = reinterpret_cast<uint16_t*>(oring + (size_t)(s & 1) * 4 * 4 * 16) + b * 32 + u0;
                 od[0] = ar; od[128] = az; od[256] = an; od[384] = aq;
             }
@@ -1532,20 +1535,19 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             f32x4 acc[NT];
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            Frag a[3];
 #pragma unroll
-            for (int gg = 0; gg < 3; ++gg) {
-                Frag a;
-                a.u = make_uint4(0, 0, 0, 0);
-                if ((lane & 15) < 4) a.u = *reinterpret_cast<const uint4*>(aimg + (gg * 4 + (lane & 15)) * 32 + 8 * (lane >> 4));
+            for (int gg = 0; gg < 3; ++gg) a[gg].u = *reinterpret_cast<const uint4*>(aimg + (gg * 16 + (lane & 15)) * 32 + 8 * (lane >> 4));
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bb[gg][nn].v, acc[nn], 0, 0, 0);
-            }
+            for (int gg = 0; gg < 3; ++gg)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gg].v, bb[gg][nn].v, acc[nn], 0, 0, 0);
             const unsigned ring_off = (unsigned)(s & (PS_RING - 1)) * xslot_bytes, rearm_off = (unsigned)((s + 2) & (PS_RING - 1)) * xslot_bytes;
             if (lane < 16) {
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) {
-                    unsigned lo = (unsigned)f32_to_bf16(acc[nn][0]) | ((unsigned)f32_to_bf16(acc[nn][1]) << 16);
-                    unsigned hi = (unsigned)f32_to_bf16(acc[nn][2]) | ((unsigned)f32_to_bf16(acc[nn][3]) << 16);
+                    unsigned lo = pack_bf16x2(acc[nn][0], acc[nn][1]);              // one v_cvt_pk_bf16_f32 per dword
+                    unsigned hi = pack_bf16x2(acc[nn][2], acc[nn][3]);
                     if (lo == 0xffffffffu) lo = 0x7fc07fc0u;            // (NaN pairs of a diverged run) never the sentinel
                     if (hi == 0xffffffffu) hi = 0x7fc07fc0u;
                     const unsigned o = soff + (unsigned)nn * 128u + ring_off;
