@@ -1421,6 +1421,13 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASR_RAW_BARRIER();
     const bool local = LOCAL && s_abort[1] != 0;
+    // -DASR_STAMP: cycles per phase and wave (s_memtime), read back by tools/stamp_gru_ps.py
+#ifdef ASR_STAMP
+    unsigned long long ps_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ps_last = __builtin_amdgcn_s_memtime();
+#define ASR_PS(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += n_ - ps_last; ps_last = n_; }
+#else
+#define ASR_PS(i)
+#endif
 
     // hand-off loads of the gate waves: 128 lanes x 2 pieces of 16 B = H/32 (<= 16.. 32) producers x 256 B.  Piece q = gl + 128 i:
     // producer q / 16, columns j0 + 2 (q % 16), + 1 (x 4 rows).  (H = 1024: 32 producers -> 4 pieces per lane.)
@@ -1457,6 +1464,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             r = of[0]; z = of[128]; n = of[256]; qq = of[384];
             hp = s < T - 1 ? of[512] : 0.f;
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
+            ASR_PS(0)
             if (s > 0) {
                 // P_{s-1}: the first attempt was issued right behind this wave's own stores of the previous step
 #pragma unroll
@@ -1477,6 +1485,10 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                     }
                     fetch_p(pcur, (s - 1) & (PS_RING - 1));
                 }
+                ASR_PS(1)
+#ifdef ASR_STAMP
+                ps_acc[7] += spins + 1;
+#endif
                 // lane-local sum over this lane's producers, then [group = gl / 16][row][unit parity][seg] float32 in LDS
                 float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1497,7 +1509,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                     for (int rr = 0; rr < 4; ++rr) rw[rr * 32 + e * 16] = acc8[e * 4 + rr];
             }
         }
+        ASR_PS(2)
         ASR_RAW_BARRIER();                  // (R) the partial sums of the eight lane groups are in LDS
+        ASR_PS(3)
         if ((s & 15) == 0 && lds_peek(s_abort)) break;
         if (is_loader) {
             issue(s + BIO_GD);              // the slot step s read above (before barrier R); waits until step s + 2 has landed
@@ -1530,7 +1544,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                 od[0] = ar; od[128] = az; od[256] = an; od[384] = aq;
             }
         }
+        ASR_PS(4)
         ASR_RAW_BARRIER();                  // (A) the gate gradients of this step are in LDS
+        ASR_PS(5)
         if (is_compute && s + 1 < T) {
             f32x4 acc[NT];
 #pragma unroll
@@ -1581,6 +1597,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                 fetch_p(pahead, s & (PS_RING - 1));
             }
         }
+        ASR_PS(6)
     }
     if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ASR_RAW_BARRIER();
@@ -1591,6 +1608,10 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
         atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
         atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
     }
+#ifdef ASR_STAMP
+    if (blockIdx.x < 32 && (blockIdx.x & 15) == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[(((blockIdx.x >> 4) * 10) + w) * 8 + i] = ps_acc[i];
+#endif
 }
 
 // Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
