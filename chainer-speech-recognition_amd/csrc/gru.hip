@@ -278,6 +278,18 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #ifndef ASR_BWD_POLL_DELAY
 #define ASR_BWD_POLL_DELAY 0
 #endif
+#ifndef ASR_COMP_AFTER_BARRIER
+#define ASR_COMP_AFTER_BARRIER 0
+#endif
+constexpr int kCompAfterBarrier = ASR_COMP_AFTER_BARRIER;
+#ifndef ASR_TOUCH
+#define ASR_TOUCH 1
+#endif
+constexpr bool kTouch = ASR_TOUCH != 0;
+#ifndef ASR_TOUCH_AHEAD
+#define ASR_TOUCH_AHEAD 2
+#endif
+constexpr int kTouchAhead = ASR_TOUCH_AHEAD;
 constexpr int kFirstPollDelay = ASR_FIRST_POLL_DELAY, kCompPollDelay = ASR_COMP_POLL_DELAY, kBwdPollDelay = ASR_BWD_POLL_DELAY;
 constexpr int kPersistLds = 96 * 1024;
 // The wide backward kernel asks for so much LDS that no GEMM workgroup (36..64 KB) fits beside it on a CU.  Sharing the
@@ -603,6 +615,16 @@ __device__ __forceinline__ bool wait_counter_l2(unsigned* counter, unsigned targ
 // access a flat_load / flat_store with sc0 sc1 followed by s_waitcnt vmcnt(0) -- on the gate waves that drained their own
 // payload store before the next hand-off loads could be issued
 typedef __attribute__((address_space(3))) volatile int lds_vint;
+// 16 B out of LDS by inline asm (waits for that read only).  The compiler puts s_waitcnt vmcnt(0) in front of every LDS read of a
+// kernel that also uses LDS-DMA (the DMA writes LDS and may alias) -- on the storer wave that is a wait for the acknowledgement of
+// everything it has written so far, and for its pre-touch loads, before it may read what it is about to store.
+typedef float f32x4_asm __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_asm lds_read16_raw(const void* p) {
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+    f32x4_asm v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 __device__ __forceinline__ int lds_peek(const int* p) { return *(const lds_vint*)(const __attribute__((address_space(3))) int*)p; }
 __device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribute__((address_space(3))) int*)p = v; }
 
@@ -1384,8 +1406,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
         const int gsel = lane >> 4, row = (lane & 15) >> 2, c = lane & 3;
         if (lane < 48 && row < Bl) {
             const size_t off = ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c * 8;
-            *reinterpret_cast<uint4*>(dgi + off) = *reinterpret_cast<const uint4*>(src + (gsel * 4 + row) * 16 + c * 4);
-            *reinterpret_cast<uint4*>(dgh + off) = *reinterpret_cast<const uint4*>(src + ((gsel == 2 ? 3 : gsel) * 4 + row) * 16 + c * 4);
+            // (raw LDS reads: see lds_read16_raw)
+            *reinterpret_cast<f32x4_asm*>(dgi + off) = lds_read16_raw(src + (gsel * 4 + row) * 16 + c * 4);
+            *reinterpret_cast<f32x4_asm*>(dgh + off) = lds_read16_raw(src + ((gsel == 2 ? 3 : gsel) * 4 + row) * 16 + c * 4);
         }
     };
     if (is_loader) {
@@ -1701,7 +1724,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 const size_t rowi = (size_t)tq * B + b0 + row;
                 float* dst = arr == 0 ? hseq + rowi * hs + (size_t)d * H + j0 + c4
                                       : gates + (rowi * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c4;
-                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src + pp * 4);
+                *reinterpret_cast<f32x4_asm*>(dst) = lds_read16_raw(src + pp * 4);
             }
         }
     };
@@ -1810,6 +1833,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
     // gate waves read after beta_{s+1} -- a barrier now separates every landing check from the read it covers.
     if (dp) {
         constexpr int GD = BIO_GD;
+        // -DASR_STAMP_DP: cycles per phase of the compute waves (read back by tools/stamp_gru_fwd_dp.py)
+#ifdef ASR_STAMP_DP
+        unsigned long long pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_last = __builtin_amdgcn_s_memtime();
+#define ASR_PF(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_acc[i] += n_ - pf_last; pf_last = n_; }
+#else
+#define ASR_PF(i)
+#endif
         if (is_loader) {
             issue(GD - 1);                                          // (the prologue issued steps 0 .. GD - 2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1836,8 +1866,8 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
             for (int s = 0; s < T; ++s) {
                 ASR_RAW_BARRIER();
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
-                if (toucher && s + 2 < T) {
-                    const int t2 = d == 0 ? s + 2 : T - 3 - s;
+                if (kTouch && toucher && s + kTouchAhead < T) {
+                    const int t2 = d == 0 ? s + kTouchAhead : T - 1 - kTouchAhead - s;
                     const char* tp_ = tbase + (size_t)t2 * row_bytes_;
                     asm volatile("global_load_dword %0, %1, off sc1" : "+v"(touched) : "v"(tp_) : "memory");
                 }
@@ -1855,11 +1885,19 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     read_gi(slot, gr, gz, gn);
                     slot = slot == GD - 1 ? 0 : slot + 1;
                 }
+                ASR_PF(0)
                 if (s > 0) {
                     const int tp = d == 0 ? t - 1 : t + 1;
                     if (gate_wave) {
 #pragma unroll
                         for (int i2 = 0; i2 < NA; ++i2) acur[i2].u = ahead[i2].u;
+                    } else if (kCompAfterBarrier > 0) {
+                        // no flag: the gate waves of every workgroup take the same time from the step's barrier to their store, so the
+                        // two pure compute waves time their first poll from the barrier as well (the flag -- an LDS word polled with
+                        // s_sleep(1) -- made them ask ~300 cycles later than the gate waves, which then waited for them at the
+                        // next barrier); a poll that is too early is retried like any other
+                        __builtin_amdgcn_s_sleep(kCompAfterBarrier);
+                        fetch_row(acur, tp);
                     } else {
                         unsigned nap = 0;
                         while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
@@ -1883,6 +1921,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         }
                         fetch_row(acur, tp);
                     }
+                    ASR_PF(1)
+#ifdef ASR_STAMP_DP
+                    pf_acc[7] += spins + 1;
+#endif
                     f32x4 acc[3];
 #pragma unroll
                     for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1903,7 +1945,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                             for (int r = 0; r < 4; ++r) pw[(gg * 128 + r * 16) * 4] = acc[gg][r];
                     }
                 }
+                ASR_PF(2)
                 ASR_RAW_BARRIER();
+                ASR_PF(3)
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
                 if (gate_wave) {
                     float gh0 = bh[0], gh1 = bh[1], gh2 = bh[2];
@@ -1921,6 +1965,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     hprev = h;
                     const unsigned mine = (unsigned)f32_to_bf16(h);
                     const unsigned other = lane_xor1_u32(mine);
+                    ASR_PF(4)
                     __builtin_amdgcn_s_waitcnt(0x0F70);              // nothing of this wave is in flight (see the generic loop)
                     if (act && !(u & 1)) {
                         unsigned packed = mine | (other << 16);
@@ -1936,8 +1981,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         if (kFirstPollDelay > 0) __builtin_amdgcn_s_sleep(kFirstPollDelay);
                         fetch_row(ahead, t);
                     }
+                    ASR_PF(5)
                 }
             }
+#ifdef ASR_STAMP_DP
+            if (blockIdx.x < 16 && (blockIdx.x & 7) == 0 && lane == 0)
+                for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[(((blockIdx.x >> 3) * 4) + w) * 8 + i] = pf_acc[i];
+#endif
         }
     } else
 #endif
