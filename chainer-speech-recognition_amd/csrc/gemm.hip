@@ -1289,7 +1289,7 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     static int persist = -1;
     if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
     static int pmin = -1;
-    if (pmin < 0) { const char* e = getenv("ASR_NT_PERSIST_MIN"); pmin = e ? atoi(e) : 400; }
+    if (pmin < 0) { const char* e = getenv("ASR_NT_PERSIST_MIN"); pmin = e ? atoi(e) : 256; }      // (one tile per CU: 32000 x 384 x 3072 642 -> 688, x 320 x 3008 532 -> 604 TFLOP/s against the 128 x 128 kernel)
     if (persist && aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= pmin && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
         (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldb < (1ull << 31) && M < (1 << 24) && N < (1 << 24) &&
         lda < (1 << 23) && ldb < (1 << 23)) {

@@ -272,9 +272,6 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #ifndef ASR_FIRST_POLL_DELAY
 #define ASR_FIRST_POLL_DELAY 11
 #endif
-#ifndef ASR_COMP_POLL_DELAY
-#define ASR_COMP_POLL_DELAY ASR_FIRST_POLL_DELAY
-#endif
 #ifndef ASR_BWD_POLL_DELAY
 #define ASR_BWD_POLL_DELAY 0
 #endif
@@ -290,7 +287,7 @@ constexpr bool kTouch = ASR_TOUCH != 0;
 #define ASR_TOUCH_AHEAD 2
 #endif
 constexpr int kTouchAhead = ASR_TOUCH_AHEAD;
-constexpr int kFirstPollDelay = ASR_FIRST_POLL_DELAY, kCompPollDelay = ASR_COMP_POLL_DELAY, kBwdPollDelay = ASR_BWD_POLL_DELAY;
+constexpr int kFirstPollDelay = ASR_FIRST_POLL_DELAY, kBwdPollDelay = ASR_BWD_POLL_DELAY;
 constexpr int kPersistLds = 96 * 1024;
 // The wide backward kernel asks for so much LDS that no GEMM workgroup (36..64 KB) fits beside it on a CU.  Sharing the
 // CU paid while the recurrence waited on memory ("Co-residency"); once its step had become an
@@ -630,6 +627,15 @@ __device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribu
 
 // value of lane ^ 1 through DPP quad_perm [1,0,3,2]: __shfl_xor compiles to ds_bpermute, an LDS round trip on the chain
 // between the gate math and the payload store
+// the pause in front of a first poll: one s_sleep with an immediate for the values the host hands out (a loop of s_sleep(1) costs
+// the chain ~0.02 us more: 1.369 against 1.347 us per step), the loop for anything else (ASR_GRU_POLL_DELAY)
+__device__ __forceinline__ void poll_pause(int n) {
+    if (n == 11) __builtin_amdgcn_s_sleep(11);
+    else if (n == 3) __builtin_amdgcn_s_sleep(3);
+    else if (n == 6) __builtin_amdgcn_s_sleep(6);
+    else for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
 __device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
@@ -1783,6 +1789,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
     // simply loads its K slices until no sentinel dword is left -- no flags, no drain of the payload stores before a
     // signal, and one barrier per step (partials double-buffered by step parity)
     const bool dp = local && PAIRED && (forge & 8) != 0;
+    const int poll_delay = (forge >> 8) & 0xff;          // s_sleep(1) units between a wave's own store / flag and its first poll (host: fwd_poll_delay)
 #ifdef ASR_STAMP
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #define ASR_ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_last; st_last = n_; }
@@ -1844,7 +1851,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
             issue(GD - 1);                                          // (the prologue issued steps 0 .. GD - 2)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int s = 0; s < T; ++s) {
+                ASR_PF(2)
                 ASR_RAW_BARRIER();
+                ASR_PF(3)
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
                 issue(s + GD);                                       // slot s % GD: read at the top of step s, before beta_s
                 // in flight afterwards: the issues of steps s + 3 .. s + GD that exist (two LDS-DMA instructions each)
@@ -1853,6 +1862,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 else if (left == 1) { if (GI16) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+#ifdef ASR_STAMP_DP
+            if (blockIdx.x < 16 && (blockIdx.x & 7) == 0 && lane == 0)
+                for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[64 + (((blockIdx.x >> 3) * 2) + 0) * 8 + i] = pf_acc[i];
+#endif
         } else if (is_storer) {
             // Pre-touch: the payload lines of step s + 2 (still all sentinel) are pulled into this XCD's L2 two steps before their
             // producers write them, so that partial-line stores and polls find the line resident instead of fetching the sentinel
@@ -1864,7 +1877,9 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
             const char* tbase = reinterpret_cast<const char*>(hseq16) + (((size_t)b0 + (trow < Bl ? trow : 0)) * hs + (size_t)d * H) * 2 + (size_t)(tl & 7) * 128;
             const bool toucher = lane < 2 && trow < Bl && (size_t)(tl & 7) * 128 < (size_t)H * 2;
             for (int s = 0; s < T; ++s) {
+                ASR_PF(2)
                 ASR_RAW_BARRIER();
+                ASR_PF(3)
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
                 if (kTouch && toucher && s + kTouchAhead < T) {
                     const int t2 = d == 0 ? s + kTouchAhead : T - 1 - kTouchAhead - s;
@@ -1874,6 +1889,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 if (s > 0) store_step(s - 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ASR_STAMP_DP
+            if (blockIdx.x < 16 && (blockIdx.x & 7) == 0 && lane == 0)
+                for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[64 + (((blockIdx.x >> 3) * 2) + 1) * 8 + i] = pf_acc[i];
+#endif
             if (touched == 0x12345678u && lane == 63) lds_poke(s_abort + 3, 0);      // (keeps the register alive; never true for bf16 pairs of a GRU state)
         } else {
             const bool gate_wave = w >= 2;
@@ -1902,7 +1921,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         unsigned nap = 0;
                         while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
-                        if (kCompPollDelay > 0) __builtin_amdgcn_s_sleep(kCompPollDelay);
+                        poll_pause(poll_delay);
                         fetch_row(acur, tp);
                     }
                     unsigned spins = 0;
@@ -1978,7 +1997,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh2;
                     }
                     if (s + 1 < T) {
-                        if (kFirstPollDelay > 0) __builtin_amdgcn_s_sleep(kFirstPollDelay);
+                        poll_pause(poll_delay);
                         fetch_row(ahead, t);
                     }
                     ASR_PF(5)
@@ -2977,6 +2996,16 @@ static bool can_persist(int T, int B, int H, int ndir, int mode, const void* syn
     return true;
 }
 
+// first-poll delay of the forward hand-off in s_sleep(1) units (~70 cycles each), see kFirstPollDelay: measured per H (the number of
+// producers of a recurrence, H / 16, shifts the moment the last store lands); ASR_GRU_POLL_DELAY overrides
+static int fwd_poll_delay(int H) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("ASR_GRU_POLL_DELAY"); env = e ? atoi(e) : -1; }
+    if (env >= 0) return env > 255 ? 255 : env;
+    // T=1000, B=32, us per step at 0 / best: H=512 1.49 / 1.34 (11), H=384 1.41 / 1.39 (2-4), H=256 1.156 / 1.137 (2-4), H=128 1.24 / 1.21 (6-12)
+    return H >= 512 ? kFirstPollDelay : (H >= 256 ? 3 : 6);
+}
+
 // which forward kernel family serves a call: 0 one launch per step, 1 wide, 2 16-unit x 8-row (the default at B <= 32),
 // 3 grouped, 4 plain persistent
 static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
@@ -3048,12 +3077,13 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
         // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
         const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
         if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
+        const int forge_k = forge | (fwd_poll_delay(H) << 8);
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
 #define ASR_FWDIO_(K, L, G)                                                                                               \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
         hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge : 0);           \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge_k : 0);         \
     } while (0)
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \

@@ -19,3 +19,8 @@ for wg in (0, 1):
     for w in range(4):
         print("wg", wg, "wave", w, " ".join("%s=%d" % (n, st[wg, w, i].item() // T) for i, n in enumerate(names)),
               "sum=%d" % (st[wg, w, :6].sum().item() // T), "attempts/step=%.2f" % (st[wg, w, 7].item() / T))
+io = s[4096 + 64 * 8:4096 + 64 * 8 + 2 * 2 * 8 * 8].view(torch.int64).reshape(2, 2, 8)
+for wg in (0, 1):
+    for i, nm in enumerate(("loader", "storer")):
+        print("wg", wg, nm, "barrier..next barrier arrival=%d" % (io[wg, i, 2].item() // T), "wait in barrier=%d" % (io[wg, i, 3].item() // T))
+
