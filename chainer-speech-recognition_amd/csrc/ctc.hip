@@ -81,22 +81,29 @@ __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ xs,
                                                    const int* __restrict__ path_label, int T, int B, int V, int Sp,
                                                    float* __restrict__ lse_out, float* __restrict__ lp, const float* __restrict__ lse_in) {
     __shared__ float scratch[32];
-    const int row = blockIdx.x;            // row = t * B + b
-    const int t = row / B, b = row - t * B;
-    const int xl = x_len ? min(x_len[b], T) : T;
-    if (t >= xl) return;
-    const float* x = xs + (size_t)row * V;
-    if (lse_in) {       // the producer of the logits formed the row's log-sum-exp while it had the row in registers: gather only
+    if (lse_in) {       // the producer of the logits formed the row's log-sum-exp while it had the row in registers: gather only,
+                        // one wave per row, four rows per workgroup
+        const int row = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (row >= T * B) return;
+        const int t = row / B, b = row - t * B;
+        const int xl = x_len ? min(x_len[b], T) : T;
+        if (t >= xl) return;
+        const float* x = xs + (size_t)row * V;
         const float lse = lse_in[row];
-        if (threadIdx.x == 0) lse_out[row] = lse;
+        if (lane == 0) lse_out[row] = lse;
         const int* pl = path_label + (size_t)b * Sp;
         float* out = lp + ((size_t)b * T + t) * Sp;
-        for (int s = threadIdx.x; s < Sp; s += blockDim.x) {
+        for (int s = lane; s < Sp; s += 64) {
             const int l = pl[s];
             out[s] = l >= 0 ? x[l] - lse : -INFINITY;
         }
         return;
     }
+    const int row = blockIdx.x;            // row = t * B + b
+    const int t = row / B, b = row - t * B;
+    const int xl = x_len ? min(x_len[b], T) : T;
+    if (t >= xl) return;
+    const float* x = xs + (size_t)row * V;
     float m = -INFINITY;
     const bool vec = ((V & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
     if (vec) {
@@ -424,7 +431,7 @@ extern "C" int asr_ctc_forward_lse(void* stream_, const float* xs, const int32_t
         hipLaunchKernelGGL(prep_kernel<false>, dim3(B), dim3(256), 0, stream, label_unigram, label_bigram, l_len, Lmax,
                            Sp, V, blank, w.path_label, w.path_mask, w.path_len);
     ASR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_kernel, dim3(T * B), dim3(row_lse ? 64 : 256), 0, stream, xs, x_len, w.path_label, T, B, V, Sp, w.lse, w.lp, row_lse);
+    hipLaunchKernelGGL(rows_kernel, dim3(row_lse ? (T * B + 3) / 4 : T * B), dim3(256), 0, stream, xs, x_len, w.path_label, T, B, V, Sp, w.lse, w.lp, row_lse);
     ASR_LAUNCH_CHECK();
     const int threads = Sp < 1024 ? Sp : 1024;
     if (gram) {
