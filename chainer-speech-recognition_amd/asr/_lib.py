@@ -62,6 +62,9 @@ SIGNATURES = {
     "asr_conv_weight_pack": (c_int, [c_void_p] * 3 + [c_int] * 6),
     "asr_conv_weight_grad_unpack": (c_int, [c_void_p] * 3 + [c_int] * 6),
     "asr_conv_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
+    "asr_conv_tn_copies": (c_int, [c_int] * 4),
+    "asr_conv_tn_acc_copies": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 13),
+    "asr_conv_weight_grad_unpack_copies": (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6),
     "asr_maxout2_fwd": (c_int, [c_void_p] * 3 + [c_longlong]),
     "asr_maxout2_bwd": (c_int, [c_void_p] * 4 + [c_longlong]),
     "asr_maxout2_pool_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),

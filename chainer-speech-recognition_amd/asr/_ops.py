@@ -105,23 +105,32 @@ def conv_weight_pack(W, transpose=False, Kp=None):
 
 
 def conv_weight_grad_unpack(scratch, gW, channel_pitch=0):
-    """gW (Co, Ci, KH, KW) += scratch (Co, Kp) with k = (kh, kw, c), c < channel_pitch (0: Ci)"""
+    """gW (Co, Ci, KH, KW) += scratch (Co, Kp) with k = (kh, kw, c), c < channel_pitch (0: Ci); a scratch of shape (copies, Co, Kp)
+    (per-XCD copies, conv_tn_copies) is summed over its first axis on the way"""
     Co, Ci, KH, KW = gW.shape
     assert scratch.dtype == F32 and scratch.is_contiguous() and gW.is_contiguous()
-    check(_lib.lib().asr_conv_weight_grad_unpack(stream(), ptr(scratch), ptr(gW), Co, Ci, KH, KW, scratch.shape[1],
-                                                 int(channel_pitch)), "asr_conv_weight_grad_unpack")
+    copies = scratch.shape[0] if scratch.dim() == 3 else 1
+    check(_lib.lib().asr_conv_weight_grad_unpack_copies(stream(), ptr(scratch), copies, ptr(gW), Co, Ci, KH, KW, scratch.shape[-1],
+                                                        int(channel_pitch)), "asr_conv_weight_grad_unpack_copies")
+
+
+def conv_tn_copies(Co, Cs, KH, KW):
+    """8 if the weight-gradient kernel wants one scratch copy per XCD for this layer (few output tiles), else 1"""
+    return int(_lib.lib().asr_conv_tn_copies(int(Co), int(Cs), int(KH), int(KW)))
 
 
 def conv_tn_acc(g2, x, scratch, KH, KW, pad_h, pad_t, Tr, Hr):
     """scratch (Co, KH*KW*Cs) f32 += weight gradient of the convolution that maps x (Ts, B, Hs, Cs) bf16 to (Tr, B, Hr, Co),
-    g2 (Tr*B*Hr, Co) bf16 its output gradient: the implicit form of gemm_tn_acc(g2, im2col(x), scratch)"""
+    g2 (Tr*B*Hr, Co) bf16 its output gradient: the implicit form of gemm_tn_acc(g2, im2col(x), scratch).  scratch may be
+    (8, Co, KH*KW*Cs) where conv_tn_copies says so: every XCD adds into its own copy."""
     Ts, B, Hs, Cs = x.shape
     Co = g2.shape[1]
     assert x.dtype == BF16 and g2.dtype == BF16 and scratch.dtype == F32 and g2.shape[0] == Tr * B * Hr
-    assert scratch.shape == (Co, KH * KW * Cs) and scratch.is_contiguous()
-    rc = _lib.lib().asr_conv_tn_acc(stream(), ptr(g2), g2.stride(0), ptr(x), ptr(scratch), scratch.shape[1], Co, Ts, B, Hs, Cs,
-                                    KH, KW, pad_h, pad_t, Tr, Hr)
-    check(rc, "asr_conv_tn_acc")
+    copies = scratch.shape[0] if scratch.dim() == 3 else 1
+    assert tuple(scratch.shape[-2:]) == (Co, KH * KW * Cs) and scratch.is_contiguous() and copies in (1, 8)
+    rc = _lib.lib().asr_conv_tn_acc_copies(stream(), ptr(g2), g2.stride(0), ptr(x), ptr(scratch), scratch.shape[-1], copies, Co, Ts, B,
+                                           Hs, Cs, KH, KW, pad_h, pad_t, Tr, Hr)
+    check(rc, "asr_conv_tn_acc_copies")
 
 
 ACT_KINDS = {"relu": 0, "clipped_relu": 1, "leaky_relu": 2, "elu": 3, "sigmoid": 4, "tanh": 5, "hard_sigmoid": 6,

@@ -352,7 +352,8 @@ class _Conv2D(torch.autograd.Function):
         def weight_grads():
             if implicit:            # no column matrix here either: the virtual im2col rows are gathered by the TN kernel
                 Cs = xphys.shape[3]         # 8 for the first layer's zero-padded channels
-                scratch = torch.empty((Co, KH * KW * Cs), dtype=F32, device=gy.device)
+                copies = _ops.conv_tn_copies(Co, Cs, KH, KW)       # one copy per XCD where a single tile takes hundreds of K splits
+                scratch = torch.empty((copies, Co, KH * KW * Cs) if copies > 1 else (Co, KH * KW * Cs), dtype=F32, device=gy.device)
                 _ops.fill_(scratch, 0.0)
                 _ops.conv_tn_acc(g2, xphys, scratch, KH, KW, pad_h, pad_t, Tout, Hout)
                 _ops.conv_weight_grad_unpack(scratch, gW, Cs)

@@ -443,7 +443,7 @@ __global__ void conv_weight_pack_bwd_kernel(const float* __restrict__ W, uint16_
 }
 // unpack: gW[co][ci][kh][kw] += scratch[co][(kh*KW + kw)*Cs + ci]   (Cs >= Ci: channel pitch of the scratch rows)
 __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch, float* __restrict__ gW, int Co, int Ci,
-                                               int KH, int KW, int Kp, int Cs) {
+                                               int KH, int KW, int Kp, int Cs, int copies) {
     const long long n = (long long)Co * Ci * KH * KW;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         long long r = i;
@@ -451,7 +451,10 @@ __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch
         const int kh = (int)(r % KH); r /= KH;
         const int ci = (int)(r % Ci);
         const int co = (int)(r / Ci);
-        atomicAdd(gW + i, scratch[(long long)co * Kp + (kh * KW + kw) * Cs + ci]);      // (two half batches may add at once)
+        const long long o = (long long)co * Kp + (kh * KW + kw) * Cs + ci;
+        float v = scratch[o];
+        for (int c = 1; c < copies; ++c) v += scratch[o + (long long)c * Co * Kp];           // (per-XCD copies: asr_conv_tn_acc_copies)
+        atomicAdd(gW + i, v);      // (two half batches may add at once)
     }
 }
 
@@ -1050,14 +1053,19 @@ extern "C" int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst,
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
-extern "C" int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW,
-                                           int Kp, int Cs) {
+extern "C" int asr_conv_weight_grad_unpack_copies(void* stream, const float* scratch, int copies, float* gW, int Co, int Ci, int KH,
+                                                  int KW, int Kp, int Cs) {
     if (Cs <= 0) Cs = Ci;
-    if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Cs < Ci || Kp < KH * KW * Cs) return ASR_ERR_BAD_ARG;
+    if (!scratch || !gW || Co <= 0 || Ci <= 0 || KH <= 0 || KW <= 0 || Cs < Ci || Kp < KH * KW * Cs || copies < 1 || copies > 8)
+        return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(conv_weight_grad_unpack_kernel, dim3(grid_for((long long)Co * Ci * KH * KW)), dim3(kThreads), 0,
-                       (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp, Cs);
+                       (hipStream_t)stream, scratch, gW, Co, Ci, KH, KW, Kp, Cs, copies);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
+}
+extern "C" int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW,
+                                           int Kp, int Cs) {
+    return asr_conv_weight_grad_unpack_copies(stream, scratch, 1, gW, Co, Ci, KH, KW, Kp, Cs);
 }
 
 extern "C" int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC,

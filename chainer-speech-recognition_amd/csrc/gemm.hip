@@ -875,7 +875,7 @@ template <bool CONV>
 __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                       const uint16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                       int ldc, int M, int N, int K, int tiles_n, int k_per_split,
-                                                      ConvDesc cd) {
+                                                      ConvDesc cd, long long copy_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
     uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
@@ -885,6 +885,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
     // Only a locality hint: any placement computes the same thing.
     const int tiles = ((M + BM - 1) / BM) * tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    C += (size_t)xcd * copy_stride;      // (one copy of the output per XCD when hundreds of K splits share one tile: asr_conv_tn_copies)
     const int round = slot / tiles, bid = slot - round * tiles;
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -1383,18 +1384,28 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{});
+                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
 
-extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B,
-                               int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr) {
+// Few output tiles (one for the first layer: 128 x 120) mean hundreds of K splits, i.e. hundreds of workgroups on all eight XCDs adding
+// into the same 64 KB: 91 of the 166 us of that call were the atomics.  With copies == 8 every XCD (workgroup id % 8) adds into its own
+// copy C + xcd * Co * ldc -- the adds stay in one L2 -- and asr_conv_weight_grad_unpack_copies sums the copies.
+extern "C" int asr_conv_tn_copies(int Co, int Cs, int KH, int KW) {
+    const int N = KH * KW * Cs;
+    if (tn256_ok(Co, 8, 8, nullptr, nullptr, true)) return 1;
+    return cdiv(Co, BM) * cdiv(N, BN) <= 2 ? 8 : 1;
+}
+
+extern "C" int asr_conv_tn_acc_copies(void* stream_, const void* g, int ldg, const void* x, float* C, int ldc, int copies, int Co, int Ts,
+                                      int B, int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr) {
     if (!g || !x || !C || Co <= 0 || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0)
         return ASR_ERR_BAD_ARG;
     const int N = KH * KW * Cs;
     const long long K = (long long)Tr * B * Hr;
-    if (ldg < Co || ldc < N) return ASR_ERR_BAD_ARG;
+    if (ldg < Co || ldc < N || (copies != 1 && copies != 8)) return ASR_ERR_BAD_ARG;
+    if (copies == 8 && asr_conv_tn_copies(Co, Cs, KH, KW) != 8) return ASR_ERR_BAD_ARG;
     if ((Cs & 7) || K > 0x7fffffffLL || (((uintptr_t)x) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
@@ -1413,9 +1424,14 @@ extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, (int)K, k_per_split);
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd);
+                       (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd, copies == 8 ? (long long)Co * ldc : 0LL);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
+}
+
+extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B,
+                               int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr) {
+    return asr_conv_tn_acc_copies(stream_, g, ldg, x, C, ldc, 1, Co, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, Tr, Hr);
 }
 
 extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias,

@@ -174,6 +174,14 @@ int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst, int Co, in
 int asr_conv_tn_acc(void* stream, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B, int Hs,
                     int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr);
 int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp, int Cs);
+/* Few output tiles -> hundreds of K splits adding into the same few KB (first layer: 91 of 166 us were the atomics): with
+ * asr_conv_tn_copies(...) == 8 the caller hands a zeroed scratch of 8 x (Co, ldc) floats, every XCD adds into its own copy, and
+ * asr_conv_weight_grad_unpack_copies sums them into the gradient. */
+int asr_conv_tn_copies(int Co, int Cs, int KH, int KW);
+int asr_conv_tn_acc_copies(void* stream, const void* g, int ldg, const void* x, float* C, int ldc, int copies, int Co, int Ts, int B,
+                           int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr);
+int asr_conv_weight_grad_unpack_copies(void* stream, const float* scratch, int copies, float* gW, int Co, int Ci, int KH, int KW, int Kp,
+                                       int Cs);
 int asr_maxout2_fwd(void* stream, const void* x, void* y, long long n_out);
 int asr_maxout2_bwd(void* stream, const void* x, const void* dy, void* dx, long long n_out);
 /* Maxout(2) + MaxPooling2D((k, 1)) in one pass: x (R, Hin, 2C) bf16 -> y (R, ceil(Hin / k), C); C % 8 == 0 (else

@@ -617,6 +617,13 @@ def test_first_layer_weight_gradient_with_padded_channels(device):
         for kw in range(KW):
             ref[:, :, kh, kw] = torch.einsum("bohs,bchs->oc", g, xp[:, :, kh:kh + Hout, kw:kw + Tout])
     assert _rel(gW.cpu().double(), ref) < 1e-5
+    # one scratch copy per XCD (a single output tile under hundreds of K splits): the same gradient after the unpack's sum
+    assert _ops.conv_tn_copies(Co, 8, KH, KW) == 8 and _ops.conv_tn_copies(512, 256, KH, KW) == 1
+    scratch8 = torch.zeros(8, Co, KH * KW * 8, device=device)
+    _ops.conv_tn_acc(gy.to(device).to(torch.bfloat16).reshape(-1, Co), xpad, scratch8, KH, KW, ph, pt, Tout, Hout)
+    gW8 = torch.ones(Co, Ci, KH, KW, device=device)
+    _ops.conv_weight_grad_unpack(scratch8, gW8, 8)
+    assert _rel((gW8 - 1.0).cpu().double(), ref) < 1e-5
 
 
 def test_persistent_recurrence_waits_out_busy_cus(device):
