@@ -630,10 +630,17 @@ __device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribu
 // the pause in front of a first poll: one s_sleep with an immediate for the values the host hands out (a loop of s_sleep(1) costs
 // the chain ~0.02 us more: 1.369 against 1.347 us per step), the loop for anything else (ASR_GRU_POLL_DELAY)
 __device__ __forceinline__ void poll_pause(int n) {
-    if (n == 11) __builtin_amdgcn_s_sleep(11);
-    else if (n == 3) __builtin_amdgcn_s_sleep(3);
-    else if (n == 6) __builtin_amdgcn_s_sleep(6);
-    else for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    switch (n) {
+        case 0: break;
+        case 3: __builtin_amdgcn_s_sleep(3); break;
+        case 4: __builtin_amdgcn_s_sleep(4); break;
+        case 5: __builtin_amdgcn_s_sleep(5); break;
+        case 6: __builtin_amdgcn_s_sleep(6); break;
+        case 7: __builtin_amdgcn_s_sleep(7); break;
+        case 8: __builtin_amdgcn_s_sleep(8); break;
+        case 11: __builtin_amdgcn_s_sleep(11); break;
+        default: for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 }
 
 __device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
@@ -1649,7 +1656,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 // Raw barriers (s_barrier + lgkmcnt(0)): __syncthreads() would also wait for the loader's LDS-DMA in flight.
 // GI16: the input projections arrive in bf16 (asr_gemm_nt with a bf16 output: half the bytes written by the projection and
 // read here, ONE LDS-DMA instruction per step instead of two): ring slot = [3 gates][8 rows][16 units] bf16 = 768 B.
-template <int KSW, bool LOCAL, bool GI16>
+template <int KSW, bool LOCAL, bool GI16, bool RING>
 __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
@@ -1732,6 +1739,18 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                                       : gates + (rowi * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c4;
                 *reinterpret_cast<f32x4_asm*>(dst) = lds_read16_raw(src + pp * 4);
             }
+        }
+    };
+    // RING: the storer also writes the bf16 sequence (8 rows x 16 units: lanes 0..15 write 16 B each)
+    auto store_h16 = [&](int sp) {
+        if (lane < 16 && (lane >> 1) < Bl) {
+            const long long tq = tfirst + tstep * sp;
+            const float* src = oring + (size_t)(sp & 1) * 5 * 8 * 16 + (lane >> 1) * 16 + (lane & 1) * 8;
+            const f32x4_asm v0 = lds_read16_raw(src), v1 = lds_read16_raw(src + 4);
+            uint4 pk;
+            pk.x = pack_bf16x2(v0[0], v0[1]); pk.y = pack_bf16x2(v0[2], v0[3]);
+            pk.z = pack_bf16x2(v1[0], v1[1]); pk.w = pack_bf16x2(v1[2], v1[3]);
+            *reinterpret_cast<uint4*>(hseq16 + ((size_t)tq * B + b0 + (lane >> 1)) * hs + (size_t)d * H + j0 + (lane & 1) * 8) = pk;
         }
     };
     if (is_loader) {
@@ -1823,6 +1842,35 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         }
     };
     const unsigned store_off = (unsigned)((((size_t)b0 + b) * hs + (size_t)d * H + j0 + u) * 2);
+    // RING: the polled payload lives in a 4-slot ring of this recurrence inside sync_ws ([slot][8 rows][H] bf16, behind the control
+    // words, the place of the backward kernel's partial-sum ring): 32 KB of L2-resident lines per recurrence, written and read every
+    // fourth step, instead of a fresh 8 KB of the (T, B, ndir H) sequence per step, which has to be filled with sentinels before the
+    // launch and pre-touched.  A producer re-arms its piece of slot s - 2 behind its store of step s (every consumer has read slot
+    // s - 2: it needed it to produce the h_{s-1} this workgroup has consumed).  The bf16 sequence itself (operand of the dW_hh
+    // product) is then written by the storer, off the chain.
+    const unsigned slot_bytes = (unsigned)(8 * H * 2);
+    const __amdgpu_buffer_rsrc_t ringrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<char*>(sync) + kPsOffset + (size_t)rec * PS_RING * slot_bytes), 0, (int)(PS_RING * slot_bytes), 0x00020000);
+    unsigned ring_frag_off[NA];
+#pragma unroll
+    for (int i2 = 0; i2 < KSW / 2; ++i2) {
+        const int r16 = lane & 15, row = r16 & 7;
+        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
+        // producer-major slots: [workgroup (16 units)][8 rows][16 units], so that a producer's store instruction writes its 256 B as
+        // two whole lines (in the (T, B, H) sequence a workgroup's piece is 32 B of every row's line)
+        const int kk = ks * 32 + 8 * (lane >> 4);
+        ring_frag_off[i2] = (unsigned)(((kk >> 4) * 128 + row * 16 + (kk & 15)) * 2);
+    }
+    auto fetch_ring = [&](Frag (&f)[NA], int slot) {
+#pragma unroll
+        for (int i2 = 0; i2 < KSW / 2; ++i2) {
+            if (frag_on[i2]) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ringrsrc, ring_frag_off[i2] + (unsigned)slot * slot_bytes, 0, 16 /* sc1 */);
+                f[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    };
+    const unsigned ring_store_off = (unsigned)(((j0 >> 4) * 128 + b * 16 + u) * 2);
     Frag ahead[NA], acur[NA];   // ahead: (gate waves) the next step's first attempt, issued right behind their own h store
 #pragma unroll
     for (int i2 = 0; i2 < NA; ++i2) { ahead[i2].u = make_uint4(0, 0, 0, 0); acur[i2].u = make_uint4(0, 0, 0, 0); }
@@ -1881,12 +1929,12 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 ASR_RAW_BARRIER();
                 ASR_PF(3)
                 if ((s & 15) == 0 && lds_peek(s_abort)) break;
-                if (kTouch && toucher && s + kTouchAhead < T) {
+                if (!RING && kTouch && toucher && s + kTouchAhead < T) {
                     const int t2 = d == 0 ? s + kTouchAhead : T - 1 - kTouchAhead - s;
                     const char* tp_ = tbase + (size_t)t2 * row_bytes_;
                     asm volatile("global_load_dword %0, %1, off sc1" : "+v"(touched) : "v"(tp_) : "memory");
                 }
-                if (s > 0) store_step(s - 1);
+                if (s > 0) { store_step(s - 1); if (RING) store_h16(s - 1); }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef ASR_STAMP_DP
@@ -1922,7 +1970,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
                         poll_pause(poll_delay);
-                        fetch_row(acur, tp);
+                        if (RING) fetch_ring(acur, (s - 1) & (PS_RING - 1)); else fetch_row(acur, tp);
                     }
                     unsigned spins = 0;
                     for (;;) {
@@ -1938,7 +1986,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                                 break;
                             }
                         }
-                        fetch_row(acur, tp);
+                        if (RING) fetch_ring(acur, (s - 1) & (PS_RING - 1)); else fetch_row(acur, tp);
                     }
                     ASR_PF(1)
 #ifdef ASR_STAMP_DP
@@ -1989,7 +2037,12 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     if (act && !(u & 1)) {
                         unsigned packed = mine | (other << 16);
                         if (packed == 0xffffffffu) packed = 0x7fc07fc0u;
-                        __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, store_off + (unsigned)t * row_bytes, 0, 0);
+                        if (RING) {
+                            __builtin_amdgcn_raw_buffer_store_b32(packed, ringrsrc, ring_store_off + (unsigned)(s & (PS_RING - 1)) * slot_bytes, 0, 0);
+                            if (s >= 2) __builtin_amdgcn_raw_buffer_store_b32(0xffffffffu, ringrsrc, ring_store_off + (unsigned)((s - 2) & (PS_RING - 1)) * slot_bytes, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(packed, h16rsrc, store_off + (unsigned)t * row_bytes, 0, 0);
+                        }
                     }
                     if (s + 1 < T && lane == 0) lds_poke(s_abort + w, s + 1);
                     if (act) {
@@ -1998,7 +2051,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     }
                     if (s + 1 < T) {
                         poll_pause(poll_delay);
-                        fetch_row(ahead, t);
+                        if (RING) fetch_ring(ahead, s & (PS_RING - 1)); else fetch_row(ahead, t);
                     }
                     ASR_PF(5)
                 }
@@ -2998,11 +3051,14 @@ static bool can_persist(int T, int B, int H, int ndir, int mode, const void* syn
 
 // first-poll delay of the forward hand-off in s_sleep(1) units (~70 cycles each), see kFirstPollDelay: measured per H (the number of
 // producers of a recurrence, H / 16, shifts the moment the last store lands); ASR_GRU_POLL_DELAY overrides
-static int fwd_poll_delay(int H) {
+static int fwd_poll_delay(int H, bool ring) {
     static int env = -2;
     if (env == -2) { const char* e = getenv("ASR_GRU_POLL_DELAY"); env = e ? atoi(e) : -1; }
     if (env >= 0) return env > 255 ? 255 : env;
-    // T=1000, B=32, us per step at 0 / best: H=512 1.49 / 1.34 (11), H=384 1.41 / 1.39 (2-4), H=256 1.156 / 1.137 (2-4), H=128 1.24 / 1.21 (6-12)
+    // T=1000, B=32, us per step at 0 / best.  Ring form (whole-line stores into L2-resident slots): H=512 1.30 / 1.23 (5-6),
+    // H=384 1.20 / 1.18 (3), H=256 1.03 / 1.00 (3), H=128 1.20 flat.  Sequence form (32-B pieces of fresh lines): H=512 1.49 / 1.34 (11),
+    // H=384 1.41 / 1.39 (2-4), H=256 1.156 / 1.137 (2-4), H=128 1.24 / 1.21 (6-12)
+    if (ring) return H >= 512 ? 6 : 3;
     return H >= 512 ? kFirstPollDelay : (H >= 256 ? 3 : 6);
 }
 
@@ -3076,19 +3132,25 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
         const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
         // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
         const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
-        if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
-        const int forge_k = forge | (fwd_poll_delay(H) << 8);
+        static int ring_env = -1;
+        if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }      // (0: the payload is polled in the bf16 sequence itself)
+        const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
+        if (use_ring) {
+            if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)8 * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
+        } else if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
+        const int forge_k = forge | (fwd_poll_delay(H, use_ring) << 8);
         const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
-#define ASR_FWDIO_(K, L, G)                                                                                               \
+#define ASR_FWDIO_(K, L, G, R)                                                                                            \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G, R>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
                            (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge_k : 0);         \
     } while (0)
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \
-        if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true); else ASR_FWDIO_(K, true, false); }                           \
-        else { if (gi_bf16) ASR_FWDIO_(K, false, true); else ASR_FWDIO_(K, false, false); }                               \
+        if (use_ring) { if (gi_bf16) ASR_FWDIO_(K, true, true, true); else ASR_FWDIO_(K, true, false, true); }            \
+        else if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true, false); else ASR_FWDIO_(K, true, false, false); }        \
+        else { if (gi_bf16) ASR_FWDIO_(K, false, true, false); else ASR_FWDIO_(K, false, false, false); }                 \
     } while (0)
         if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
 #undef ASR_FWDIO_
