@@ -630,17 +630,10 @@ __device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribu
 // the pause in front of a first poll: one s_sleep with an immediate for the values the host hands out (a loop of s_sleep(1) costs
 // the chain ~0.02 us more: 1.369 against 1.347 us per step), the loop for anything else (ASR_GRU_POLL_DELAY)
 __device__ __forceinline__ void poll_pause(int n) {
-    switch (n) {
-        case 0: break;
-        case 3: __builtin_amdgcn_s_sleep(3); break;
-        case 4: __builtin_amdgcn_s_sleep(4); break;
-        case 5: __builtin_amdgcn_s_sleep(5); break;
-        case 6: __builtin_amdgcn_s_sleep(6); break;
-        case 7: __builtin_amdgcn_s_sleep(7); break;
-        case 8: __builtin_amdgcn_s_sleep(8); break;
-        case 11: __builtin_amdgcn_s_sleep(11); break;
-        default: for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
+    if (n == 6) __builtin_amdgcn_s_sleep(6);
+    else if (n == 3) __builtin_amdgcn_s_sleep(3);
+    else if (n == 11) __builtin_amdgcn_s_sleep(11);
+    else for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 
 __device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
