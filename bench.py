@@ -494,13 +494,13 @@ def main():
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_v8.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_v9.json")
         if os.path.exists(pmc_path):
             ks = json.load(open(pmc_path))["kernels"]
             sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k or "gru::bwd_ps_kernel" in k]
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
-                traffic_src = "profiles/r02_pmc_traffic_v8.json"
+                traffic_src = "profiles/r02_pmc_traffic_v9.json"
         out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
                            "fwd_us_per_time_step": tot["gru_fwd"][0] * 1e3 / tot["gru_fwd"][1] / T, "bwd_us_per_time_step": tot["gru_bwd"][0] * 1e3 / tot["gru_bwd"][1] / T,
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
