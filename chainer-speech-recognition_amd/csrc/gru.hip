@@ -275,10 +275,6 @@ constexpr unsigned kSpinLimit = 1u << 22;
 #ifndef ASR_BWD_POLL_DELAY
 #define ASR_BWD_POLL_DELAY 0
 #endif
-#ifndef ASR_COMP_AFTER_BARRIER
-#define ASR_COMP_AFTER_BARRIER 0
-#endif
-constexpr int kCompAfterBarrier = ASR_COMP_AFTER_BARRIER;
 #ifndef ASR_TOUCH
 #define ASR_TOUCH 1
 #endif
@@ -1951,15 +1947,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     if (gate_wave) {
 #pragma unroll
                         for (int i2 = 0; i2 < NA; ++i2) acur[i2].u = ahead[i2].u;
-                    } else if (kCompAfterBarrier > 0) {
-                        // no flag: the gate waves of every workgroup take the same time from the step's barrier to their store, so the
-                        // two pure compute waves time their first poll from the barrier as well (the flag -- an LDS word polled with
-                        // s_sleep(1) -- made them ask ~300 cycles later than the gate waves, which then waited for them at the
-                        // next barrier); a poll that is too early is retried like any other
-                        __builtin_amdgcn_s_sleep(kCompAfterBarrier);
-                        fetch_row(acur, tp);
                     } else {
                         unsigned nap = 0;
+                        // (timing this first poll from the step's barrier instead of the gate waves' flag measured worse: 1.35-1.38
+                        // against 1.33 us per step)
                         while ((lds_peek(s_abort + 2) < s || lds_peek(s_abort + 3) < s) && !lds_peek(s_abort) && ++nap < kSpinLimit)
                             __builtin_amdgcn_s_sleep(1);
                         poll_pause(poll_delay);

@@ -703,3 +703,16 @@ def test_tn256_kernel_in_a_forced_process():
                           "-k", "test_gemm_tn_acc or test_implicit_conv or test_gru_step_kernels"], env=env, capture_output=True,
                          text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_forward_recurrence_without_the_ring_in_a_forced_process():
+    """the forward hand-off normally goes through the L2-resident ring; ASR_FWD_RING=0 (read once per process) polls the payload in the
+    bf16 state sequence instead (sentinel fill + pre-touch): the recurrence tests of this file must pass on that path as well"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_FWD_RING="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gru_step_kernels or test_gru_full_size_forms_agree"], env=env, capture_output=True,
+                         text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
