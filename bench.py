@@ -508,8 +508,9 @@ def main():
                            "ms_per_launch": per_launch_s * 1e3, "launches_per_step": launches,
                            "us_per_time_step": per_launch_s * 1e6 / T, "algorithmic_bytes_per_launch": alg,
                            "note": "latency-bound recurrence (8000 dependent steps per train step): neither roofline binds -- a step is one "
-                                   "cross-CU hand-off through the L2 (MI355X_MICROARCH.md price list: 0.8-1.0 us for <= 4 KB) plus ~0.5 us of "
-                                   "MFMA / gate work; see DESIGN.md section 5; HBM-bound CTC sweep and MFMA-bound GEMMs reported beside it"}
+                                   "cross-CU hand-off through the L2 (whole-line stores into an L2-resident ring, ~0.16 us to land, + one timed "
+                                   "poll, ~0.38 us round trip) plus ~0.6 us of MFMA / LDS exchange / gate work; see DESIGN.md sections 5 and 11.4; "
+                                   "HBM-bound CTC sweep and MFMA-bound GEMMs reported beside it"}
         ctc_bytes = 2.0 * T * B * V * 4
         ctc_ms = ctc["ctc_forward"] + ctc["ctc_grad"]
         out["roofline_ctc_sweep"] = {"bound": "hbm", "achieved": ctc_bytes / (ctc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
