@@ -57,8 +57,22 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src, uint16_t* _
 // first_tile ascending; a tile is 64 x 64 elements of src.
 __global__ void __launch_bounds__(256) cast_many_kernel(const long long* __restrict__ jobs, int njobs) {
     __shared__ float tile[64][65];
+    __shared__ long long first_tile[256];
+    // which job owns this tile: the first_tile column goes to LDS in one load per thread and is searched there (a linear walk over
+    // the table in global memory cost the workgroups of the last jobs ~40 dependent L2 round trips before their first byte of work)
     int j = 0;
-    while (j + 1 < njobs && (long long)blockIdx.x >= jobs[(j + 1) * 6 + 5]) ++j;
+    if (njobs <= 256) {
+        if ((int)threadIdx.x < njobs) first_tile[threadIdx.x] = jobs[threadIdx.x * 6 + 5];
+        __syncthreads();
+        int lo = 0, hi = njobs - 1;                 // last job whose first_tile <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (first_tile[mid] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        j = lo;
+    } else {
+        while (j + 1 < njobs && (long long)blockIdx.x >= jobs[(j + 1) * 6 + 5]) ++j;
+    }
     const float* __restrict__ src = (const float*)jobs[j * 6 + 0];
     uint16_t* __restrict__ dst = (uint16_t*)jobs[j * 6 + 1];
     const int rows = (int)jobs[j * 6 + 2], cols = (int)jobs[j * 6 + 3];
