@@ -1482,13 +1482,17 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 
     for (int s = 0; s < T; ++s) {
         float rcr = 0.f;
-        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f;
+        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f, dyc = 0.f, f_an = 0.f, f_az = 0.f, f_ar = 0.f;
         if (gate_wave) {
             const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
             const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
             r = of[0]; z = of[128]; n = of[256]; qq = of[384];
             hp = s < T - 1 ? of[512] : 0.f;
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
+            dyc = dyy + carry;                          // dh = dy + z dh' + (the exchanged sum)
+            f_an = (1.0f - z) * (1.0f - n * n);         // dan = dh (1 - z)(1 - n^2)
+            f_az = (hp - n) * z * (1.0f - z);           // daz = dh (h' - n) z (1 - z)
+            f_ar = qq * r * (1.0f - r);                 // dar = dan q r (1 - r)
             ASR_PS(0)
             if (s > 0) {
                 // P_{s-1}: the first attempt was issued right behind this wave's own stores of the previous step
@@ -1552,13 +1556,12 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 #pragma unroll
                 for (int gq = 0; gq < 8; ++gq) rcr += rr_[gq * 128];
             }
-            const float dh = dyy + carry + rcr;
-            const float dn = dh * (1.0f - z);
-            const float dz = dh * (hp - n);
-            const float dan = dn * (1.0f - n * n);
-            const float daz = dz * z * (1.0f - z);
+            // (the factors that do not depend on dh were formed at the top of the step, under the hand-off's round trip)
+            const float dh = dyc + rcr;
+            const float dan = dh * f_an;
+            const float daz = dh * f_az;
             const float dq = dan * r;
-            const float dar = dan * qq * r * (1.0f - r);
+            const float dar = dan * f_ar;
             carry = dh * z;
             const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
             if (act) { sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq); }
