@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+PARITY_GATE_LOSS, PARITY_GATE_GRAD = 2e-3, 1e-2      # bench line's own gate against the rounding-matched oracle (tests: 1e-3 / 5e-3)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
@@ -48,6 +49,10 @@ def parse():
                          "branch, always 8 conv layers (822 GFLOP/utterance): run/ctc/cnn/model.py:153-157,177-187")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (Gram-CTC at configs[3] size, the two configs[4] CNN steps, "
+                                                           "the ragged-length step)")
+    ap.add_argument("--ragged", action="store_true", help="time the step on the ragged batch of SURVEY 8d (x_length ~ U{600..T}, "
+                                                          "length-exact recurrences) instead of full-length utterances")
     ap.add_argument("--halves", type=int, default=int(os.environ.get("ASR_BENCH_HALVES", "0")),
                     help="1: the batch as two concurrent half batches (asr/pipeline.py; measured slower at the BASELINE "
                          "configuration, DESIGN.md section 5), 0: one stream (default)")
@@ -176,21 +181,46 @@ def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
         def cos(a, b):
             a, b = a.double().flatten(), b.double().flatten()
             return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+        def rel(a, b):
+            a, b = a.double().flatten(), b.double().flatten()
+            return float((a - b).norm() / (b.norm() + 1e-30))
         logits = torch.stack(tuple(ys)).detach().float().cpu()
-        worst, worst_name, norm_ratio = 1.0, None, []
+        worst, worst_name, norm_ratio, rel32 = 1.0, None, [], {}
         for name, p in gpu.named_parameters():
             gr = ref.g(name).grad
             c = cos(p.grad.detach().cpu(), gr)
+            rel32[name] = rel(p.grad.detach().cpu(), gr)
             norm_ratio.append(float(p.grad.detach().cpu().double().norm() / (gr.double().norm() + 1e-30)))
             if c < worst:
                 worst, worst_name = c, name
-        parity = {"against": "oracle/model.py (torch-CPU fp32), same B=%d batch and initial parameters, T=%d, V=%d" % (B, T, V),
-                  "loss_gpu": float(loss.item()), "loss_oracle": float(loss_ref.item()),
-                  "loss_rel": abs(float(loss.item()) - float(loss_ref.item())) / abs(float(loss_ref.item())),
-                  "logits_cos": cos(logits, logits_ref.detach()), "worst_param_grad_cos": worst,
-                  "worst_param": worst_name, "grad_norm_ratio_min_max": [min(norm_ratio), max(norm_ratio)],
-                  "note": "bf16 activations / MFMA operands against fp32: BASELINE.md section 3 expects ~1e-2 on the loss; "
-                          "the CTC kernel itself is held to 1e-4 on identical logits (tests/test_ctc_gpu.py)"}
+        # the gate: the SAME step on the rounding-matched oracle (oracle/bf16.py: bf16 roundings where the device rounds, float32
+        # accumulation) -- what is left is summation order, the fast exp / rcp of the gate math and float32-vs-float64 CTC
+        from asr import _ops as _o
+        H = cfg.ndim_rnn
+        refm = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, cfg.bidirectional, matched=True,
+                                gi_bf16=(_o.gru_gi_dtype(T, B, H, 2 if cfg.bidirectional else 1) == torch.bfloat16),
+                                fused_logit_bias=(V % 4 == 0))
+        logits_m = refm(x)
+        loss_m = omodel.ctc_mean_loss(logits_m, labels, x_len, l_len)
+        loss_m.backward()
+        relm = {name: rel(p.grad.detach().cpu(), refm.g(name).grad) for name, p in gpu.named_parameters()}
+        wm = max(relm, key=relm.get)
+        w32 = max(rel32, key=rel32.get)
+        gate = {"loss_rel_max": PARITY_GATE_LOSS, "grad_rel_l2_max": PARITY_GATE_GRAD}
+        loss_rel_m = abs(float(loss.item()) - float(loss_m.item())) / abs(float(loss_m.item()))
+        parity = {"against": "oracle/model.py on the same B=%d batch and initial parameters, T=%d, V=%d: (matched) bf16 roundings where the "
+                             "device rounds -- the gate; (fp32) plain float32 -- the price of bf16, reported" % (B, T, V),
+                  "loss_gpu": float(loss.item()), "loss_oracle_matched": float(loss_m.item()), "loss_oracle_fp32": float(loss_ref.item()),
+                  "matched": {"loss_rel": loss_rel_m, "logits_rel_l2": rel(logits, logits_m.detach()),
+                              "worst_param_grad_rel_l2": relm[wm], "worst_param": wm},
+                  "fp32": {"loss_rel": abs(float(loss.item()) - float(loss_ref.item())) / abs(float(loss_ref.item())),
+                           "logits_cos": cos(logits, logits_ref.detach()), "worst_param_grad_cos": worst, "worst_param_cos": worst_name,
+                           "worst_param_grad_rel_l2": rel32[w32], "worst_param": w32,
+                           "grad_norm_ratio_min_max": [min(norm_ratio), max(norm_ratio)]},
+                  "gate": gate, "pass": bool(loss_rel_m <= PARITY_GATE_LOSS and relm[wm] <= PARITY_GATE_GRAD),
+                  "note": "the CTC kernel itself is held to 1e-4 on identical logits (tests/test_ctc_gpu.py)"}
+        del refm
         del gpu, ys, loss
         for p in ref.parameters():
             p.grad = None
@@ -208,6 +238,23 @@ def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
     out = {"value": B / dt, "unit": "utterances/s", "cores": cores, "kind": "port",
            "sample": "%d train steps of B=%d utterances (T=%d, V=%d, same model, fp32, torch-CPU oracle) after 2 warm-up; %.2f s/step"
                      % (n, B, T, V, dt)}
+    # also n = 1 thread (one utterance, one timed step after one warm-up: ~20 s)
+    torch.set_num_threads(1)
+    x1, l1, xl1, ll1 = x[:1], labels[:1], x_len[:1], l_len[:1]
+    omodel.train_step(ref, mm, vv, 9, x1, l1, xl1, ll1)
+    t0 = time.time()
+    omodel.train_step(ref, mm, vv, 10, x1, l1, xl1, ll1)
+    one_thread = time.time() - t0
+    torch.set_num_threads(cores)
+    out["one_thread"] = {"value": 1.0 / one_thread, "unit": "utterances/s", "cores": 1,
+                         "sample": "1 train step of B=1 utterance after 1 warm-up; %.2f s/step" % one_thread}
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        out["cpu_model"] = names[0] if names else None
+        out["host_logical_cpus"] = len(names)
+    except OSError:
+        pass
     return out, parity
 
 
@@ -319,15 +366,208 @@ def cpu_baseline_cnn(cfg, T, V, dev=None, seconds_budget=25.0):
                       % (n, B, T, V, dt)}, parity
 
 
+def time_gram_ctc(dev, T=1000, B=32, V=3000, L=120, iters=10):
+    """BASELINE configs[3]: the Gram-CTC loss + gradient (asr_ctc_loss_grad, gram = 1) as a stand-alone operator at its own size:
+    unigram ids U{1..118}, bigram ids U{119..V-1} with 30 % absent, label lengths U{40..120} -> N = 3L+1 <= 361 lattice nodes"""
+    from asr import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(T, B, V, generator=g).to(dev)
+    lab = torch.randint(1, 119, (B, L), generator=g, dtype=torch.int32).to(dev)
+    big = torch.randint(119, V, (B, L), generator=g, dtype=torch.int32)
+    big[torch.rand(B, L, generator=g) < 0.3] = -1
+    big[:, 0] = -1
+    big = big.to(dev)
+    tl = torch.randint(40, L + 1, (B,), generator=g, dtype=torch.int32).to(dev)
+    res = {}
+    for gram in (1, 0):
+        n = lib.asr_ctc_workspace_bytes(T, B, V, L, gram)
+        ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        loss, lm, grad = torch.empty(B, device=dev), torch.empty((), device=dev), torch.empty_like(xs)
+        s = torch.cuda.current_stream()
+
+        def run():
+            rc = lib.asr_ctc_loss_grad(s.cuda_stream, xs.data_ptr(), lab.data_ptr(), big.data_ptr() if gram else None, None, tl.data_ptr(),
+                                       T, B, V, L, 0, 1.0 / B, loss.data_ptr(), lm.data_ptr(), grad.data_ptr(), ws.data_ptr(), n)
+            assert rc == 0, rc
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(iters):
+            run()
+        e1.record(s)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        alg = 2.0 * T * B * V * 4
+        res["gram_ctc" if gram else "ctc_same_batch"] = {"ms": ms, "algorithmic_bytes": alg, "achieved_GBps": alg / ms / 1e6,
+                                                        "frac_of_hbm_peak": alg / ms / 1e6 / HBM_PEAK_GBPS, "loss_mean": float(lm.item())}
+    res["workload"] = "BASELINE configs[3]: Gram-CTC loss + gradient, T=%d, B=%d, V=%d, L<=%d (N<=%d nodes, 7 diagonals), 30%% bigrams absent" \
+                      % (T, B, V, L, 3 * L + 1)
+    return res
+
+
+def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
+    """BASELINE configs[4] on ONE GPU: one train step of the `zhang+residual` recipe (4 conv layers / the wide 8-layer branch), B=32,
+    T=1000, V=119: ms per step, utterances/s and the MFMA fraction of its GEMM-class time"""
+    import copy
+    from asr import _ops
+    from asr import functions as asr_functions
+    from asr.model.architectures import build_model
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import Adam, GradientClipping, WeightDecay
+    from asr.data.synthetic import synthetic_batch
+    a = copy.copy(args)
+    a.num_conv_layers = nconv
+    B, T, V = 32, args.frames, 119
+    torch.manual_seed(0)
+    cfg = cnn_config(a, V)
+    model = build_model(cfg).to_gpu(dev.index)
+    x, labels, x_len, l_len = (t.to(dev) for t in synthetic_batch(B, T, V, seed=0))
+    with torch.no_grad():
+        model(x)
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    opt.add_hook(WeightDecay(1e-5))
+
+    def step():
+        loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
+        opt.update(lossfun=lambda: loss)
+        return loss
+    dt, _, loss = timed_region(step, steps, warmup, None, torch.cuda.synchronize)
+    census = Census()
+    census.wrap(_ops)
+    asr_functions._SIDE["enabled"] = False
+    step()
+    torch.cuda.synchronize()
+    census.events = []
+    step()
+    tot = census.totals()
+    asr_functions._SIDE["enabled"] = True
+    census.unwrap()
+    macs = cnn_macs_per_frame(cfg)
+    gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
+    flops = 3 * 2.0 * macs * T * B
+    res = {"workload": "BASELINE configs[4] on one GPU: zhang+residual, %s, ndim_h 128, ndim_dense 320, B=%d, T=%d, V=%d, bf16 (see dtype_note)"
+                       % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V),
+           "ms_per_step": dt / steps * 1e3, "utterances_per_s": B * steps / dt, "steps": steps, "final_loss": float(loss.item()),
+           "gflop_per_utterance": 3 * 2.0 * macs * T / 1e9,
+           "roofline": {"bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "ms": gemm_ms, "traffic": None}}
+    del model, opt
+    torch.cuda.empty_cache()
+    return res
+
+
+def sq_profile():
+    """per-kernel SQ counter summary of a `bench.py` step (rocprofv3 --pmc passes condensed by tools/pmc_sq.py into profiles/): a
+    process cannot read its own PMC counters, so the line quotes the committed pass of this same command"""
+    for name in ("r03_pmc_sq.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path)), "profiles/" + name
+            except ValueError:
+                pass
+    return None, None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE): start N fresh rank processes through torch.distributed.run
+    BEFORE this process has touched the GPU (it never does), relay rank 0's JSON line, exit with the children's status.  Never an
+    exec of a process that initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no WORLD_SIZE in the environment: starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            log("[ranks] " + out)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    if rc != 0 or line is None:
+        raise SystemExit(rc if rc != 0 else 1)
+
+
+def timed_region(step, steps, warmup, comm, sync, dev=None):
+    """the contract's timed region: W untimed steps, barrier + synchronize, K steps, synchronize + barrier, MAX over ranks"""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    sync()
+    if comm is not None:
+        comm.barrier()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    sync()
+    if comm is not None:
+        comm.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    per_rank = [dt]
+    if comm is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if comm.backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(t) for _ in range(comm.size)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(g.item()) for g in gathered]
+        dt = max(per_rank)
+    return dt, per_rank, last
+
+
+def rehearse(args, world, rank):
+    """ASR_BENCH_REHEARSE=1: the multi-rank control flow of this file -- rendezvous, Communicator, sliced all-reduce joined before the
+    'optimiser', barrier + max-over-ranks timing, the JSON line -- with gloo on CPU tensors and NO GPU: a stand-in step sums a flat
+    buffer over the ranks.  tests/test_parallel_cpu.py runs `bench.py --gpus 2` this way; the numbers mean nothing."""
+    from asr.parallel import Communicator
+    comm = Communicator("gloo", buckets=3) if world > 1 else None
+    flat = torch.full((4096,), float(rank + 1))
+
+    def step():
+        g = flat.clone()
+        if comm is not None:
+            torch.distributed.all_reduce(g)
+        return float(g[0])
+    dt, per_rank, last = timed_region(step, args.steps, args.warmup, comm, lambda: None)
+    if rank == 0:
+        print(json.dumps({"metric": "utterances/sec (T=1000, 40x3 feat, |V|~3000) CTC train step", "value": world * args.batch * args.steps / dt,
+                          "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "rehearsal", "data": "none",
+                          "config": {"workload": "REHEARSAL of the multi-rank control flow (gloo, CPU, no model)", "global_batch": world * args.batch,
+                                     "parallelism": "dp%d" % world, "check": last},
+                          "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank]}))
+    if comm is not None:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.vocab is None:
         args.vocab = 3000 if args.config == "ds2" else 119
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("ASR_BENCH_REHEARSE") == "1":
+        return rehearse(args, world, rank)
     # ASR_BENCH_BACKEND=gloo + ASR_BENCH_ONE_DEVICE=1: rehearse the multi-rank control flow with several processes on
     # ONE GPU (no RCCL between ranks of one device); the numbers of such a run mean nothing
     if os.environ.get("ASR_BENCH_ONE_DEVICE") == "1":
@@ -346,6 +586,7 @@ def main():
     if world > 1 or os.environ.get("ASR_BENCH_FORCE_COMM") == "1":      # the latter: exercise the RCCL path on one GPU
         from asr.parallel import Communicator
         comm = Communicator(os.environ.get("ASR_BENCH_BACKEND", "nccl"))
+        comm.measure = True
 
     B, T, V = args.batch, args.frames, args.vocab
     torch.manual_seed(0)                         # identical initial weights on every rank (also broadcast below)
@@ -357,8 +598,9 @@ def main():
         cfg = ds2.configure()
         cfg.vocab_size = V
         model = ds2.Model(cfg).to_gpu(local_rank)
-    x, labels, x_len, l_len = synthetic_batch(B, T, V, seed=rank)
+    x, labels, x_len, l_len = synthetic_batch(B, T, V, seed=rank, ragged=args.ragged)
     x, labels, x_len, l_len = x.to(dev), labels.to(dev), x_len.to(dev), l_len.to(dev)
+    model_kw = {"x_length": x_len} if (args.ragged and args.config == "ds2") else {}
     if args.config == "cnn":
         with torch.no_grad():
             model(x)                             # the recipes size their layer norms lazily: materialise before opt.setup
@@ -379,34 +621,27 @@ def main():
     def half_loss(sl):
         return connectionist_temporal_classification(model(x[sl]), labels[sl], 0, x_len[sl], l_len[sl])
 
+    exposed = []
+
     def step():
         if pipe is not None:
             return pipe.step(opt, half_loss, B, stagger_us=0)
-        loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
+        loss = connectionist_temporal_classification(model(x, **model_kw), labels, 0, x_len, l_len)
         opt.update(lossfun=lambda: loss)
+        if comm is not None:
+            exposed.append(list(comm.exposed))
         return loss
 
-    log("rank %d/%d: model built, warm-up" % (rank, world))
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    log("timing %d steps" % args.steps)
-    if comm is not None:
-        comm.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if comm is not None:
-        comm.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if comm is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = tmax.item()
+    log("rank %d/%d: model built, warm-up %d + timing %d steps" % (rank, world, args.warmup, args.steps))
+    dt, per_rank, loss = timed_region(step, args.steps, args.warmup, comm, torch.cuda.synchronize, dev)
     loss_value = loss.item()
+    exposed_ms = None
+    if comm is not None:
+        # time the launch stream stood still waiting for collectives (events around every join), per step, this rank and max
+        mine = sum(a.elapsed_time(b) for pairs in exposed[-args.steps:] for a, b in pairs) / args.steps
+        t = torch.tensor([mine], device=dev if comm.backend == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        exposed_ms = {"rank0": mine, "max_over_ranks": float(t.item())}
 
     if rank != 0:
         return
@@ -415,6 +650,10 @@ def main():
     out = {"metric": "utterances/sec (T=1000, 40x3 feat, |V|~3000) CTC train step", "value": value, "unit": "utterances/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "dtype_note": "bf16 MFMA operands / activations, float32 accumulation, master weights, optimiser state, statistics, logits and "
+                         "CTC; bf16 also stands in for the fp16 of BASELINE configs[4] (same MFMA rate on gfx950, no loss scaling needed: "
+                         "DESIGN.md section 11.1) -- no fp16 path exists",
+           "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
            "config": {"workload": ("BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
                                    "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V)) if args.config == "ds2" else
                                   ("BASELINE configs[4]: fully convolutional zhang+residual (run/ctc/cnn/model.py:142-204), ndim_h 128, "
@@ -422,7 +661,10 @@ def main():
                                    "bf16 MFMA operands (the deliberate substitute for fp16: DESIGN.md section 4)"
                                    % ("4 conv layers" if args.num_conv_layers <= 4 else "wide branch: 8 conv layers", B, T, V)),
                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
-                      "final_loss": loss_value}}
+                      "final_loss": loss_value,
+                      "x_length": "U{600..%d}, length-exact recurrences (x_length passed to the model)" % T if args.ragged else "all %d" % T}}
+    if exposed_ms is not None:
+        out["allreduce_exposed_ms_per_step"] = exposed_ms
 
     # which hand-off the persistent GRU kernels of the last launch agreed on (decided inside the launch: DESIGN.md section 5)
     if _ops.LAST_SYNC[0] is not None:
@@ -501,7 +743,9 @@ def main():
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
                 traffic_src = "profiles/r02_pmc_traffic_v9.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
+        out["roofline"] = {"bound": "latency", "priced_against": "hbm",
+                           "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
+                           "hop_price_us": "0.8-1.0 (MI355X_MICROARCH.md: one producer -> consumer hop through the L2, <= 4 KB, idle chip)",
                            "fwd_us_per_time_step": tot["gru_fwd"][0] * 1e3 / tot["gru_fwd"][1] / T, "bwd_us_per_time_step": tot["gru_bwd"][0] * 1e3 / tot["gru_bwd"][1] / T,
                            "achieved": alg / per_launch_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": alg / per_launch_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -540,10 +784,42 @@ def main():
         out["roofline_gemm"] = {"bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                 "ms": gemm_ms}
+        sq, sq_src = sq_profile()
+        if sq is not None:
+            # MFMA utilisation of the GEMM kernels that ship (north_star: "MFMA utilisation for the GEMM blocks against gfx950 peak"):
+            # SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per kernel over one bench step (rocprofv3 --pmc, tools/pmc_sq.py)
+            out["roofline_gemm"]["mfma_busy_frac"] = {k: v.get("mfma_busy_frac") for k, v in sq.get("kernels", {}).items()
+                                                      if "gemm" in k}
+            out["roofline_gemm"]["mfma_busy_source"] = sq_src
+    if world == 1 and not args.no_extra and args.config == "ds2" and not args.ragged:
+        log("extra configs: ragged step, Gram-CTC at configs[3] size, configs[4] CNN steps")
+        extra = {}
+        # SURVEY 8d's ragged variant: the same model and optimiser on x_length ~ U{600..T}, recurrences length-exact
+        from asr.data.synthetic import synthetic_batch as _sb
+        xr, lr, xlr, llr = (t.to(dev) for t in _sb(B, T, V, seed=1, ragged=True))
+
+        def ragged_step():
+            loss_r = connectionist_temporal_classification(model(xr, x_length=xlr), lr, 0, xlr, llr)
+            opt.update(lossfun=lambda: loss_r)
+            return loss_r
+        dtr, _, lossr = timed_region(ragged_step, 5, 2, None, torch.cuda.synchronize)
+        extra["ds2_ragged"] = {"workload": "configs[1] with x_length ~ U{%d..%d} (mean %.0f), length-exact BiGRU (reverse direction starts at each "
+                                           "utterance's last frame)" % (int(0.6 * T), T, float(xlr.float().mean().item())),
+                               "ms_per_step": dtr / 5 * 1e3, "utterances_per_s": B * 5 / dtr, "final_loss": float(lossr.item())}
+        extra["gram_ctc"] = time_gram_ctc(dev, T, B, V, 120)
+        del model, opt
+        torch.cuda.empty_cache()
+        extra["cnn_4conv"] = time_cnn_config(args, 4, dev)
+        extra["cnn_wide8"] = time_cnn_config(args, 8, dev)
+        out["extra_configs"] = extra
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, T, V, dev)
         out["gpu_vs_cpu"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    sys.stdout.flush()
+    if out.get("parity") is not None and out["parity"].get("pass") is False:
+        log("PARITY GATE FAILED: %s" % json.dumps(out["parity"]["matched"]))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -93,8 +93,8 @@ SIGNATURES = {
     "asr_weightnorm_init": (c_int, [c_void_p] * 5 + [c_int]),
     "asr_gru_sync_bytes": (c_size_t, [c_int] * 3),
     "asr_gru_fwd_accepts_bf16_gi": (c_int, [c_int] * 5),
-    "asr_gru_fwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_int]),
-    "asr_gru_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_int]),
+    "asr_gru_fwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_int, c_void_p]),
+    "asr_gru_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p]),
     "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4),
     "asr_sru_bwd": (c_int, [c_void_p] * 13 + [c_int] * 4),
     "asr_sru_combine": (c_int, [c_void_p] * 5 + [c_longlong, c_int]),
@@ -103,7 +103,8 @@ SIGNATURES = {
     "asr_clip_decay_sgd": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 5 + [c_void_p]),
     "asr_clip_decay_adam": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 7 + [c_void_p, c_int]),
     "asr_sqnorm_partials_count": (c_int, [c_longlong]),
-    "asr_step_control": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2),
+    "asr_gather_abort": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "asr_step_control": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2 + [c_int]),
     "asr_adam_ctl": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 4 + [c_void_p]),
     "asr_sgd_ctl": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 3 + [c_void_p]),
 }

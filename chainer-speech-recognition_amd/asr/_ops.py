@@ -351,6 +351,13 @@ def gru_poll_status():
             st[1] = ev
 
 
+def reset_poll_status():
+    """forget the abort-word copies in flight (the optimiser has just reported and cleared the words)"""
+    for st in _STATUS.values():
+        st[0][0] = 0
+        st[1] = None
+
+
 # asr.parallel hangs two callables here during a data-parallel backward pass: "before" runs before a recurrence is
 # queued (the launch stream then waits for every collective in flight), "after" right behind it (complete gradient slices
 # are all-reduced in the gap that follows).  A persistent recurrence wants every CU; see asr/parallel.py.
@@ -374,15 +381,25 @@ def gru_gi_dtype(T, B, H, ndir):
     return F32
 
 
-def gru_fwd(gi, whh16, bhh, T, B, H, ndir):
+def _len_i32(x_len, B, dev):
+    if x_len is None:
+        return None
+    if x_len.dtype != torch.int32 or x_len.numel() != B or x_len.device != dev:
+        raise ValueError("x_length must be %d int32 frame counts on %s" % (B, dev))
+    return x_len.contiguous()
+
+
+def gru_fwd(gi, whh16, bhh, T, B, H, ndir, x_len=None):
+    """x_len (B) int32 or None: per-utterance lengths (asr_hip.h: the dead rows' update-gate columns of gi are overwritten)"""
     dev = gi.device
+    x_len = _len_i32(x_len, B, dev)
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
     gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
     y = torch.empty((T * B, H), dtype=BF16, device=dev)
     rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), _is_bf16(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
-                                T, B, H, ndir, ptr(sync), GRU_MODE[0])
+                                T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len))
     check(rc, "asr_gru_fwd")
     LAST_SYNC[0] = sync
     return y, hseq, hseq16, gates
@@ -411,16 +428,18 @@ def gru_check_all():
         raise _lib.AsrHipError("a persistent GRU kernel gave up an in-launch wait: the outputs of that forward pass are invalid")
 
 
-def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None):
+def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None, x_len=None):
     """db_ih / db_hh: (ndir * 3H) f32 buffers the bias gradients are accumulated into (optional)."""
     dev = dy.device
+    x_len = _len_i32(x_len, B, dev)
+    dy_ws = torch.empty((T * B, H), dtype=BF16, device=dev) if x_len is not None else None
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
     _hook("before")
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
-                                ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0])
+                                ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len), ptr(dy_ws))
     check(rc, "asr_gru_bwd")
     _hook("after")
     LAST_SYNC[0] = sync
@@ -445,17 +464,38 @@ def clip_decay_adam(p, g, m, v, alpha, beta1, beta2, eps, weight_decay, clip, gr
 
 
 def abort_words():
-    """device pointers of the abort words of every control buffer a recurrence of this process has used (asr_hip.h: sync_ws
-    int 1023) -- what asr_step_control looks at to drop a step whose recurrences gave up"""
+    """the abort words of every control buffer a recurrence of this process has used (asr_hip.h: sync_ws int 1023)"""
     return [buf[1023:1024] for buf in _SYNC.values()]
 
 
-def step_control(g, partials, clip, grad_scale, alpha, beta1, beta2, applied, ctl):
-    words = [w for w in abort_words() if w.device == g.device][:2]
-    a0 = ptr(words[0]) if len(words) > 0 else None
-    a1 = ptr(words[1]) if len(words) > 1 else None
-    rc = _lib.lib().asr_step_control(stream(), ptr(g), g.numel(), ptr(partials), a0, a1, float(clip), float(grad_scale),
-                                     float(alpha), float(beta1), float(beta2), ptr(applied), ptr(ctl))
+_ABORT = {}         # device index -> [number of control buffers covered, device table of word addresses, the ORed word]
+
+
+def gather_abort(dev, poison=None):
+    """ONE device word = the OR of every abort word on `dev` (any number of control buffers: a process that ran recurrences on three
+    streams -- eval on the default stream, then two half-batch streams -- has three), queued on the current stream.  poison: an
+    element of the local gradient buffer that gets a NaN when a word is raised (data parallelism: every rank then drops the step)."""
+    words = [w for w in abort_words() if w.device == dev]
+    st = _ABORT.get(dev.index)
+    if st is None or st[0] != len(words):
+        table = torch.tensor([w.data_ptr() for w in words] or [0], dtype=torch.int64).to(dev)
+        st = _ABORT[dev.index] = [len(words), table, torch.zeros(1, dtype=torch.int32, device=dev)]
+    check(_lib.lib().asr_gather_abort(stream(), ptr(st[1]), len(words), ptr(st[2]), ptr(poison)), "asr_gather_abort")
+    return st[2]
+
+
+def clear_abort_words(dev):
+    for w in abort_words():
+        if w.device == dev:
+            w.zero_()
+
+
+def step_control(g, partials, clip, grad_scale, alpha, beta1, beta2, applied, ctl, any_abort=None, reserved_index=-1):
+    """any_abort: the word gather_abort returned for this step (None: gathered here); reserved_index: see asr_hip.h"""
+    if any_abort is None:
+        any_abort = gather_abort(g.device)
+    rc = _lib.lib().asr_step_control(stream(), ptr(g), g.numel(), ptr(partials), ptr(any_abort), None, float(clip), float(grad_scale),
+                                     float(alpha), float(beta1), float(beta2), ptr(applied), ptr(ctl), int(reserved_index))
     check(rc, "asr_step_control")
 
 

@@ -179,18 +179,32 @@ def ctc_box_of(xs):
 
 
 def _incoming_bf16(ctx, gy, width):
-    """the gradient of a producer's output as contiguous bf16 rows (-1, width): autograd's part + the mailbox's"""
+    """the gradient of a producer's output as contiguous bf16 rows (-1, width): autograd's part + the mailbox's.
+    Returns (total, autograd_part): autograd_part is None when autograd delivered only the zero token, i.e. the mailbox's
+    consumer was the only one -- a consumer that already added ITS column sums to the producer's bias gradient (bias_done) has
+    not seen what other consumers sent through autograd, so the producer still owes the bias the column sums of that part."""
     box = getattr(ctx, "_asr_mailbox", None)
     extra = box.take() if box is not None else None
     if extra is not None and _is_zero_token(gy):
-        return extra.reshape(-1, width)
+        return extra.reshape(-1, width), None
     gy = gy.contiguous()
     if gy.dtype != BF16:
         gy = _ops.cast_bf16(gy.reshape(-1, width))
     gy = gy.reshape(-1, width)
     if extra is not None:
-        gy = _ops.add_bf16(gy, extra.reshape(-1, width))
-    return gy
+        return _ops.add_bf16(gy, extra.reshape(-1, width)), gy
+    return gy, gy
+
+
+def _take_bias_done(ctx):
+    """read AND reset the "a consumer has added its column sums to my bias gradient" flags of this node's boxes"""
+    done = False
+    for attr in ("_asr_mailbox", "_asr_biasbox"):
+        box = getattr(ctx, attr, None)
+        if box is not None and box.bias_done:
+            done = True
+            box.bias_done = False          # consumed: a second backward pass over the same graph starts afresh
+    return done
 
 
 # ---------------------------------------------------------------------------------------------- layout helpers
@@ -322,11 +336,8 @@ class _Conv2D(torch.autograd.Function):
         col, w16t, wbwd = ctx.saved_tensors
         W, b = ctx.params
         B, Ci, Hin, T, Co, KH, KW, pad_h, pad_t, Tout, Hout, pointwise, xdtype, need_dx, implicit = ctx.meta
-        bbox = getattr(ctx, "_asr_biasbox", None)
-        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False) or (bbox is not None and bbox.bias_done)
-        if bbox is not None:
-            bbox.bias_done = False          # consumed: a second backward pass over the same graph starts afresh
-        gy = _incoming_bf16(ctx, gy, Co)
+        bias_done = _take_bias_done(ctx)
+        gy, gy_auto = _incoming_bf16(ctx, gy, Co)
         g2 = gy.reshape(Tout * B * Hout, Co)
         Kreal = KH * KW * Ci
         xphys = col if implicit else None        # the implicit forward saved the input, not a column matrix
@@ -365,8 +376,11 @@ class _Conv2D(torch.autograd.Function):
                 _ops.fill_(scratch, 0.0)
                 _ops.gemm_tn_acc(g2, col, scratch)
                 _ops.conv_weight_grad_unpack(scratch, gW)
-            if gb is not None and not bias_done:
-                _ops.colsum_acc(g2, gb)
+            if gb is not None:
+                if not bias_done:
+                    _ops.colsum_acc(g2, gb)
+                elif gy_auto is not None and getattr(ctx, "_asr_mailbox", None) is not None:
+                    _ops.colsum_acc(gy_auto, gb)        # the part another consumer of y sent through autograd
         if w_is_param:
             with _OnSide(g2, col):
                 weight_grads()
@@ -445,15 +459,18 @@ class _Dense(torch.autograd.Function):
     def backward(ctx, gy):
         x2, w16t = ctx.saved_tensors
         W, b = ctx.params
-        bias_done = getattr(getattr(ctx, "_asr_mailbox", None), "bias_done", False)
-        gy = _incoming_bf16(ctx, gy, W.shape[0])
+        bias_done = _take_bias_done(ctx)
+        gy, gy_auto = _incoming_bf16(ctx, gy, W.shape[0])
         gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         gW = grad_buffer(W).reshape(W.shape[0], -1)
         gb = grad_buffer(b) if b is not None else None
-        with _OnSide(gy, x2):
+        with _OnSide(gy, x2, gy_auto):
             _ops.gemm_tn_acc(gy, x2, gW)
-            if gb is not None and not bias_done:
-                _ops.colsum_acc(gy, gb)
+            if gb is not None:
+                if not bias_done:
+                    _ops.colsum_acc(gy, gb)
+                elif gy_auto is not None:
+                    _ops.colsum_acc(gy_auto, gb)        # the part another consumer of y sent through autograd
         grads_queued(W, b)
         return gx, None, None, None, None, None
 
@@ -811,23 +828,23 @@ class _GRU(torch.autograd.Function):
     """x rows (T*B, I) bf16 -> y rows (T*B, H) bf16 (directions summed)."""
 
     @staticmethod
-    def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir):
+    def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir, x_len):
         wih16, wih16t, whh16, whh16t = copies
         gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), _ops.gru_gi_dtype(T, B, H, ndir))
-        y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, b_hh.detach().reshape(-1), T, B, H, ndir)
+        y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, b_hh.detach().reshape(-1), T, B, H, ndir, x_len)
         ctx.save_for_backward(x2, hseq, hseq16, gates, wih16t, whh16t)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
-        ctx.meta = (T, B, H, ndir, ctx.needs_input_grad[0])
+        ctx.meta = (T, B, H, ndir, ctx.needs_input_grad[0], x_len)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x2, hseq, hseq16, gates, wih16t, whh16t = ctx.saved_tensors
         w_ih, w_hh, b_ih, b_hh = ctx.params
-        T, B, H, ndir, need_dx = ctx.meta
+        T, B, H, ndir, need_dx, x_len = ctx.meta
         gy = gy.contiguous()
         dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir, grad_buffer(b_ih).reshape(-1),
-                                grad_buffer(b_hh).reshape(-1))
+                                grad_buffer(b_hh).reshape(-1), x_len)
         gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None        # the only product on the critical path
         gwih = grad_buffer(w_ih).reshape(ndir * 3 * H, -1)
         gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
@@ -842,12 +859,15 @@ class _GRU(torch.autograd.Function):
                     else:
                         _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
         grads_queued(w_ih, w_hh, b_ih, b_hh)
-        return gx, None, None, None, None, None, None, None, None, None
+        return gx, None, None, None, None, None, None, None, None, None, None
 
 
-def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
+def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir, x_length=None):
     """x logical (B, I, T); parameters stacked over directions: w_ih (ndir, 3H, I), w_hh (ndir, 3H, H),
-    b_ih / b_hh (ndir, 3H).  Returns logical (B, H, T), the directions summed."""
+    b_ih / b_hh (ndir, 3H).  Returns logical (B, H, T), the directions summed.
+    x_length (B) int32 device tensor or None: frames per utterance -- the recurrences then run every utterance over its own
+    length as chainer.links.NStepBiGRU does (asr/nn/nn.py:3): the reverse direction of utterance b starts at x_length[b] - 1,
+    the output is zero beyond it and the padding receives / passes no gradient."""
     p = phys3(x)
     T, B, I = p.shape
     H = w_hh.shape[2]
@@ -857,7 +877,7 @@ def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir):
         link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape), "plain"),
         link.compute_copy("whh16t", w_hh, _cast_transposed_per_direction, "t_each"),
     )
-    y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir)
+    y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir, x_length)
     return logical3(y.reshape(T, B, H))
 
 

@@ -65,12 +65,19 @@ class Model(nn.Module):
         dense_blocks.add(logits, _PerFrame(norm))
         self.dense_blocks = dense_blocks
 
-    def __call__(self, x, split_into_variables=True):
+    def __call__(self, x, split_into_variables=True, x_length=None):
+        """x_length (B) int32 on the device (the Loader's x_length_batch, asr/data/loaders/base.py:30): the recurrent layers then
+        run every utterance over its own frames (the reverse direction starts at the utterance's last frame, not in the padding);
+        None = the padded block as it is."""
         batchsize = x.shape[0]
         seq_length = x.shape[3]
         out_data = self.conv_blocks(x)
         out_data = functions.reshape(out_data, (batchsize, -1, seq_length))
-        out_data = self.rnn_blocks(out_data)
+        if x_length is None:
+            out_data = self.rnn_blocks(out_data)
+        else:
+            for layer in self.rnn_blocks.layers:
+                out_data = layer(out_data, x_length) if isinstance(layer, (nn.GRU, nn.BiGRU)) else layer(out_data)
         out_data = self.dense_blocks(out_data)
         assert out_data.shape[2] == seq_length
         return split_output(out_data, batchsize, seq_length, split_into_variables)

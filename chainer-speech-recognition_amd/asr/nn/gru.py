@@ -27,11 +27,12 @@ class _GRUBase(Link):
         self.in_size = in_size
         self.w_ih.data = self._init((self.ndir, 3 * self.out_size, in_size)).to(self.w_ih.device)
 
-    def __call__(self, x):
-        """x (B, D, T) -> (B, H, T); bidirectional outputs are summed (Deep-Speech-2 style)."""
+    def __call__(self, x, x_length=None):
+        """x (B, D, T) -> (B, H, T); bidirectional outputs are summed (Deep-Speech-2 style).  x_length (B) int32 on the device:
+        run every utterance over its own length (NStepBiGRU semantics on the padded block; functions.gru)."""
         if self.w_ih.numel() == 0:
             self._initialize_params(x.shape[1])
-        return functions.gru(x, self.w_ih, self.w_hh, self.b_ih, self.b_hh, self, self.ndir)
+        return functions.gru(x, self.w_ih, self.w_hh, self.b_ih, self.b_hh, self, self.ndir, x_length)
 
 
 class GRU(_GRUBase):

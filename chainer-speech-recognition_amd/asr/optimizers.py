@@ -14,6 +14,7 @@ from . import _ops
 from .link import bump_weight_epoch, refresh_compute_copies
 
 F32 = torch.float32
+RESERVED = 64       # floats in front of the first parameter in the flat buffers: element 0 carries the cross-rank "gave up" mark
 
 
 class GradientClipping(object):
@@ -41,6 +42,7 @@ class Optimizer(object):
         self.communicator = None
         self.pipeline = None
         self._needs_broadcast = False
+        self._gave_up = [None, None]        # pinned host copy of ctl[5] of the previous step, event of that copy
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -56,6 +58,10 @@ class Optimizer(object):
         """Data parallelism: gradients are summed over ranks (RCCL) before the step and scaled by 1/world."""
         self.communicator = comm
         self._needs_broadcast = comm is not None    # the flat buffer (and the optimiser state with it) stays as it is
+        if comm is not None and self._flat is not None:
+            # a running optimiser: take rank 0's parameters and state NOW -- deferred to the next update the first data-parallel
+            # forward pass would still run on the rank-local weights (ADVICE r2)
+            self._broadcast_state()
 
     def set_pipeline(self, pipeline):
         """asr.pipeline.HalfBatches whose streams carry gradient kernels the update must wait for"""
@@ -67,19 +73,30 @@ class Optimizer(object):
             self.cleargrads()
             if self.communicator is not None:
                 self.communicator.begin_backward(self)
-            loss.backward()
+            try:
+                loss.backward()
+            except BaseException:
+                if self.communicator is not None:
+                    self.communicator.abort_backward()      # no listener / recurrence hooks left behind
+                raise
         self._ensure_flat()
         from .functions import join_side_stream
         if self.pipeline is not None:
             self.pipeline.join()            # gradient kernels of the two half batches (asr/pipeline.py)
         join_side_stream()                  # weight-gradient GEMMs issued on the side stream
-        _ops.gru_poll_status()              # raises if a persistent GRU launch of the previous step gave up a wait
+        P, G = self._flat["P"], self._flat["G"]
+        # every abort word of this process ORed into one device word; data parallel: a raised word also plants a NaN in the
+        # reserved element of the LOCAL gradient buffer before its slice is summed, so that EVERY rank drops this step
+        any_abort = _ops.gather_abort(G.device, G[0:1] if self.communicator is not None else None)
         scale = 1.0
         if self.communicator is not None:
             self.communicator.finish_backward(self)
             scale = 1.0 / self.communicator.size
+        # the host learns of a given-up recurrence one step late and without synchronising -- on EVERY rank at the same step (ctl[5]
+        # derives from the reduced reserved element), and only after this step's collectives have been queued / joined: a rank that
+        # raised before finish_backward would leave its peers waiting in an all-reduce
+        self._raise_if_previous_step_gave_up()
         self.t += 1                         # steps ATTEMPTED; the device counts the applied ones (flat["applied"])
-        P, G = self._flat["P"], self._flat["G"]
         clip, decay = 0.0, 0.0
         for h in self._hooks:
             if isinstance(h, GradientClipping):
@@ -90,10 +107,32 @@ class Optimizer(object):
         # (asr_step_control: non-finite norm = the reference's NaN check, run/ctc/cnn/train.py:193-197, or a persistent GRU
         # launch that gave up a wait and left garbage behind) -- without a host synchronisation
         alpha, beta1, beta2 = self._control_constants()
-        _ops.step_control(G, self._flat["partials"], clip, scale, alpha, beta1, beta2, self._flat["applied"], self._flat["ctl"])
+        _ops.step_control(G, self._flat["partials"], clip, scale, alpha, beta1, beta2, self._flat["applied"], self._flat["ctl"],
+                          any_abort, 0)
         self._step(P, G, decay, self._flat["ctl"])
+        self._watch_gave_up()
         bump_weight_epoch()
         refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
+
+    def _watch_gave_up(self):
+        st = self._gave_up
+        if st[0] is None:
+            st[0] = torch.zeros(1, dtype=F32).pin_memory()
+        if st[1] is None or st[1].query():
+            st[0].copy_(self._flat["ctl"][5:6], non_blocking=True)
+            st[1] = torch.cuda.Event()
+            st[1].record()
+
+    def _raise_if_previous_step_gave_up(self):
+        st = self._gave_up
+        if st[1] is not None and st[1].query() and float(st[0][0]) != 0.0:
+            st[0][0] = 0.0
+            st[1] = None
+            _ops.clear_abort_words(self._flat["G"].device)       # sticky until somebody has been told: now
+            _ops.reset_poll_status()
+            from ._lib import AsrHipError
+            raise AsrHipError("a persistent GRU kernel gave up an in-launch wait during the previous step (on this rank or on a "
+                              "data-parallel peer): that step was dropped on every rank, parameters and optimiser state are intact")
 
     def applied_steps(self):
         """number of update steps that were not dropped on the device (synchronises: tests / logging only)"""
@@ -117,13 +156,13 @@ class Optimizer(object):
             raise RuntimeError("optimizer.setup(model) was given a model without initialised parameters")
         dev = params[0].device
         sizes = [(p.numel() + 63) // 64 * 64 for p in params]           # 256-byte aligned slices
-        total = sum(sizes)
+        total = RESERVED + sum(sizes)           # element 0 belongs to no parameter (asr_step_control's reserved_index)
         old = self._flat
         P = torch.empty(total, dtype=F32, device=dev)
         G = torch.empty(total, dtype=F32, device=dev)
         _ops.fill_(P, 0.0)
         _ops.fill_(G, 0.0)
-        offs, o = [], 0
+        offs, o = [], RESERVED
         for p, n in zip(params, sizes):
             offs.append(o)
             view = P[o:o + p.numel()].view(p.shape)

@@ -45,6 +45,9 @@ class Communicator(object):
         self._plan = None
         self.launch_log = []            # (slice index, parameters announced so far) per launch of the last step: tests
         self._recurrent = False         # the previous backward pass met a recurrence: defer launches to the boundaries
+        self.measure = False            # bench.py: time the launch stream's stalls on collectives (exposed_ms)
+        self.exposed = []
+        self._hold_all = False
 
     # -- parameters -------------------------------------------------------------------------------
     def broadcast(self, flat):
@@ -65,7 +68,8 @@ class Communicator(object):
     @staticmethod
     def make_plan(offsets, sizes, buckets):
         """contiguous slices [begin, end) of the flat gradient buffer, cut at parameter boundaries, last parameters first:
-        (begin, end, first parameter index, last parameter index)"""
+        (begin, end, first parameter index, last parameter index).  The last slice starts at element 0: it takes the reserved
+        elements in front of the first parameter along (optimizers.RESERVED: the cross-rank "a recurrence gave up" mark)."""
         total = offsets[-1] + sizes[-1]
         target = (total + buckets - 1) // buckets
         plan, end = [], total
@@ -74,7 +78,7 @@ class Communicator(object):
         for i in range(len(offsets) - 1, -1, -1):
             acc += sizes[i]
             if acc >= target or i == 0:
-                plan.append((offsets[i], end, i, last))
+                plan.append((offsets[i] if i > 0 else 0, end, i, last))
                 end = offsets[i]
                 last = i - 1
                 acc = 0
@@ -98,6 +102,11 @@ class Communicator(object):
         self._new_pass()
         self.launch_log = []
         self._defer, self._met_recurrence = self._recurrent, False
+        # two passes on two streams (asr/pipeline.py): the "no collective beside a recurrence" rule would have to hold on BOTH
+        # launch streams -- the other half's persistent recurrences keep starting while a collective queued from this pass is
+        # resident.  Nothing is launched before finish_backward then.
+        self._hold_all = self._passes > 1
+        self.exposed = []               # (event before, event after) around every join of the launch stream with the collectives
         if self.backend == "nccl" and self._stream is None:
             self._stream = torch.cuda.Stream()
         from . import link, _ops
@@ -141,7 +150,11 @@ class Communicator(object):
             self._launch_complete()
 
     def _launch_complete(self):
-        while self._next < len(self._plan) and self._complete(self._next):
+        # the LAST slice (first parameters + the reserved mark) always waits for finish_backward: the optimiser plants the
+        # "gave up" mark in it after the last recurrence has been queued and before it is summed
+        if self._hold_all:
+            return
+        while self._next < len(self._plan) - 1 and self._complete(self._next):
             self._passed(self._next)
             self._next += 1
 
@@ -189,11 +202,34 @@ class Communicator(object):
 
     def _join_pending(self):
         """the current stream waits for every collective in flight (RCCL: a stream dependency, the host goes on)"""
+        timed = self.measure and self._stream is not None and self._pending
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self._pending:
             w.wait()
         if self._stream is not None and self._pending:
             torch.cuda.current_stream().wait_stream(self._stream)
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.exposed.append((e0, e1))
         self._pending = []
+
+    def exposed_ms(self):
+        """time the launch stream spent stalled on collectives during the last step (measure=True; synchronises)"""
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.exposed)
+
+    def abort_backward(self):
+        """the backward pass raised: take the listener and the recurrence hooks down, wait out what is in flight"""
+        from . import link, _ops
+        link._GRAD_LISTENER[0] = None
+        _ops.RECURRENCE_HOOKS["before"] = _ops.RECURRENCE_HOOKS["after"] = None
+        try:
+            self._join_pending()
+        finally:
+            self._pending, self._plan = [], None
 
     def finish_backward(self, opt):
         from . import link, _ops

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x, c
         const int t = (int)(row / B);
 #pragma unroll
         for (int k = 0; k < NV; ++k) v[k] = vn[k];
-        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float mean = mean_in[row], rstd = rstd_in[row] < INFINITY ? rstd_in[row] : 0.f;      // (zero-variance rows: ln::usable_rstd)
         // occupancy of this row's lattice nodes -> occ[par][loss][label]; every scattering thread remembers its slot
         float* oc = occ + (size_t)par * NL * D;
         // (the utterance constants in registers are those of THIS row: fetch_ab(row) loaded them; the prefetch for the next

@@ -2915,16 +2915,48 @@ __global__ __launch_bounds__(704) void bwd_group_kernel(const uint16_t* __restri
 #undef ASR_OP_PUT
 }
 
-// y = hf + hb (or a copy for one direction): f32 state -> bf16 layer output
+// y = hf + hb (or a copy for one direction): f32 state -> bf16 layer output; rows beyond an utterance's length are zero
 __global__ void merge_dirs_kernel(const float* __restrict__ hseq, uint16_t* __restrict__ y, long long rows, int H,
-                                  int ndir) {
+                                  int ndir, const int* __restrict__ x_len, int B) {
     const long long n = rows * H;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / H;
         const int j = (int)(i - r * H);
         float v = hseq[r * ndir * H + j];
         if (ndir == 2) v += hseq[r * ndir * H + H + j];
+        if (x_len && (int)(r / B) >= x_len[(int)(r % B)]) v = 0.f;
         y[i] = f32_to_bf16(v);
+    }
+}
+
+// ---- per-utterance lengths (chainer.links.NStepBiGRU runs every sequence over its own length: asr/nn/nn.py:3)
+// Row b is live for t < x_len[b].  Beyond that the state must stay frozen -- so that the reverse direction, which meets the
+// padding first, arrives at t = x_len[b] - 1 with the zero state it would start from -- and no gradient may pass.  Instead of a
+// length test on the latency chain of every recurrence kernel, the update gate is pinned to exactly 1 on those rows:
+// z = sigmoid(gi_z + gh_z) with gi_z = +10^4 is 1.0f (exp underflows to 0, rcp(1) = 1), hence h' = (1 - z) n + z h = h bit for
+// bit, and in the backward pass every gate gradient carries a factor (1 - z) = 0 while dh passes through unchanged (dh z).
+// One workgroup per (t, b) row; live rows leave at once.
+template <typename GT>
+__global__ __launch_bounds__(256) void pin_update_gate_kernel(GT* __restrict__ gi, const int* __restrict__ x_len, int B, int H, int ndir) {
+    const long long row = blockIdx.x;
+    const int t = (int)(row / B), b = (int)(row % B);
+    if (t < x_len[b]) return;
+    GT* g = gi + row * (long long)ndir * 3 * H;
+    for (int i = threadIdx.x; i < ndir * H; i += blockDim.x) {
+        const int d = i / H, j = i - d * H;
+        if (sizeof(GT) == 2) g[(size_t)d * 3 * H + H + j] = (GT)f32_to_bf16(1.0e4f);
+        else g[(size_t)d * 3 * H + H + j] = (GT)1.0e4f;
+    }
+}
+
+// the layer output is zero (a constant) beyond an utterance's length: whatever gradient arrives there is dropped
+__global__ void mask_rows_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, const int* __restrict__ x_len,
+                                 long long rows, int B, int W8) {
+    const long long n = rows * W8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / W8;
+        const bool live = (int)(r / B) < x_len[(int)(r % B)];
+        reinterpret_cast<uint4*>(dst)[i] = live ? reinterpret_cast<const uint4*>(src)[i] : make_uint4(0, 0, 0, 0);
     }
 }
 
@@ -3069,9 +3101,9 @@ extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mo
     return fwd_family(T, B, H, ndir, mode, &dummy) == 2 ? 1 : 0;
 }
 
-extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
+extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
                            void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
-                           int mode) {
+                           int mode, const int* x_len) {
     if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
@@ -3079,6 +3111,12 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
     const float* gi = reinterpret_cast<const float*>(gi_any);
     if (gi_bf16 && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
     hipStream_t st = (hipStream_t)stream;
+    if (x_len) {        // pin the update gate of the rows beyond each utterance's length (see pin_update_gate_kernel)
+        if ((long long)T * B > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
+        if (gi_bf16) hipLaunchKernelGGL(pin_update_gate_kernel<uint16_t>, dim3((unsigned)(T * B)), dim3(256), 0, st, (uint16_t*)gi_any, x_len, B, H, ndir);
+        else hipLaunchKernelGGL(pin_update_gate_kernel<float>, dim3((unsigned)(T * B)), dim3(256), 0, st, (float*)gi_any, x_len, B, H, ndir);
+        ASR_LAUNCH_CHECK();
+    }
     const dim3 grid(H / 16, ndir), block(256);
     const int ksw = (H / 32 + 3) / 4;
     if (ksw > 8) return ASR_ERR_UNSUPPORTED;      // H <= 1024
@@ -3183,7 +3221,7 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
         long long g = (n + 255) / 256;
         if (g > 4096) g = 4096;
         hipLaunchKernelGGL(merge_dirs_kernel, dim3((unsigned)g), dim3(256), 0, st, hseq, (uint16_t*)y_bf16,
-                           (long long)T * B, H, ndir);
+                           (long long)T * B, H, ndir, x_len, B);
         ASR_LAUNCH_CHECK();
     }
     return ASR_OK;
@@ -3191,11 +3229,22 @@ extern "C" int asr_gru_fwd(void* stream, const void* gi_any, int gi_bf16, const 
 
 extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq,
                            const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih,
-                           float* db_hh, int T, int B, int H, int ndir, void* sync_ws, int mode) {
+                           float* db_hh, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len,
+                           void* dy_ws) {
     if (!dy_bf16 || !gates || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (x_len) {        // the forward pass pinned z = 1 beyond the lengths (no gate gradient, dh passes); drop dy there
+        if (!dy_ws || (H % 8)) return ASR_ERR_BAD_ARG;
+        const long long n = (long long)T * B * (H / 8);
+        long long g = (n + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, (const uint16_t*)dy_bf16, (uint16_t*)dy_ws, x_len,
+                           (long long)T * B, B, H / 8);
+        ASR_LAUNCH_CHECK();
+        dy_bf16 = dy_ws;
+    }
     const dim3 grid(H / 16, ndir), block(256);
     const int ksw = (3 * H / 32 + 3) / 4;
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12;

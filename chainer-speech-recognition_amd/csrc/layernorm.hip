@@ -21,6 +21,12 @@ __device__ __forceinline__ void stf(T* p, long long i, float v) {
     if (sizeof(T) == 2) p[i] = (T)f32_to_bf16(v); else p[i] = (T)v;
 }
 
+// A row of zero variance has rstd = inf (the reference divides by std without an epsilon, asr/nn/layernorm.py:42-48: its forward
+// output is NaN there, and so is ours).  Such rows occur legitimately: frames beyond an utterance's length are all-zero after a
+// length-aware recurrent layer with zero biases.  The backward kernels give them no gradient and take none from them
+// (xhat := 0, dx := 0) instead of spreading 0 * NaN into the parameter gradients.
+__device__ __forceinline__ float usable_rstd(float r) { return r < INFINITY ? r : 0.f; }
+
 template <typename XT, typename YT>
 __global__ __launch_bounds__(256) void fwd_kernel(const XT* __restrict__ x, YT* __restrict__ y,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const XT* __restrict__ x, cons
     const XT* xr = x + row * D;
     const GT* gr = dy + row * D;
     DT* dr = dx + row * D;
-    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float mean = mean_in[row], rstd = usable_rstd(rstd_in[row]);
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < D; i += blockDim.x) {
         const float g = ldf(gr, i) * gamma[i % C];
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const XT* __restrict__ 
     if (i < D)
         for (long long r = r0 + w; r < r1; r += 4) {
             const float g = ldf(dy, r * D + i);
-            sg += g * (ldf(x, r * D + i) - mean_in[r]) * rstd_in[r];
+            sg += g * (ldf(x, r * D + i) - mean_in[r]) * usable_rstd(rstd_in[r]);
             sb += g;
         }
     pg[w][threadIdx.x & 63] = sg;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(256) void bwd_f32x4_kernel(const float* __restrict_
     const float4* gr = reinterpret_cast<const float4*>(dy + row * D);
     float4* dr = reinterpret_cast<float4*>(dx + row * D);
     const int n4 = D >> 2;
-    const float mean = mean_in[row], rstd = rstd_in[row];
+    const float mean = mean_in[row], rstd = usable_rstd(rstd_in[row]);
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < n4; i += blockDim.x) {
         const float4 v = xr[i], gy = gr[i];
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void bwd_rows_f32_kernel(const float* __restri
     for (; row < rows; row += gridDim.x) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) { v[k] = vn[k]; gy[k] = gn[k]; }
-        const float mean = mean_in[row], rstd = rstd_in[row];
+        const float mean = mean_in[row], rstd = usable_rstd(rstd_in[row]);
         const long long nxt = row + gridDim.x;
         if (nxt < rows) {
 #pragma unroll

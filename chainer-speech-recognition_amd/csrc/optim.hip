@@ -98,10 +98,24 @@ __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* __res
     if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 
+// every abort word of the process (any number of control buffers: one per (device, stream) that launched a recurrence) ORed into
+// ONE word, and -- data parallelism -- a NaN planted in the reserved element of the local gradient buffer BEFORE the last slice is
+// summed over the ranks, so that every rank's step_control sees a non-finite reserved element and drops the same step
+__global__ void gather_abort_kernel(const long long* __restrict__ word_ptrs, int n, int* __restrict__ any_word, float* __restrict__ poison) {
+    int any = 0;
+    for (int i = 0; i < n; ++i) {
+        const int* w = reinterpret_cast<const int*>(word_ptrs[i]);
+        if (w && w[0] != 0) any = 1;
+    }
+    if (any_word) any_word[0] = any;
+    if (any && poison) poison[0] = __int_as_float(0x7fc00000);
+}
+
 __global__ __launch_bounds__(256) void step_control_kernel(const float* __restrict__ partials, int npartials,
                                                            const int* __restrict__ abort0, const int* __restrict__ abort1,
                                                            float clip, float grad_scale, float alpha, float beta1, float beta2,
-                                                           int* __restrict__ applied, float* __restrict__ ctl) {
+                                                           int* __restrict__ applied, float* __restrict__ ctl,
+                                                           const float* __restrict__ reserved) {
     __shared__ float scratch[32];
     float s = 0.f;
     for (int i = threadIdx.x; i < npartials; i += blockDim.x) s += partials[i];
@@ -110,8 +124,11 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
     ctl[4] = sq;
     const float* sqnorm = &sq;
     bool drop = !isfinite(sqnorm[0]);
-    if (abort0 && abort0[0] != 0) drop = true;
-    if (abort1 && abort1[0] != 0) drop = true;
+    bool gave_up = false;               // a recurrence of this rank (abort words) or of a peer (the reduced reserved element)
+    if (abort0 && abort0[0] != 0) gave_up = true;
+    if (abort1 && abort1[0] != 0) gave_up = true;
+    if (reserved && !isfinite(reserved[0])) gave_up = true;
+    if (gave_up) drop = true;
     float rate = grad_scale;
     if (!drop && clip > 0.f) {
         const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
     ctl[1] = rate;
     ctl[2] = (float)((double)alpha * sqrt(fix2) / fix1);
     ctl[3] = (float)t;
+    ctl[5] = gave_up ? 1.f : 0.f;
 }
 
 __global__ __launch_bounds__(256) void adam_ctl_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -217,14 +235,22 @@ extern "C" int asr_clip_decay_sgd(void* stream, float* p, const float* g, float*
 
 extern "C" int asr_sqnorm_partials_count(long long n) { return grid_for(n); }
 
+extern "C" int asr_gather_abort(void* stream, const long long* word_ptrs, int n, int* any_word, float* poison) {
+    if (n < 0 || (n > 0 && !word_ptrs) || (!any_word && !poison)) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gather_abort_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, word_ptrs, n, any_word, poison);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
 extern "C" int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
                                 float clip_threshold, float grad_scale, float alpha, float beta1, float beta2,
-                                int* applied_steps, float* ctl) {
-    if (!g || n <= 0 || !partials || !applied_steps || !ctl) return ASR_ERR_BAD_ARG;
+                                int* applied_steps, float* ctl, int reserved_index) {
+    if (!g || n <= 0 || !partials || !applied_steps || !ctl || reserved_index >= n) return ASR_ERR_BAD_ARG;
     const int blocks = grid_for(n);
     hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, partials);
     hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, blocks, abort0,
-                       abort1, clip_threshold, grad_scale, alpha, beta1, beta2, applied_steps, ctl);
+                       abort1, clip_threshold, grad_scale, alpha, beta1, beta2, applied_steps, ctl,
+                       reserved_index >= 0 ? g + reserved_index : (const float*)nullptr);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -304,11 +304,18 @@ size_t asr_gru_sync_bytes(int B, int H, int ndir);
  * GEMM and streamed here; accepted by the default persistent kernel only -- ask asr_gru_fwd_accepts_bf16_gi first, the call
  * returns -3 otherwise) */
 int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode);
-int asr_gru_fwd(void* stream, const void* gi, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
-                float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode);
+/* x_len (B) int32 or NULL: per-utterance frame counts -- chainer.links.NStepBiGRU (asr/nn/nn.py:3) runs every sequence over
+ * its own length; with the padded (T, B) block of asr/data/processing.py:113-126 that means: row b is live for t < x_len[b], the
+ * state is frozen beyond it (the reverse direction, which meets the padding first, therefore reaches t = x_len[b] - 1 with the zero
+ * state it would start from), y is zero there and no gradient flows through those steps.  Implemented off the latency chain:
+ * asr_gru_fwd overwrites the update-gate columns of gi on the dead rows (gi is scratch of the caller's projection GEMM: it is
+ * MODIFIED when x_len is given) so that z == 1.0f exactly, asr_gru_bwd drops dy on the dead rows into dy_ws ((T*B, H) bf16,
+ * required with x_len) -- every recurrence kernel form serves ragged batches unchanged. */
+int asr_gru_fwd(void* stream, void* gi, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
+                float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len);
 int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
                 void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh, int T, int B, int H,
-                int ndir, void* sync_ws, int mode);
+                int ndir, void* sync_ws, int mode, const int* x_len, void* dy_ws);
 
 /* ---------------------------------------------------------------------------------------- SRU scan
  * Replaces the CUDA kernels `forward` / `backward` of asr/nn/sru.py:17-73,75-191 (SRUFunction.forward_gpu :327-367,
@@ -344,11 +351,16 @@ int asr_clip_decay_sgd(void* stream, float* p, const float* g, float* v, long lo
  * dropped when the norm is not finite (the reference's NaN check, run/ctc/cnn/train.py:193-197) or an abort word is raised
  * (the recurrence's outputs are garbage); *applied_steps (device int, zero at start) counts the steps that were NOT dropped
  * and is the t of Adam's bias correction (the reference `continue`s before optimizer.update).  asr_adam_ctl / asr_sgd_ctl
- * apply the step ctl describes. */
+ * apply the step ctl describes.  ctl[5] = 1 when the drop was caused by a recurrence that gave up -- here (abort words) or on
+ * another data-parallel rank: reserved_index >= 0 names an element of g that belongs to no parameter; asr_gather_abort ORs any
+ * number of abort words (device array of n device addresses) into *any_word and, when one is raised, plants a NaN in *poison
+ * (that element of the LOCAL gradient buffer, before it is summed over the ranks), so every rank drops the same step and every
+ * rank can tell why. */
 int asr_sqnorm_partials_count(long long n);
+int asr_gather_abort(void* stream, const long long* word_ptrs, int n, int* any_word, float* poison);
 int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
                      float clip_threshold, float grad_scale, float alpha, float beta1, float beta2, int* applied_steps,
-                     float* ctl);
+                     float* ctl, int reserved_index);
 int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps,
                  float weight_decay, const float* ctl);
 int asr_sgd_ctl(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,

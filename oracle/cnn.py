@@ -90,11 +90,19 @@ def _layer_norm(x, gamma, beta):
     return diff / std * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
 
 
-def forward(arch, cfg, params, x):
+def forward(arch, cfg, params, x, matched=False, fused_logit_bias=False):
     """params: dict name -> torch tensor (requires_grad as the caller likes) with this package's state_dict names
-    (``layer_0.W`` ...; a weight-normalised layer has ``.V``, ``.g``, ``.b``).  x (B, C, H, T) -> logits (B, V, 1, T)."""
-    h, skip = x, None
-    for op, name, args in program(arch, cfg):
+    (``layer_0.W`` ...; a weight-normalised layer has ``.V``, ``.g``, ``.b``).  x (B, C, H, T) -> logits (B, V, 1, T).
+    matched: bf16 roundings where the HIP path rounds (oracle/bf16.py): every operator output except the last projection and the
+    last normalisation (float32 logits), every activation gradient an operator writes; fused_logit_bias: the last projection's
+    bias gradient is the float32 column sum formed inside the fused LayerNorm + CTC sweep (V % 4 == 0)."""
+    from . import bf16 as Q
+    on = bool(matched)
+    prog = program(arch, cfg)
+    last_conv = max(i for i, (op, _, _) in enumerate(prog) if op in ("conv", "glu"))
+    last_ln = max(i for i, (op, _, _) in enumerate(prog) if op == "ln")
+    h, skip = (Q.rnd(x) if on else x), None
+    for i, (op, name, args) in enumerate(prog):
         if op in ("conv", "glu"):
             ph, pt = args
             if name + ".V" in params:                                     # asr/nn/convolution_2d.py:21-25,62-64
@@ -103,25 +111,32 @@ def forward(arch, cfg, params, x):
             else:
                 W = params[name + ".W"]
             b = params.get(name + ".b")
-            y = F.conv2d(h, W, b, stride=1, padding=(ph, pt))
+            f32_out = on and i == last_conv and last_ln > last_conv
+            y = F.conv2d(Q.inp(h, on), Q.weight(W, on), None, stride=1, padding=(ph, pt))
             if pt > 0:
                 y = y[..., :-pt]                                          # run/ctc/cnn/model.py:44, asr/nn/nn.py:276-277
+            bias = 0.0 if b is None else b.reshape(1, -1, 1, 1)
+            if f32_out:                                                   # float32 logits, gradient handed over in bf16
+                y = (Q.inp(y, on) + bias) if fused_logit_bias else Q.inp(y + bias, on)
+            else:
+                y = Q.out(y + bias, on)
             if op == "glu":
-                a, g = torch.chunk(y, 2, dim=1)                           # asr/nn/nn.py:279-280
-                y = a * torch.sigmoid(g)
+                a, g = torch.chunk(Q.inp(y, on), 2, dim=1)                # asr/nn/nn.py:279-280
+                y = Q.out(a * torch.sigmoid(g), on)
             h = y
         elif op == "ln":
-            h = _layer_norm(h, params[name + ".gamma"], params[name + ".beta"])
+            y = _layer_norm(Q.inp(h, on), params[name + ".gamma"], params[name + ".beta"])
+            h = y if (on and i == last_ln) else Q.out(y, on)
         elif op == "maxout":
-            h = onn.maxout2(h)
+            h = Q.out(onn.maxout2(h), on)
         elif op == "relu":
-            h = torch.relu(h)
+            h = Q.out(torch.relu(Q.inp(h, on)), on)
         elif op == "pool":
-            h = onn.maxpool_h(h, args)
+            h = Q.out(onn.maxpool_h(h, args), on)
         elif op == "res_begin":
             skip = h
         elif op == "res_end":
-            h = h + skip                                                  # asr/nn/nn.py:322-328
+            h = Q.out(h + skip, on)                                       # asr/nn/nn.py:322-328
     return h
 
 

@@ -16,52 +16,52 @@ from . import nn as onn
 
 
 class DS2Oracle(torch.nn.Module):
-    def __init__(self, state, num_conv_layers, num_rnn_layers, bidirectional=True):
-        """state: dict name -> float32 CPU tensor with the names of asr.model.ds2.Model.state_dict()."""
+    def __init__(self, state, num_conv_layers, num_rnn_layers, bidirectional=True, matched=False, gi_bf16=True, ps_units=None,
+                 fused_logit_bias=False):
+        """state: dict name -> float32 CPU tensor with the names of asr.model.ds2.Model.state_dict().
+        matched: restate the step with bf16 roundings where the HIP path rounds (oracle/bf16.py) -- gi_bf16 / ps_units say which
+        recurrence kernels serve the shape (asr_gru_fwd_accepts_bf16_gi; partial-sum backward at H % 128 == 0), fused_logit_bias
+        that the logit projection's bias gradient comes out of the fused LayerNorm + CTC sweep (V % 4 == 0) in float32."""
         super().__init__()
         self.nconv, self.nrnn, self.ndir = num_conv_layers, num_rnn_layers, 2 if bidirectional else 1
+        self.matched, self.gi_bf16, self.ps_units, self.fused_logit_bias = bool(matched), bool(gi_bf16), ps_units, bool(fused_logit_bias)
         self.p = torch.nn.ParameterDict({k.replace(".", "__"): torch.nn.Parameter(v.clone().float()) for k, v in state.items()})
 
     def g(self, name):
         return self.p[name.replace(".", "__")]
 
-    def forward(self, x):
-        """x (B, 3, 40, T) -> logits (T, B, V)"""
+    def forward(self, x, x_len=None):
+        """x (B, 3, 40, T) -> logits (T, B, V).  x_len: per-utterance frame counts for the recurrent layers (NStepBiGRU semantics:
+        the reverse direction of utterance b starts at x_len[b] - 1, outputs beyond it are zero); None = the padded block."""
+        from . import bf16 as Q
+        on = self.matched
         pools = [3] + [2] * (self.nconv - 1)
-        h = x
+        h = Q.rnd(x) if on else x
         for i, pool in enumerate(pools):
             W, b = self.g("conv_blocks._sequential_%d.W" % (4 * i)), self.g("conv_blocks._sequential_%d.b" % (4 * i))
-            h = onn.conv2d_causal(h, W, b, 0)
-            h = onn.maxout2(h)
-            h = onn.maxpool_h(h, pool)
+            h = Q.out(onn.conv2d_causal(Q.inp(h, on), Q.weight(W, on), b, 0), on)
+            h = Q.out(onn.maxpool_h(onn.maxout2(h), pool), on)
         B, C, H, T = h.shape
         h = h.permute(3, 0, 2, 1).reshape(T, B, H * C)          # feature order (h, c): see ds2.py / functions.reshape
         for i in range(self.nrnn):
             pre = "rnn_blocks._sequential_%d." % (2 * i)
             w_ih, w_hh, b_ih, b_hh = (self.g(pre + n) for n in ("w_ih", "w_hh", "b_ih", "b_hh"))
-            Hh = w_hh.shape[2]
-            outs = []
-            for d in range(self.ndir):
-                xs = h if d == 0 else h.flip(0)
-                hs, _ = torch._VF.gru(xs, torch.zeros(1, B, Hh), [w_ih[d], w_hh[d], b_ih[d], b_hh[d]], True, 1, 0.0, False,
-                                      False, False)
-                outs.append(hs if d == 0 else hs.flip(0))
-            h = outs[0] if self.ndir == 1 else outs[0] + outs[1]
+            h = Q.gru(h, w_ih, w_hh, b_ih, b_hh, x_len, on, self.gi_bf16, self.ps_units)
         for j, idx in enumerate((0, 3)):
             W, b = self.g("dense_blocks._sequential_%d.W" % idx), self.g("dense_blocks._sequential_%d.b" % idx)
-            h = F.linear(h, W[:, :, 0], b)
-            h = h.reshape(T, B, -1, 2).max(dim=3)[0]
+            h = Q.linear(h, W[:, :, 0], b, on)
+            h = Q.out(h.reshape(T, B, -1, 2).max(dim=3)[0], on)
         W, b = self.g("dense_blocks._sequential_6.W"), self.g("dense_blocks._sequential_6.b")
-        h = F.linear(h, W[:, :, 0], b)
+        h = Q.linear(h, W[:, :, 0], b, on, f32_out=True, bias_grad_unrounded=self.fused_logit_bias)
         gamma, beta = self.g("dense_blocks._sequential_7.norm.gamma"), self.g("dense_blocks._sequential_7.norm.beta")
-        mean = h.mean(dim=2, keepdim=True)
-        diff = h - mean
-        std = torch.sqrt((diff * diff).mean(dim=2, keepdim=True))
-        return diff / std * gamma + beta
+        return Q.layer_norm_rows(h, gamma, beta)
 
 
 def ctc_mean_loss(logits, labels, x_len, l_len, blank=0):
     """Chainer's normalisation: mean over utterances of -log p(label | x)."""
+    T = logits.shape[0]
+    live = (torch.arange(T).reshape(T, 1) < x_len.reshape(1, -1).long()).unsqueeze(2)
+    logits = torch.where(live, logits, torch.zeros_like(logits))      # frames beyond the length never reach the loss (may be NaN)
     lp = torch.log_softmax(logits, dim=2)
     loss = F.ctc_loss(lp, labels.long(), x_len.long(), l_len.long(), blank=blank, reduction="none", zero_infinity=False)
     return loss.mean()

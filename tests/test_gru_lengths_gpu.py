@@ -1,0 +1,189 @@
+"""Length-exact (Bi)GRU on the fast path: ``nn.BiGRU(x, x_length)`` / ``ds2.Model(x, x_length=...)`` run every utterance over its
+own frames -- chainer.links.NStepBiGRU semantics (asr/nn/nn.py:3) on the padded block of asr/data/processing.py:113-126 -- in
+every recurrence kernel form, checked against ``torch.nn.utils.rnn.pack_padded_sequence`` on the CPU (float32) and against the
+rounding-matched oracle (oracle/bf16.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bf16 as Q
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _layer_and_reference(device, T, B, I, H, ndir, seed, x_len, ps_units=None):
+    """one (Bi)GRU link on a random padded batch through autograd on the device; returns device results and the two oracles'."""
+    from asr import nn, _ops
+    from asr import functions as F
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / np.sqrt(H)
+    P = dict(w_ih=torch.empty(ndir, 3 * H, I).uniform_(-k, k, generator=g), w_hh=torch.empty(ndir, 3 * H, H).uniform_(-k, k, generator=g),
+             b_ih=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g), b_hh=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g))
+    x = Q.rnd(torch.randn(T, B, I, generator=g))
+    gy = Q.rnd(torch.randn(T, B, H, generator=g))         # NOT zero beyond the lengths: the layer has to drop it there
+    layer = (nn.BiGRU if ndir == 2 else nn.GRU)(I, H)
+    with torch.no_grad():
+        for name, v in P.items():
+            getattr(layer, name).data = v.clone()
+    layer.to_gpu()
+    xd = x.permute(1, 2, 0).contiguous().to(device).requires_grad_(True)           # the links' (B, I, T) layout
+    xl = None if x_len is None else x_len.to(device)
+    y = layer(xd, xl)
+    y.backward(gy.permute(1, 2, 0).contiguous().to(device, BF16))
+    F.join_side_stream()
+    torch.cuda.synchronize()
+    _ops.gru_check_sync()
+    got = dict(y=y.detach().float().cpu().permute(2, 0, 1), dx=xd.grad.float().cpu().permute(2, 0, 1),
+               w_ih=layer.w_ih.grad.cpu(), w_hh=layer.w_hh.grad.cpu(), b_ih=layer.b_ih.grad.cpu(), b_hh=layer.b_hh.grad.cpu())
+    gi_bf16 = _ops.gru_gi_dtype(T, B, H, ndir) == BF16
+    refs = []
+    for matched in (False, True):
+        p = {n: Q.rnd(v).clone().requires_grad_(True) if (n.startswith("w") and not matched) else v.clone().requires_grad_(True)
+             for n, v in P.items()}
+        xr = x.clone().requires_grad_(True)
+        yr = Q.gru(xr, p["w_ih"], p["w_hh"], p["b_ih"], p["b_hh"], x_len, matched, gi_bf16, ps_units)
+        yr.backward(gy)
+        refs.append(dict(y=yr.detach(), dx=xr.grad, w_ih=p["w_ih"].grad, w_hh=p["w_hh"].grad, b_ih=p["b_ih"].grad, b_hh=p["b_hh"].grad))
+    return got, refs[0], refs[1]
+
+
+# mode 0: the default kernels (16-unit x 8-row forward or the wide forward at 4 < B <= 16; partial-sum or wide backward);
+# 1: one launch per time step; 2: placement-free persistent; 3: grouped; 5: 16-unit x 8-row backward
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("T,B,I,H,ndir", [(17, 3, 32, 64, 2), (40, 7, 48, 128, 2), (33, 32, 64, 128, 2), (25, 5, 32, 64, 1),
+                                          (60, 12, 32, 256, 2)])
+def test_gru_runs_every_utterance_over_its_own_length(device, T, B, I, H, ndir, mode):
+    from asr import _ops
+    if mode == 3 and H % 128:
+        pytest.skip("grouped kernels need H % 128 == 0")
+    g = torch.Generator().manual_seed(B * T)
+    x_len = torch.randint(max(1, T // 3), T + 1, (B,), generator=g, dtype=torch.int32)
+    x_len[0] = T                                  # one full-length utterance, one of a single frame
+    if B > 2:
+        x_len[1] = 1
+    # the default backward kernel at H % 128 == 0 exchanges per-producer partial sums rounded to bf16; every other form exchanges dgh
+    ps_served = mode == 0 and H % 128 == 0 and ndir * ((B + 3) // 4) <= 16 and B <= 32
+    _ops.GRU_MODE[0] = mode
+    try:
+        got, f32, matched = _layer_and_reference(device, T, B, I, H, ndir, seed=T * H + B, x_len=x_len, ps_units=32 if ps_served else 0)
+    finally:
+        _ops.GRU_MODE[0] = 0
+    live = (torch.arange(T).reshape(T, 1) < x_len.reshape(1, B)).unsqueeze(2)
+    assert float(got["y"][~live.expand_as(got["y"])].abs().max()) == 0.0           # zero beyond the length, exactly
+    assert float(got["dx"][~live.expand(T, B, I)].abs().max()) == 0.0              # the padding receives no gradient
+    for name in got:
+        # bf16 hand-offs against float32 pack_padded_sequence: loose; against the rounding-matched oracle: tight
+        assert _rel(got[name], f32[name]) < 3e-2, (name, "fp32", _rel(got[name], f32[name]))
+        assert _rel(got[name], matched[name]) < 3e-3, (name, "matched", _rel(got[name], matched[name]))
+
+
+def test_lengths_equal_truncated_utterances(device):
+    """the length-aware batch gives utterance b exactly what a batch of the utterance alone, cut to its length, gives (same kernels,
+    same bf16 roundings: only the float32 summation order of the projection GEMM may differ)"""
+    from asr import nn, _ops
+    from asr import functions as F
+    T, B, I, H = 48, 6, 32, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, I, T, generator=g)
+    x_len = torch.tensor([48, 20, 1, 33, 47, 9], dtype=torch.int32)
+    layer = nn.BiGRU(I, H).to_gpu()
+    y = layer(x.to(device), x_len.to(device)).detach().float().cpu()
+    for b in range(B):
+        L = int(x_len[b])
+        alone = layer(x[b:b + 1, :, :L].contiguous().to(device)).detach().float().cpu()
+        torch.cuda.synchronize()
+        assert _rel(y[b, :, :L], alone[0]) < 2e-3, (b, _rel(y[b, :, :L], alone[0]))
+        assert float(y[b, :, L:].abs().max()) == 0.0 if L < T else True
+    _ops.gru_check_sync()
+
+
+def test_full_size_ragged_batch(device):
+    """SURVEY 8d's ragged variant at BASELINE size: T=1000, B=32, H=512, lengths U{600..1000}, default kernels, against
+    pack_padded_sequence in float32 and the rounding-matched oracle (relative L2)."""
+    T, B, I, H = 1000, 32, 384, 512
+    g = torch.Generator().manual_seed(11)
+    x_len = torch.randint(600, 1001, (B,), generator=g, dtype=torch.int32)
+    got, f32, matched = _layer_and_reference(device, T, B, I, H, 2, seed=3, x_len=x_len)
+    e32 = {n: _rel(got[n], f32[n]) for n in got}
+    em = {n: _rel(got[n], matched[n]) for n in got}
+    print("ragged full-size BiGRU: vs float32 pack_padded_sequence", {k: "%.2e" % v for k, v in e32.items()})
+    print("ragged full-size BiGRU: vs rounding-matched oracle     ", {k: "%.2e" % v for k, v in em.items()})
+    for n in got:
+        assert e32[n] < 1.2e-2, (n, e32[n])
+        assert em[n] < 3e-3, (n, em[n])
+
+
+@pytest.mark.parametrize("B,T,H", [(4, 60, 128), (3, 41, 64)])
+def test_model_with_lengths_matches_the_oracle(device, B, T, H):
+    """ds2.Model(x, x_length=...) + CTC + backward against the oracles run with the same lengths"""
+    from asr import _ops
+    from asr.loss import connectionist_temporal_classification
+    from asr.model import ds2
+    V = 32
+    torch.manual_seed(2)
+    cfg = ds2.configure()
+    cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, H, 32, 2
+    model = ds2.Model(cfg).to_gpu()
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=1, ragged=True)
+    xl = x_len.to(device)
+    with torch.no_grad():
+        model(x.to(device), x_length=xl)
+        for name, p in model.named_parameters():           # non-zero biases: padded frames must not be degenerate by luck
+            if name.endswith(".b"):
+                p.data.uniform_(-0.1, 0.1)
+    from asr.link import bump_weight_epoch
+    bump_weight_epoch()
+    ys = model(x.to(device), x_length=xl)
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, xl, l_len.to(device))
+    loss.backward()
+    from asr.functions import join_side_stream
+    join_side_stream()
+    torch.cuda.synchronize()
+    _ops.gru_check_sync()
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2) == BF16
+    for matched, tol in ((False, 0.2), (True, 5e-3)):
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=True)
+        loss_ref = omodel.ctc_mean_loss(ref(x, x_len), labels, x_len, l_len)
+        loss_ref.backward()
+        assert abs(loss.item() - loss_ref.item()) <= (2e-2 if not matched else 1e-3) * abs(loss_ref.item()), (matched, loss.item(), loss_ref.item())
+        worst = max((_rel(p.grad.cpu(), ref.g(name).grad), name) for name, p in model.named_parameters())
+        print("ragged model, matched=%s: worst parameter-gradient relative L2 %.2e (%s)" % (matched, worst[0], worst[1]))
+        assert worst[0] < tol, (matched, worst)
+    for p in model.parameters():
+        assert torch.isfinite(p.grad).all()
+
+
+def test_zero_bias_padding_rows_do_not_poison_the_gradients(device):
+    """frames beyond an utterance's length are exactly zero after the length-aware recurrent layers; with zero biases (the
+    initial state of the model) the logits of such a frame are all equal, the reference's epsilon-free LayerNormalization
+    (asr/nn/layernorm.py:42-48) is NaN there -- and the backward pass must keep that out of every parameter gradient"""
+    from asr.loss import connectionist_temporal_classification
+    from asr.model import ds2
+    V, B, T = 32, 4, 50
+    torch.manual_seed(4)
+    cfg = ds2.configure()
+    cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 64, 32, 2
+    for fused in (True, False):
+        from asr import functions as F
+        F.FUSE_CTC_INTO_LAYERNORM[0] = fused
+        try:
+            model = ds2.Model(cfg).to_gpu()
+            x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=1, ragged=True)
+            assert int(x_len.min()) < T
+            ys = model(x.to(device), x_length=x_len.to(device))
+            loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+            loss.backward()
+            F.join_side_stream()
+            torch.cuda.synchronize()
+            assert np.isfinite(loss.item())
+            for name, p in model.named_parameters():
+                assert torch.isfinite(p.grad).all(), (fused, name)
+        finally:
+            F.FUSE_CTC_INTO_LAYERNORM[0] = True

@@ -26,35 +26,61 @@ def _build(device, V=29, conv=16, rnn=64, dense=32, nrnn=2, bidir=True, seed=0):
     return cfg, model
 
 
-@pytest.mark.parametrize("B,T,bidir", [(3, 60, True), (4, 41, False)])
-def test_forward_backward_matches_oracle(device, B, T, bidir):
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+# Gates.  MATCHED: the oracle rounds to bf16 where the device does (oracle/bf16.py), so what is left is float32 summation order, the
+# fast exp / rcp of the gate math and float32-vs-float64 CTC -- a dropped tap, a wrong pad or a missing term shows at once.
+# FP32: the plain float32 oracle; the distance to it is the price of bf16 activations (reported, loosely bounded).
+MATCHED_GRAD_REL_L2 = 5e-3
+MATCHED_LOSS_REL = 1e-3
+
+
+@pytest.mark.parametrize("B,T,bidir,V,H", [(3, 60, True, 29, 64), (4, 41, False, 32, 64), (4, 50, True, 32, 128)])
+def test_forward_backward_matches_oracle(device, B, T, bidir, V, H):
+    """logits, loss and every parameter gradient of one step: against the rounding-matched oracle at MATCHED_GRAD_REL_L2 relative
+    L2 per parameter, and against the float32 oracle at bf16 tolerance.  V = 29: three-kernel logit region; V = 32: the fused
+    LayerNorm + CTC backward (V % 4 == 0); H = 128: the partial-sum backward recurrence."""
+    from asr import _ops
     from asr.loss import connectionist_temporal_classification
-    V = 29
-    cfg, model = _build(device, V=V, bidir=bidir)
+    cfg, model = _build(device, V=V, rnn=H, bidir=bidir)
     x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=1, ragged=True)
     ys = model(x.to(device))
     assert isinstance(ys, tuple) and len(ys) == T and ys[0].shape == (B, V) and ys[0].dtype == torch.float32
+    before = _ops.CALLS.get("layernorm_ctc_bwd", 0)
     loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
     loss.backward()
+    from asr.functions import join_side_stream
+    join_side_stream()
+    torch.cuda.synchronize()
+    fused = _ops.CALLS.get("layernorm_ctc_bwd", 0) > before
+    assert fused == (V % 4 == 0)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir)
-    logits_ref = ref(x)
-    loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
-    loss_ref.backward()
     logits = torch.stack(ys).detach().cpu()
-    assert _cos(logits, logits_ref.detach()) > 0.999
-    assert abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()) < 2e-2
-    grads = dict(model.named_parameters())
-    worst = 1.0
-    for name, p in grads.items():
-        g_ref = ref.g(name).grad
-        assert p.grad is not None, name
-        c = _cos(p.grad.cpu(), g_ref)
-        worst = min(worst, c)
-        assert c > 0.97, (name, c)
-        ratio = p.grad.cpu().norm().item() / (g_ref.norm().item() + 1e-30)
-        assert 0.9 < ratio < 1.1, (name, ratio)
-    assert worst > 0.97
+    gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2 if bidir else 1) == torch.bfloat16
+    report = {}
+    for matched in (True, False):
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=fused)
+        logits_ref = ref(x)
+        loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+        loss_ref.backward()
+        errs = {name: _rel(p.grad.cpu(), ref.g(name).grad) for name, p in model.named_parameters()}
+        worst = max(errs, key=errs.get)
+        report[matched] = (abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), _rel(logits, logits_ref.detach()), errs[worst], worst)
+        if matched:
+            assert report[True][0] < MATCHED_LOSS_REL, report[True]
+            assert report[True][1] < 2e-3, report[True]
+            for name, e in errs.items():
+                assert e < MATCHED_GRAD_REL_L2, (name, e)
+        else:
+            assert _cos(logits, logits_ref.detach()) > 0.999
+            assert report[False][0] < 2e-2
+            for name, e in errs.items():
+                assert e < 0.25, (name, e)
+    print("model step B=%d T=%d V=%d H=%d: matched oracle loss %.1e logits %.1e worst grad %.1e (%s); float32 oracle loss %.1e logits %.1e "
+          "worst grad %.1e (%s)" % ((B, T, V, H) + report[True] + report[False]))
 
 
 def test_train_steps_follow_oracle(device):
@@ -466,23 +492,34 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
     from asr.functions import join_side_stream
     join_side_stream()
     torch.cuda.synchronize()
-    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-    out = ocnn.forward(arch, cfg, params, x)
-    assert out.shape == (B, V, 1, T)
-    logits_ref = ocnn.logits_tbv(out)
-    loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
-    loss_ref.backward()
     logits = torch.stack(tuple(ys)).detach().float().cpu()
-    assert _cos(logits, logits_ref.detach()) > 0.998, _cos(logits, logits_ref.detach())
-    assert abs(loss.item() - loss_ref.item()) <= 3e-2 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
-    for name, p in model.named_parameters():
-        g_ref = params[name].grad
-        assert p.grad is not None and g_ref is not None, name
-        c = _cos(p.grad.cpu(), g_ref)
-        # (a weight-norm g or a bias is a handful of numbers, each the difference of large bf16-rounded sums: looser)
-        assert c > (0.95 if p.numel() >= 256 else 0.90), (name, c)
-        ratio = p.grad.cpu().norm().item() / (g_ref.norm().item() + 1e-30)
-        assert 0.85 < ratio < 1.15, (name, ratio)
+    report = {}
+    for matched in (True, False):
+        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+        out = ocnn.forward(arch, cfg, params, x, matched=matched, fused_logit_bias=False)       # V = 19: three-kernel logit region
+        assert out.shape == (B, V, 1, T)
+        logits_ref = ocnn.logits_tbv(out)
+        loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
+        loss_ref.backward()
+        errs = {}
+        for name, p in model.named_parameters():
+            g_ref = params[name].grad
+            assert p.grad is not None and g_ref is not None, name
+            errs[name] = _rel(p.grad.cpu(), g_ref)
+        worst = max(errs, key=errs.get)
+        report[matched] = (abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), _rel(logits, logits_ref.detach()), errs[worst], worst)
+        if matched:         # one bar for every parameter, large or small (the float32 oracle needed 0.90 cosine for 16-element ones)
+            assert report[True][0] < MATCHED_LOSS_REL, report[True]
+            assert report[True][1] < 2e-3, report[True]
+            for name, e in errs.items():
+                assert e < MATCHED_GRAD_REL_L2, (name, e)
+        else:
+            assert _cos(logits, logits_ref.detach()) > 0.998
+            assert report[False][0] <= 3e-2
+            for name, e in errs.items():
+                assert e < 0.45, (name, e)
+    print("recipe %s/%d/wn=%s: matched oracle loss %.1e logits %.1e worst grad %.1e (%s); float32 oracle loss %.1e logits %.1e worst grad "
+          "%.1e (%s)" % ((arch, nconv, wn) + report[True] + report[False]))
 
 
 def test_fused_logit_region_gives_the_gradients_of_the_unfused_one(device):
@@ -516,3 +553,82 @@ def test_fused_logit_region_gives_the_gradients_of_the_unfused_one(device):
     # the logit projection's bias gradient comes out of the fused sweep in float32 (no bf16 rounding of dx in between)
     name = "dense_blocks._sequential_6.b"
     assert float((gf[name] - gu[name]).norm() / gu[name].norm()) < 5e-3
+
+
+def test_abort_word_of_a_third_stream_is_seen(device):
+    """one control buffer per (device, stream) that launched a recurrence; a process that ran recurrences on three
+    streams has three abort words, and the step control used to look at the first two.  All of them are ORed on the device now
+    (asr_gather_abort): raise the LAST one and the step must be dropped."""
+    from asr import _ops, _lib
+    from asr.loss import connectionist_temporal_classification
+    from asr.optimizers import Adam, GradientClipping
+    B, T, V = 4, 40, 29
+    cfg, model = _build(device, V=V, seed=3)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=2)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+    opt = Adam(alpha=1e-3, beta1=0.9)
+    model(xd)
+    opt.setup(model)
+    opt.add_hook(GradientClipping(1.0))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    with torch.no_grad():
+        for st in streams:                      # forward passes on two more streams: two more control buffers
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                model(xd)
+            torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    words = [w for w in _ops.abort_words() if w.device == device]
+    assert len(words) >= 3
+
+    def step():
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
+    step()
+    torch.cuda.synchronize()
+    assert opt.applied_steps() == 1
+    snap = opt.flat_parameters().clone()
+    last = list(_ops._SYNC.keys())[-1]
+    assert last[1] != torch.cuda.current_stream().cuda_stream          # not the stream the train step launches on
+    _ops._SYNC[last][1023:1024].fill_(1)
+    step()
+    torch.cuda.synchronize()
+    assert torch.equal(snap, opt.flat_parameters()) and opt.applied_steps() == 1
+    assert float(opt._flat["ctl"][5].item()) == 1.0
+    with pytest.raises(_lib.AsrHipError):
+        step()
+    torch.cuda.synchronize()
+    step()                                      # every word was cleared when the host was told
+    torch.cuda.synchronize()
+    assert opt.applied_steps() == 2
+
+
+@pytest.mark.parametrize("bidir", [False, True])
+def test_configs0_literal_shape(device, bidir):
+    """BASELINE configs[0] at its literal shape on the HIP path: 2 x conv + ONE GRU layer (ndim_conv 64, 512 units, dense 320), B=4,
+    T=200, V=119 (the reference's unigram inventory), one forward + CTC + backward against the float32 oracle (the configuration's
+    "Chainer CPU reference" stand-in) and the rounding-matched oracle"""
+    from asr import _ops
+    from asr.loss import connectionist_temporal_classification
+    B, T, V = 4, 200, 119
+    cfg, model = _build(device, V=V, conv=64, rnn=512, dense=320, nrnn=1, bidir=bidir, seed=9)
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=10, Lmax=30, seed=4, ragged=True)
+    ys = model(x.to(device))
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+    loss.backward()
+    from asr.functions import join_side_stream
+    join_side_stream()
+    torch.cuda.synchronize()
+    _ops.gru_check_sync()
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    gi_bf16 = _ops.gru_gi_dtype(T, B, 512, 2 if bidir else 1) == torch.bfloat16
+    for matched in (True, False):
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, 1, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=False)
+        loss_ref = omodel.ctc_mean_loss(ref(x), labels, x_len, l_len)
+        loss_ref.backward()
+        errs = {name: _rel(p.grad.cpu(), ref.g(name).grad) for name, p in model.named_parameters()}
+        worst = max(errs, key=errs.get)
+        lrel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+        print("configs[0] bidir=%s matched=%s: loss %.2e worst gradient %.2e (%s)" % (bidir, matched, lrel, errs[worst], worst))
+        assert lrel < (MATCHED_LOSS_REL if matched else 2e-2)
+        assert errs[worst] < (MATCHED_GRAD_REL_L2 if matched else 0.25), (worst, errs[worst])

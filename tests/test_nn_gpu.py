@@ -395,3 +395,51 @@ def test_nstep_bigru_has_chainers_call_semantics(device):
     assert rnn.l0_1.w_hh.grad is not None and torch.isfinite(rnn.l1_0.w_ih.grad).all()
     with pytest.raises(NotImplementedError):
         rnn(torch.zeros(L * 2, len(lens), H, device=device), [x.to(device) for x in xs])
+
+
+def test_projection_bias_gradient_with_a_second_consumer_of_the_logits(device):
+    """the fused LayerNorm + CTC sweep adds the column sums of ITS dx to the projection's bias gradient and marks it
+    done; a second consumer of the projection's output (a branch off the un-normalised logits) sends its gradient through autograd,
+    and the projection still owes the bias the column sums of that part.  Checked against the route with every shortcut off."""
+    from asr import functions as F, nn, _ops
+    from asr.loss import connectionist_temporal_classification
+    torch.manual_seed(3)
+    B, C, T, V, L = 3, 32, 40, 24, 4
+    x = torch.randn(B, C, 1, T).to(device)
+    lab = torch.randint(1, V, (B, L), dtype=torch.int32).to(device)
+    w = torch.randn(B, V, 1, T).to(device) * 0.05
+
+    def run(shortcuts):
+        torch.manual_seed(5)
+        proj = nn.Convolution2D(C, V, (1, 1)).to_gpu()
+        norm = nn.LayerNormalization(V).to_gpu()
+        proj.output_float32 = norm.output_float32 = True
+        keep = F.FUSE_CTC_INTO_LAYERNORM[0]
+        F.FUSE_CTC_INTO_LAYERNORM[0] = shortcuts
+        try:
+            before = _ops.CALLS.get("layernorm_ctc_bwd", 0)
+            h = proj(x)
+            y = norm(h)
+            tbv = y.permute(3, 0, 2, 1).squeeze(2)
+            loss = connectionist_temporal_classification(tbv, lab, 0) + (h * w).sum()
+            loss.backward()
+            F.join_side_stream()
+            torch.cuda.synchronize()
+            assert (_ops.CALLS.get("layernorm_ctc_bwd", 0) - before) == (1 if shortcuts else 0)
+            first = proj.b.grad.float().cpu().clone()
+            # a second backward pass over a fresh graph starts afresh (the flags were reset when read)
+            proj.cleargrads(); norm.cleargrads()
+            h = proj(x)
+            tbv = norm(h).permute(3, 0, 2, 1).squeeze(2)
+            (connectionist_temporal_classification(tbv, lab, 0) + (h * w).sum()).backward()
+            F.join_side_stream()
+            torch.cuda.synchronize()
+            assert torch.allclose(proj.b.grad.float().cpu(), first, rtol=1e-4, atol=1e-6)
+            return first, proj.W.grad.float().cpu().clone()
+        finally:
+            F.FUSE_CTC_INTO_LAYERNORM[0] = keep
+    (ba, wa), (bb, wb) = run(True), run(False)
+    want_extra = w.float().sum(dim=(0, 2, 3)).cpu()           # d/db of (h * w).sum()
+    assert float((bb - ba).norm()) <= 1e-2 * float(bb.norm()), (ba, bb)
+    assert float(want_extra.norm()) > 10 * float((bb - ba).norm())        # the second consumer's share is what would be missing
+    assert float((wa - wb).norm()) <= 2e-2 * float(wb.norm())

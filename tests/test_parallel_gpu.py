@@ -162,3 +162,93 @@ def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname
     # every slice went exactly once per step
     ks = [k for k, _ in two[0]["launches"]]
     assert sorted(ks) == list(range(len(ks)))
+
+
+# ---------------------------------------------------------------------------------------------- a rank's recurrence gives up
+# the device-side drop used to be rank-local although it is decided AFTER the gradients were summed: the
+# aborting rank dropped the step, its peers applied the polluted sum, and one step later the aborting rank raised in front of
+# finish_backward while the peers waited in an all-reduce.  Now the aborting rank plants a NaN in the reserved element of its
+# gradient buffer before the last slice is summed: every rank drops the same step, every rank learns why (ctl[5]) and raises at
+# the same update, after that step's collectives.
+ABORT_SCRIPT = r'''
+import os, sys, json
+ROOT = os.environ["ASR_ROOT"]
+sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd")); sys.path.insert(0, ROOT)
+import torch
+from asr import _ops, _lib
+from asr.loss import connectionist_temporal_classification
+from asr.optimizers import get_optimizer, GradientClipping, WeightDecay
+from asr.data.synthetic import synthetic_batch
+from asr.model import ds2
+from asr.parallel import Communicator
+from asr import link
+
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+out_path = sys.argv[1]
+dev = torch.device("cuda:0")
+_ops.GRU_MODE[0] = 1
+torch.manual_seed(7)
+V, B, T = 31, 8, 48
+cfg = ds2.configure(); cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 64, 32, 2
+model = ds2.Model(cfg).to_gpu(0)
+x, labels, x_len, l_len = synthetic_batch(B, T, V, Lmin=3, Lmax=9, seed=0)
+mine = slice(rank * (B // world), (rank + 1) * (B // world))
+xd, ld, xl, ll = x[mine].to(dev), labels[mine].to(dev), x_len[mine].to(dev), l_len[mine].to(dev)
+with torch.no_grad():
+    model(xd)
+opt = get_optimizer("adam", 1e-3, 0.9)
+opt.setup(model); opt.add_hook(GradientClipping(1.0)); opt.add_hook(WeightDecay(1e-5))
+comm = Communicator("gloo", buckets=3)
+comm.bcast_data(model)
+opt.set_communicator(comm)
+# mode 1 (per-step launches) uses no control buffer: give this process one, as a persistent launch would have
+_ops._sync_buffer(dev, 8192)
+def step():
+    loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+    opt.update(lossfun=lambda: loss)
+events = []
+step(); torch.cuda.synchronize()
+events.append(("applied", opt.applied_steps()))
+snap = opt.flat_parameters().detach().cpu().clone()
+if rank == 1:
+    list(_ops._SYNC.values())[0][1023:1024].fill_(1)         # forge: "a persistent launch of rank 1 gave up"
+step(); torch.cuda.synchronize()
+events.append(("applied", opt.applied_steps()))
+events.append(("ctl5", float(opt._flat["ctl"][5].item())))
+same = bool(torch.equal(snap, opt.flat_parameters().detach().cpu()))
+raised = False
+try:
+    step()
+except _lib.AsrHipError:
+    raised = True
+torch.cuda.synchronize()
+hooks_clear = link._GRAD_LISTENER[0] is None and _ops.RECURRENCE_HOOKS["before"] is None
+step(); torch.cuda.synchronize()
+events.append(("applied", opt.applied_steps()))
+torch.save({"events": events, "unchanged": same, "raised": raised, "hooks_clear": hooks_clear,
+            "end": opt.flat_parameters().detach().cpu()}, out_path)
+comm.barrier()
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_a_given_up_recurrence_on_one_rank_drops_the_step_on_every_rank(tmp_path):
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / ("abort_r%d.pt" % r))
+        env = dict(os.environ, ASR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", ABORT_SCRIPT, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+        outs.append(out)
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    res = [torch.load(o) for o in outs]
+    for r in res:
+        assert r["events"] == [("applied", 1), ("applied", 1), ("ctl5", 1.0), ("applied", 2)], r["events"]
+        assert r["unchanged"], "a rank applied the step although a peer's recurrence had given up"
+        assert r["raised"], "every rank must learn of the dropped step (and at the same update)"
+        assert r["hooks_clear"]
+    assert torch.equal(res[0]["end"], res[1]["end"]), "ranks diverged"
