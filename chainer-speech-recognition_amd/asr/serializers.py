@@ -8,10 +8,11 @@ registers the links of a sub-module on the OWNER under flattened names (:355-392
 ``_module_<ns>_link_<name>/W``.  ``chainer_name`` reproduces those paths from this package's module tree, so a file written
 here has the reference's keys and a reference-trained file is found key by key.
 
-Container.  HDF5 needs ``h5py``, which this image does not have (Chainer's own HDF5 serialiser has the same dependency);
-when it is importable ``save_hdf5`` / ``load_hdf5`` read and write real HDF5 groups / datasets.  Otherwise the same
-path -> array table goes into a NumPy ``.npz`` archive -- the layout of ``chainer.serializers.save_npz``, which the
-reference's models can read with ``load_npz`` -- under whatever file name the caller chose.  ``load`` recognises the
+Container.  ``model.save("model.hdf5")`` writes real HDF5 -- groups = links, datasets = parameters, exactly the tree
+``chainer.serializers.save_hdf5`` builds -- and ``load`` reads it back, including files h5py wrote with Chainer's default gzip
+compression.  ``h5py`` is used when it is importable; this image does not have it, so the file format itself is implemented in
+``asr/hdf5_lite.py`` (the subset the serialiser uses: classic groups, contiguous or chunked + deflate datasets of numbers).
+A file name ending in ``.npz`` selects the layout of ``chainer.serializers.save_npz`` instead.  ``load`` recognises the
 container from the file's first bytes (HDF5 signature, zip with .npy members, or a round-1 ``torch.save`` archive).
 
 Layout differences that a checkpoint must not see:
@@ -103,10 +104,15 @@ def to_table(model):
 
 
 def from_table(model, table, strict=True, reference_layout=True):
-    """copy a {chainer path: array} table into the model; returns the list of paths of the file that were not used"""
+    """copy a {chainer path: array} table into the model; returns the list of paths of the file that were not used.
+    strict: a file that lacks an entry of the model is refused BEFORE anything is copied (the model stays as it was)."""
     from .link import bump_weight_epoch
     perm = _permutations(model) if reference_layout else {}
     used, missing = set(), []
+    if strict:
+        lacking = [path for path, _, _ in _entries(model) if path not in table]
+        if lacking:
+            raise KeyError("checkpoint lacks %d entries, e.g. %s" % (len(lacking), lacking[:3]))
     with torch.no_grad():
         for path, name, t in _entries(model):
             if path not in table:
@@ -144,27 +150,53 @@ def load_npz(filename, model, strict=True):
 
 
 def save_hdf5(filename, model):
-    """chainer.serializers.save_hdf5 layout (groups = links, datasets = parameters); needs h5py"""
-    import h5py
-    with h5py.File(filename, "w") as f:
-        for path, a in to_table(model).items():
-            f.create_dataset(path, data=a)
+    """chainer.serializers.save_hdf5 layout (groups = links, datasets = parameters): through h5py where it exists, else through
+    this package's own writer of the same format (asr/hdf5_lite.py)"""
+    table = to_table(model)
+    if have_h5py():
+        import h5py
+        with h5py.File(filename, "w") as f:
+            for path, a in table.items():
+                f.create_dataset(path, data=a)
+        return
+    from . import hdf5_lite
+    hdf5_lite.write(filename, table)
+
+
+def read_hdf5_table(filename):
+    if have_h5py():
+        import h5py
+        table = {}
+        with h5py.File(filename, "r") as f:
+            def visit(name, obj):
+                if isinstance(obj, h5py.Dataset):
+                    table[name] = np.asarray(obj)
+            f.visititems(visit)
+        return table
+    from . import hdf5_lite
+    return hdf5_lite.read(filename)
 
 
 def load_hdf5(filename, model, strict=True):
-    import h5py
-    table = {}
-    with h5py.File(filename, "r") as f:
-        def visit(name, obj):
-            if isinstance(obj, h5py.Dataset):
-                table[name] = np.asarray(obj)
-        f.visititems(visit)
-    return from_table(model, table, strict)
+    return from_table(model, read_hdf5_table(filename), strict)
 
 
 def sniff(filename):
     with open(filename, "rb") as f:
         head = f.read(8)
+        if head != _HDF5_MAGIC:             # an HDF5 superblock may sit behind a user block of 512, 1024, ... bytes
+            pos = 512
+            while True:
+                f.seek(pos)
+                probe = f.read(8)
+                if len(probe) < 8:
+                    break
+                if probe == _HDF5_MAGIC:
+                    head = probe
+                    break
+                pos *= 2
+                if pos > (1 << 20):
+                    break
     if head == _HDF5_MAGIC:
         return "hdf5"
     if head[:2] == b"PK":
@@ -175,13 +207,13 @@ def sniff(filename):
 
 
 def save(filename, model):
-    """what ``model.save(filename)`` does: real HDF5 when h5py exists (the reference's format), else the npz container;
-    written to a temporary name and renamed (asr/model/cnn.py:51-56)"""
+    """what ``model.save(filename)`` does: HDF5, the reference's format (a name ending in .npz: the npz container); written to a
+    temporary name and renamed (asr/model/cnn.py:51-56)"""
     tmp = filename + "." + str(uuid.uuid4())
-    if have_h5py() and not filename.endswith(".npz"):
-        save_hdf5(tmp, model)
-    else:
+    if filename.endswith(".npz"):
         save_npz(tmp, model)
+    else:
+        save_hdf5(tmp, model)
     if os.path.isfile(filename):
         os.remove(filename)
     os.rename(tmp, filename)
@@ -192,9 +224,6 @@ def load(filename, model, strict=True):
     if kind == "npz":
         return load_npz(filename, model, strict)
     if kind == "hdf5":
-        if not have_h5py():
-            raise RuntimeError("%s is an HDF5 file and h5py is not installed; convert it once with "
-                               "chainer.serializers.save_npz(...) where Chainer runs, or install h5py" % filename)
         return load_hdf5(filename, model, strict)
     if kind == "torch":         # round-1 checkpoints: a torch.save'd state_dict with this package's own names
         state = torch.load(filename, map_location="cpu")

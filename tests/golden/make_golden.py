@@ -392,5 +392,18 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def g_hdf5():
+    """tests/golden/tiny.hdf5: the bytes this package's own HDF5 writer (asr/hdf5_lite.py) produces for a fixed table -- not a
+    reference output (h5py does not exist here): a pin against accidental changes of the on-disk structures"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(OUT)), "chainer-speech-recognition_amd"))
+    from asr import hdf5_lite
+    table = {"layer_0/W": np.arange(24, dtype=np.float32).reshape(2, 3, 4) / 8, "layer_0/b": np.array([1.5, -2.0], np.float32),
+             "layer_5_0/W": np.ones((1, 2), np.float32), "N": np.array(3, np.int64)}
+    hdf5_lite.write(os.path.join(OUT, "tiny.hdf5"), table)
+
+
 if __name__ == "__main__":
-    main()
+    if "--hdf5" in sys.argv:
+        g_hdf5()
+    else:
+        main()
