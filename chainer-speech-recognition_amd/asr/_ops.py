@@ -513,14 +513,23 @@ def sgd_ctl(p, g, v, kind, lr, momentum, weight_decay, ctl):
     check(rc, "asr_sgd_ctl")
 
 
+SRU_CHUNKED = [True]        # (tests switch the chunked scans off to run the one-thread-per-column kernels)
+
+
+def _sru_ws(T, B, D, dev):
+    n = int(_lib.lib().asr_sru_ws_bytes(T, B, D)) if SRU_CHUNKED[0] else 0
+    return (torch.empty(n, dtype=torch.uint8, device=dev), n) if n else (None, 0)
+
+
 def sru_fwd(x, U, bias, c0, mask, use_tanh):
     """x (T, B, D) bf16, U (T*B, 3D) f32 -> H bf16, C f32, cT (B, D) f32."""
     T, B, D = x.shape
     H = torch.empty_like(x)
     C = torch.empty((T, B, D), dtype=F32, device=x.device)
     cT = torch.empty((B, D), dtype=F32, device=x.device)
+    ws, n = _sru_ws(T, B, D, x.device)
     rc = _lib.lib().asr_sru_fwd(stream(), ptr(x), ptr(U), ptr(bias), ptr(c0), ptr(mask), ptr(H), ptr(C), ptr(cT), T, B, D,
-                                int(bool(use_tanh)))
+                                int(bool(use_tanh)), ptr(ws), n)
     check(rc, "asr_sru_fwd")
     return H, C, cT
 
@@ -530,8 +539,9 @@ def sru_bwd(x, U, bias, C, c0, mask, gH, gcT, gbias, use_tanh):
     gU = torch.empty((T * B, 3 * D), dtype=BF16, device=x.device)
     gxh = torch.empty_like(x)
     gc0 = torch.empty((B, D), dtype=F32, device=x.device)
+    ws, n = _sru_ws(T, B, D, x.device)
     rc = _lib.lib().asr_sru_bwd(stream(), ptr(x), ptr(U), ptr(bias), ptr(C), ptr(c0), ptr(mask), ptr(gH), ptr(gcT), ptr(gU),
-                                ptr(gxh), ptr(gbias), ptr(gc0), T, B, D, int(bool(use_tanh)))
+                                ptr(gxh), ptr(gbias), ptr(gc0), T, B, D, int(bool(use_tanh)), ptr(ws), n)
     check(rc, "asr_sru_bwd")
     return gU, gxh, gc0
 

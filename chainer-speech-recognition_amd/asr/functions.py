@@ -152,6 +152,7 @@ def _producer_mailbox(x2):
 # in registers inside its own sweep (csrc/ctc_ln.hip).  Whatever else flows into the logits arrives through autograd as usual
 # and is added by a second, plain backward sweep.
 FUSE_CTC_INTO_LAYERNORM = [True]
+LAST_FUSED_RECIPES = [0]        # number of loss recipes the last fused LayerNorm + CTC backward took (tests)
 
 
 class _CtcBox(object):
@@ -718,6 +719,7 @@ class _LayerNorm(torch.autograd.Function):
         recipes = box.take() if box is not None else []
         dx = None
         if recipes:
+            LAST_FUSED_RECIPES[0] = len(recipes)
             T, B, _ = box.shape
             # the whole gradient of x2 is formed in this sweep: its column sums are the bias gradient of the projection in front
             dxsum = None

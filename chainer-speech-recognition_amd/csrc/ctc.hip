@@ -153,6 +153,12 @@ __device__ __forceinline__ double lse_masked(const double* v, int mask) {
     return m + (double)__logf(acc);                                  // acc in [1, NK]
 }
 
+// __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: in the one-node-per-thread loops it made every time step wait for
+// the alpha / beta store it had just issued AND for the lp prefetch of four steps ahead -- a memory round trip per step on a chain of
+// 1000 steps.  The exchange between the steps is LDS only: wait for the LDS operations, then the barrier; the prefetched values are
+// waited for where they are used (the compiler counts vmcnt), the stores never.
+#define ASR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <int NK>
 __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__ lp, const int* __restrict__ x_len,
                                                        const int* __restrict__ path_label,
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__
                     cur[sidx] = a;
                     outb[(size_t)t * Sp + sidx] = a;
                     lq[j] = t + PF < xl ? lpb[(size_t)(t + PF) * Sp + sidx] : 0.f;
-                    __syncthreads();
+                    ASR_LDS_BARRIER();
                     double* tmp = prev; prev = cur; cur = tmp;
                 }
             }
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__
                     outb[(size_t)t * Sp + sidx] = bt;
                     cur[sidx] = bt + (double)lq[j];
                     lq[j] = t - PF >= 0 ? lpb[(size_t)(t - PF) * Sp + sidx] : 0.f;
-                    __syncthreads();
+                    ASR_LDS_BARRIER();
                     double* tmp = prev; prev = cur; cur = tmp;
                 }
             }

@@ -322,12 +322,16 @@ int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const flo
  * backward_gpu :372-433).  x, H, gH, gxh: (T, B, D) bf16;  U, gU: (T*B, 3D) [z | f | r] (U f32, gU bf16);
  * C (T, B, D) f32; bias (2D) [b_f | b_r]; c0, cT, gcT, gc0, mask: (B, D) f32 (c0 / mask / gH / gcT may be NULL).
  * asr_sru_combine: out = (a + b) * mask  (b NULL: out = a * mask) -- highway + projection gradient, input masking.
+ * ws: asr_sru_ws_bytes(T, B, D) bytes of scratch (16-B aligned) for the chunked scans -- the cell recurrence is linear in c (and its
+ * backward in gc), so time is cut into chunks that run in parallel, joined through per-chunk (product, sum) summaries (csrc/sru.hip);
+ * NULL / too small / odd D / short T: the one-thread-per-column scans of the reference's shape serve.
  */
+size_t asr_sru_ws_bytes(int T, int B, int D);
 int asr_sru_fwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* c0, const float* mask,
-                void* H_bf16, float* C, float* cT, int T, int B, int D, int use_tanh);
+                void* H_bf16, float* C, float* cT, int T, int B, int D, int use_tanh, void* ws, size_t ws_bytes);
 int asr_sru_bwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* C, const float* c0,
                 const float* mask, const void* gH_bf16, const float* gcT, void* gU_bf16, void* gxh_bf16, float* gbias,
-                float* gc0, int T, int B, int D, int use_tanh);
+                float* gc0, int T, int B, int D, int use_tanh, void* ws, size_t ws_bytes);
 int asr_sru_combine(void* stream, const void* a_bf16, const void* b_bf16, const float* mask, void* out_bf16, long long n,
                     int BD);
 

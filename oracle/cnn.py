@@ -90,24 +90,53 @@ def _layer_norm(x, gamma, beta):
     return diff / std * gamma.reshape(1, -1, 1, 1) + beta.reshape(1, -1, 1, 1)
 
 
-def forward(arch, cfg, params, x, matched=False, fused_logit_bias=False):
+def forward(arch, cfg, params, x, matched=False, fused_logit_bias=False, weights=None):
     """params: dict name -> torch tensor (requires_grad as the caller likes) with this package's state_dict names
     (``layer_0.W`` ...; a weight-normalised layer has ``.V``, ``.g``, ``.b``).  x (B, C, H, T) -> logits (B, V, 1, T).
     matched: bf16 roundings where the HIP path rounds (oracle/bf16.py): every operator output except the last projection and the
     last normalisation (float32 logits), every activation gradient an operator writes; fused_logit_bias: the last projection's
-    bias gradient is the float32 column sum formed inside the fused LayerNorm + CTC sweep (V % 4 == 0)."""
+    bias gradient is the float32 column sum formed inside the fused LayerNorm + CTC sweep (V % 4 == 0).
+    weights: {layer name: float32 W} -- the VALUE a weight-normalised layer's W takes in the forward pass (the device's own
+    g V / (||V|| + 1e-9): its last float32 bit depends on the order of the norm's sum and decides bf16 roundings of W); gradients still
+    flow through the formula."""
+    from . import bf16 as Q
+    prog = program(arch, cfg)
+    h = Q.rnd(x) if matched else x
+    return run(prog, 0, len(prog), params, h, matched, fused_logit_bias, weights)
+
+
+def segments(prog):
+    """[(lo, hi)] index ranges of `prog`, one per entry of the model's layer list: a Residual (res_begin .. res_end) is ONE entry"""
+    out, i = [], 0
+    while i < len(prog):
+        if prog[i][0] == "res_begin":
+            j = i
+            while prog[j][0] != "res_end":
+                j += 1
+            out.append((i, j + 1))
+            i = j + 1
+        else:
+            out.append((i, i + 1))
+            i += 1
+    return out
+
+
+def run(prog, lo, hi, params, h, matched=False, fused_logit_bias=False, weights=None):
+    """apply prog[lo:hi] to h (the ops of the whole recipe decide which projection / normalisation are the float32 logit layers)"""
     from . import bf16 as Q
     on = bool(matched)
-    prog = program(arch, cfg)
     last_conv = max(i for i, (op, _, _) in enumerate(prog) if op in ("conv", "glu"))
     last_ln = max(i for i, (op, _, _) in enumerate(prog) if op == "ln")
-    h, skip = (Q.rnd(x) if on else x), None
-    for i, (op, name, args) in enumerate(prog):
+    skip = None
+    for i in range(lo, hi):
+        op, name, args = prog[i]
         if op in ("conv", "glu"):
             ph, pt = args
             if name + ".V" in params:                                     # asr/nn/convolution_2d.py:21-25,62-64
                 V = params[name + ".V"]
                 W = params[name + ".g"] * V / (torch.sqrt((V * V).sum(dim=(1, 2, 3), keepdim=True)) + 1e-9)
+                if weights is not None and name in weights:
+                    W = W + (weights[name].reshape(W.shape) - W.detach())
             else:
                 W = params[name + ".W"]
             b = params.get(name + ".b")

@@ -93,13 +93,19 @@ def test_lengths_equal_truncated_utterances(device):
     x = torch.randn(B, I, T, generator=g)
     x_len = torch.tensor([48, 20, 1, 33, 47, 9], dtype=torch.int32)
     layer = nn.BiGRU(I, H).to_gpu()
-    y = layer(x.to(device), x_len.to(device)).detach().float().cpu()
-    for b in range(B):
-        L = int(x_len[b])
-        alone = layer(x[b:b + 1, :, :L].contiguous().to(device)).detach().float().cpu()
-        torch.cuda.synchronize()
-        assert _rel(y[b, :, :L], alone[0]) < 2e-3, (b, _rel(y[b, :, :L], alone[0]))
-        assert float(y[b, :, L:].abs().max()) == 0.0 if L < T else True
+    # B = 6 and B = 1 are served by different forward kernels, one of which takes its input projections in bf16: keep them float32
+    # for both, so that the only difference left is float32 summation order
+    _ops.GRU_GI_BF16[0] = False
+    try:
+        y = layer(x.to(device), x_len.to(device)).detach().float().cpu()
+        for b in range(B):
+            L = int(x_len[b])
+            alone = layer(x[b:b + 1, :, :L].contiguous().to(device)).detach().float().cpu()
+            torch.cuda.synchronize()
+            assert _rel(y[b, :, :L], alone[0]) < 2e-3, (b, _rel(y[b, :, :L], alone[0]))
+            assert float(y[b, :, L:].abs().max()) == 0.0 if L < T else True
+    finally:
+        _ops.GRU_GI_BF16[0] = True
     _ops.gru_check_sync()
 
 

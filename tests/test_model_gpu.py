@@ -35,6 +35,7 @@ def _rel(a, b):
 # fast exp / rcp of the gate math and float32-vs-float64 CTC -- a dropped tap, a wrong pad or a missing term shows at once.
 # FP32: the plain float32 oracle; the distance to it is the price of bf16 activations (reported, loosely bounded).
 MATCHED_GRAD_REL_L2 = 5e-3
+MATCHED_GRAD_DEEP = 4e-2        # 8 convolutions / a recurrence of hundreds of steps with 512 units: measured 0.9e-2 .. 1.7e-2
 MATCHED_LOSS_REL = 1e-3
 
 
@@ -494,9 +495,17 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
     torch.cuda.synchronize()
     logits = torch.stack(tuple(ys)).detach().float().cpu()
     report = {}
+    # the VALUE of every weight-normalised W as the device formed it (oracle.cnn.forward: the last float32 bit of g V / ||V|| decides
+    # bf16 roundings of W; without this the weight-normalised recipes sit 3e-4 per layer further from the oracle)
+    weights = {name: mod.W.detach().float().cpu() for name, mod in model.named_modules()
+               if hasattr(mod, "V") and hasattr(mod, "g") and mod.g.numel() > 0}
+    # two correct bf16 implementations drift apart with depth (a flipped rounding is amplified by the layers behind it: see the
+    # layer-by-layer test below, which is the tight one); the 8-convolution wide branch gets the wider end-to-end bar
+    deep = nconv > 4
     for matched in (True, False):
         params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
-        out = ocnn.forward(arch, cfg, params, x, matched=matched, fused_logit_bias=False)       # V = 19: three-kernel logit region
+        out = ocnn.forward(arch, cfg, params, x, matched=matched, fused_logit_bias=False,        # V = 19: three-kernel logit region
+                           weights=weights if matched else None)
         assert out.shape == (B, V, 1, T)
         logits_ref = ocnn.logits_tbv(out)
         loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
@@ -510,9 +519,9 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         report[matched] = (abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), _rel(logits, logits_ref.detach()), errs[worst], worst)
         if matched:         # one bar for every parameter, large or small (the float32 oracle needed 0.90 cosine for 16-element ones)
             assert report[True][0] < MATCHED_LOSS_REL, report[True]
-            assert report[True][1] < 2e-3, report[True]
+            assert report[True][1] < (5e-3 if deep else 2e-3), report[True]
             for name, e in errs.items():
-                assert e < MATCHED_GRAD_REL_L2, (name, e)
+                assert e < (MATCHED_GRAD_DEEP if deep else MATCHED_GRAD_REL_L2) * (3 if name.endswith(".g") else 1), (name, e)
         else:
             assert _cos(logits, logits_ref.detach()) > 0.998
             assert report[False][0] <= 3e-2
@@ -630,5 +639,138 @@ def test_configs0_literal_shape(device, bidir):
         worst = max(errs, key=errs.get)
         lrel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
         print("configs[0] bidir=%s matched=%s: loss %.2e worst gradient %.2e (%s)" % (bidir, matched, lrel, errs[worst], worst))
-        assert lrel < (MATCHED_LOSS_REL if matched else 2e-2)
-        assert errs[worst] < (MATCHED_GRAD_REL_L2 if matched else 0.25), (worst, errs[worst])
+        assert lrel < (1e-4 if matched else 2e-2)
+        assert errs[worst] < (MATCHED_GRAD_DEEP if matched else 0.25), (worst, errs[worst])
+
+
+# ---------------------------------------------------------------------------------------------- layer by layer
+# End to end, two correct bf16 implementations drift apart with depth: a last-bit difference in a float32 sum flips one bf16 rounding,
+# the next layers amplify it (measured on the 8-layer wide recipe: 6e-5 after the fourth convolution, 1.1e-3 four residual blocks
+# later, 1.7e-2 in the first layer's gradient -- with every layer correct).  So the end-to-end gate above cannot be both tight and
+# depth independent.  This test is: every layer (a Residual block counts as one, Maxout + MaxPooling as the fused pair the device
+# runs) is given the DEVICE's own input and the DEVICE's own output gradient, and its output, its input gradient and its parameter
+# gradients must match the rounding-matched oracle of that ONE layer -- no accumulation, one bar for every layer of every recipe.
+LAYER_REL_L2 = 5e-4
+LAYER_GX_COL2IM = 5e-3
+
+
+def _trace_layers(model, xd):
+    """model(xd) with every top-level layer's input / output recorded and a hook on every output's gradient"""
+    from asr.nn import nn as nnmod
+    from asr import functions as F
+    rec = []
+    orig = nnmod._apply_layers
+
+    def traced(layers, x):
+        if layers is not model.layers:
+            return orig(layers, x)
+        i = 0
+        while i < len(layers):
+            j = nnmod._fusable_pool(layers, i) if x.dim() == 4 else -1
+            xin = x
+            if j > 0:
+                ks = layers[j].ksize
+                x = F.maxout_max_pooling(x, ks[0] if isinstance(ks, (tuple, list)) else ks, sole_consumer=i > 0)
+                span = (i, j + 1)
+                i = j + 1
+            else:
+                y = layers[i](x)
+                if isinstance(layers[i], nnmod.Residual):
+                    y = F.add(y, x)
+                x = y
+                span = (i, i + 1)
+                i += 1
+            entry = {"span": span, "xin": xin.detach(), "xout": x.detach(), "gout": None}
+            if x.requires_grad:
+                x.register_hook(lambda g, e=entry: e.__setitem__("gout", g.detach().clone()))
+            rec.append(entry)
+        return x
+    nnmod._apply_layers = traced
+    try:
+        ys = model(xd)
+    finally:
+        nnmod._apply_layers = orig
+    return ys, rec
+
+
+@pytest.mark.parametrize("arch,nconv,wn", [("zhang", 3, False), ("zhang", 3, True), ("zhang+fc_relu", 2, False), ("zhang+residual", 4, False),
+                                           ("zhang+residual", 6, False), ("zhang+residual", 5, True), ("zhang+layernorm", 2, False),
+                                           ("glu", 2, True), ("relu+layernorm", 2, False), ("relu+layernorm+residual", 3, False)])
+def test_cnn_recipes_layer_by_layer_against_the_matched_oracle(device, arch, nconv, wn):
+    from asr.model import cnn
+    from asr.model.architectures import build_model
+    from asr.loss import connectionist_temporal_classification
+    from asr import functions as F
+    from oracle import cnn as ocnn
+    torch.manual_seed(3)
+    V, B, T = 19, 3, 36
+    cfg = cnn.configure()
+    cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = V, 3, 16, 24, nconv
+    cfg.architecture, cfg.weightnorm = arch, wn
+    model = build_model(cfg).to_gpu()
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=2, Lmax=6, seed=7, ragged=True)
+    xd = x.to(device)
+    with torch.no_grad():
+        model(xd)
+    ys, rec = _trace_layers(model, xd)
+    loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
+    loss.backward()
+    F.join_side_stream()
+    torch.cuda.synchronize()
+    prog = ocnn.program(arch, cfg)
+    segs = ocnn.segments(prog)
+    assert len(segs) == len(model.layers)
+    # the VALUE of a weight-normalised W as the device formed it (see oracle.cnn.forward): the layers' W property re-runs the kernel
+    weights = {}
+    for name, mod in model.named_modules():
+        if hasattr(mod, "V") and hasattr(mod, "g") and getattr(mod, "g").numel() > 0:
+            weights[name] = mod.W.detach().float().cpu()
+    dev_grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+    worst = {"y": (-1.0, ""), "gx": (-1.0, ""), "gp": (-1.0, "")}
+
+    def note(kind, err, what):
+        if err > worst[kind][0]:
+            worst[kind] = (err, what)
+    checked_grads = set()
+    for k, e in enumerate(rec):
+        lo, hi = segs[e["span"][0]][0], segs[e["span"][1] - 1][1]
+        names = sorted({n for (_, n, _) in prog[lo:hi] if n is not None})
+        params = {pn: v.detach().cpu().clone().requires_grad_(True) for pn, v in model.named_parameters() if pn.rsplit(".", 1)[0] in names}
+        xin = e["xin"].float().cpu()
+        if k == 0:
+            xin = xin.to(torch.bfloat16).float()           # the first layer packs the loader's float32 minibatch to bf16
+        xin.requires_grad_(k > 0)
+        y = ocnn.run(prog, lo, hi, params, xin, matched=True, fused_logit_bias=False, weights=weights)
+        got = e["xout"].float().cpu()
+        tag = "%s[%d:%d] %s" % (arch, lo, hi, ",".join(names))
+        err = _rel(got, y.detach())
+        note("y", err, tag)
+        assert err < LAYER_REL_L2, ("forward", tag, err)
+        gout = e["gout"]
+        if gout is None or float(gout.float().abs().max()) == 0.0:
+            continue            # the float32 logit layers hand their gradient over outside autograd (functions._GradMailbox): see test_ctc_gpu
+        y.backward(gout.float().cpu())
+        # a convolution whose Cout * kh * kw is not a multiple of 32 takes the column-matrix route backward (gemm + col2im): its
+        # per-tap products are rounded to bf16 before col2im adds them -- one more rounding than the implicit kernel (every recipe
+        # size of the reference takes the implicit one: Cout in {128, 256, 512, 640}; the 16-channel layers of this test do not).
+        # Whatever lies upstream of such a convolution INSIDE the unit (the LayerNormalization of a pre-activation Residual) sees it too.
+        def own(n):
+            return params[n + (".V" if n + ".V" in params else ".W")]
+        col2im = [n for (op, n, _) in prog[lo:hi] if op in ("conv", "glu") and tuple(own(n).shape[2:]) == (3, 5) and (own(n).shape[0] * 15) % 32 != 0]
+        if k > 0 and rec[k - 1]["gout"] is not None and float(rec[k - 1]["gout"].float().abs().max()) > 0.0:
+            # (the device's tensor is bf16: where two branches meet -- a Residual's skip and its convolution -- the sum is rounded once more)
+            err = _rel(rec[k - 1]["gout"].float().cpu(), xin.grad.to(torch.bfloat16).float())
+            note("gx", err, tag)
+            assert err < (LAYER_GX_COL2IM if col2im else LAYER_REL_L2), ("input gradient", tag, err)
+        for pn, v in params.items():
+            err = _rel(dev_grads[pn], v.grad)
+            note("gp", err, pn)
+            checked_grads.add(pn)
+            upstream_of_col2im = bool(col2im) and pn.rsplit(".", 1)[0] not in col2im
+            # a weight-norm g gradient is sum_k gW_k V_k / ||V|| per channel (asr/nn/convolution_2d.py:92): a signed sum of few hundred
+            # terms, so whatever error gW has shows amplified by the cancellation
+            tol = (LAYER_GX_COL2IM if upstream_of_col2im else LAYER_REL_L2) * (10 if pn.endswith(".g") else 1)
+            assert err < tol, ("parameter gradient", pn, err)
+    assert len(checked_grads) >= len(dev_grads) - 4, (len(checked_grads), len(dev_grads))      # all but the logit projection + its norm
+    print("layer by layer %s/%d/wn=%s: worst forward %.1e (%s), input gradient %.1e (%s), parameter gradient %.1e (%s)"
+          % (arch, nconv, wn, worst["y"][0], worst["y"][1], worst["gx"][0], worst["gx"][1], worst["gp"][0], worst["gp"][1]))

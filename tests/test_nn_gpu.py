@@ -443,3 +443,70 @@ def test_projection_bias_gradient_with_a_second_consumer_of_the_logits(device):
     assert float((bb - ba).norm()) <= 1e-2 * float(bb.norm()), (ba, bb)
     assert float(want_extra.norm()) > 10 * float((bb - ba).norm())        # the second consumer's share is what would be missing
     assert float((wa - wb).norm()) <= 2e-2 * float(wb.norm())
+
+
+# ------------------------------------------------------------------------------------------------ SRU, chunked scans
+@pytest.mark.parametrize("T,Bn,D,use_tanh,masked", [(77, 5, 96, True, False), (64, 3, 34, False, True), (200, 8, 128, True, True),
+                                                    (33, 2, 64, True, False), (1000, 4, 64, False, False)])
+def test_sru_chunked_scans_equal_the_column_scans(device, T, Bn, D, use_tanh, masked):
+    """csrc/sru.hip: the time-chunked scans (summaries + apply) against the one-thread-per-column kernels of the reference's shape
+    on the same inputs -- same formulas; the fast exp / rcp sigmoid and the chunk products change the last float32 bits only"""
+    from asr import _ops, _lib
+    from asr.nn.sru import sru
+    from asr.link import Parameter
+    assert _lib.lib().asr_sru_ws_bytes(T, Bn, D) > 0
+    torch.manual_seed(T + D)
+    X = _bf(torch.randn(Bn, D, T))
+    W = _bf(torch.randn(3 * D, D) * (0.6 / np.sqrt(D)))
+    Bias = torch.randn(2 * D) * 0.3
+    c0 = torch.randn(Bn, D)
+    mask = (torch.rand(Bn, D) > 0.3).float() if masked else None
+    gH = _bf(torch.randn(Bn, D, T))
+    gcT = torch.randn(Bn, D)
+    res = []
+    for chunked in (True, False):
+        _ops.SRU_CHUNKED[0] = chunked
+        try:
+            Xd = X.to(device).requires_grad_(True)
+            Wp, Bp = Parameter(W.to(device)), Parameter(Bias.to(device))
+            c0d = c0.to(device).requires_grad_(True)
+            H, C, cT = sru(Xd, Wp, Bp, c0d, use_tanh, None if mask is None else mask.to(device))
+            ((H.float() * gH.to(device)).sum() + (cT * gcT.to(device)).sum()).backward()
+            torch.cuda.synchronize()
+            res.append([t.detach().float().cpu() for t in (H, C, cT, Xd.grad, Wp.grad, Bp.grad, c0d.grad)])
+        finally:
+            _ops.SRU_CHUNKED[0] = True
+    for name, a, b in zip(("H", "C", "cT", "gX", "gW", "gB", "gc0"), *res):
+        tol = 1e-5 if name in ("C", "cT") else 4e-3          # bf16 outputs: a last-bit difference in float32 may flip a rounding
+        assert _rel(a, b) < tol, (name, _rel(a, b))
+
+
+@pytest.mark.parametrize("use_tanh", [True, False])
+def test_sru_full_size_against_the_oracle(device, use_tanh):
+    """T=1000, B=32, D=512 (the size tools/time_sru.py measures): H, C, c_T and every gradient against oracle.nn.sru_fwd / sru_bwd
+    (asr/nn/sru.py:289-324 forward_cpu restated, pinned by tests/golden/sru.npz; backward = kernel K2 :75-191 restated)"""
+    from asr.nn.sru import sru
+    from asr.link import Parameter
+    torch.manual_seed(7)
+    Bn, D, T = 32, 512, 1000
+    X = _bf(torch.randn(Bn, D, T))
+    W = _bf(torch.randn(3 * D, D) * (0.6 / np.sqrt(D)))
+    Bias = torch.randn(2 * D) * 0.3
+    c0 = torch.randn(Bn, D)
+    gH = _bf(torch.randn(Bn, D, T))
+    gcT = torch.randn(Bn, D)
+    Xd = X.to(device).requires_grad_(True)
+    Wp, Bp = Parameter(W.to(device)), Parameter(Bias.to(device))
+    c0d = c0.to(device).requires_grad_(True)
+    H, C, cT = sru(Xd, Wp, Bp, c0d, use_tanh)
+    ((H.float() * gH.to(device)).sum() + (cT * gcT.to(device)).sum()).backward()
+    torch.cuda.synchronize()
+    args = (X.double().numpy(), W.double().numpy(), Bias.double().numpy(), c0.double().numpy())
+    Hr, Cr, cTr = onn.sru_fwd(*args, use_tanh)
+    assert _rel(C.cpu(), Cr) < 2e-5 and _rel(cT.cpu(), cTr) < 2e-5
+    assert _rel(H.float().cpu(), Hr) < 5e-3
+    gX, gW, gb, gc = onn.sru_bwd(*args, gH.double().numpy(), gcT.double().numpy(), use_tanh)
+    errs = dict(gX=_rel(Xd.grad.float().cpu(), gX), gW=_rel(Wp.grad.cpu(), gW), gB=_rel(Bp.grad.cpu(), gb), gc0=_rel(c0d.grad.cpu(), gc))
+    print("full-size SRU (tanh=%s) vs float64 oracle:" % use_tanh, {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 1e-2, (k, v)
