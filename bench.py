@@ -200,7 +200,7 @@ def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
         H = cfg.ndim_rnn
         refm = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, cfg.bidirectional, matched=True,
                                 gi_bf16=(_o.gru_gi_dtype(T, B, H, 2 if cfg.bidirectional else 1) == torch.bfloat16),
-                                fused_logit_bias=(V % 4 == 0))
+                                fused_logit_bias=(V % 4 == 0), gates_f16=_o.gru_gates_f16(T, B, H, 2 if cfg.bidirectional else 1))
         logits_m = refm(x)
         loss_m = omodel.ctc_mean_loss(logits_m, labels, x_len, l_len)
         loss_m.backward()

@@ -2,6 +2,8 @@
 
 Everything numeric happens inside libasr_hip.so.  torch is used for allocation and stream handles.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -371,6 +373,16 @@ def _hook(name):
 
 
 GRU_GI_BF16 = [True]        # write the input projections in bf16 where the recurrence kernel takes them (tests may switch it off)
+# saved gates in IEEE half where the default kernel pair serves (asr_hip.h).  OFF by default: measured at T=1000, B=32, H=512 it saves
+# 40 % of the forward storer's bytes and a third of the backward loader's and buys nothing (forward 1.233 -> 1.233 us per step,
+# backward 1.34 -> 1.37): the CU's memory queue is bound by the NUMBER of requests beside the hand-off, and 32-B pieces of half
+# gates make as many as 64-B pieces of float32 ones
+GRU_GATES_F16 = [os.environ.get("ASR_GRU_GATES_F16", "0") != "0"]
+
+
+def gru_gates_f16(T, B, H, ndir):
+    """whether a recurrence of this shape keeps its saved gates in half precision (the rounding-matched oracle asks)"""
+    return bool(GRU_GATES_F16[0] and _lib.lib().asr_gru_gates_f16_ok(T, B, H, ndir, GRU_MODE[0]))
 
 
 def gru_gi_dtype(T, B, H, ndir):
@@ -396,10 +408,11 @@ def gru_fwd(gi, whh16, bhh, T, B, H, ndir, x_len=None):
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))
     hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
     hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
-    gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
+    f16 = bool(GRU_GATES_F16[0] and _lib.lib().asr_gru_gates_f16_ok(T, B, H, ndir, GRU_MODE[0]))
+    gates = torch.empty((T * B, ndir, 4, H), dtype=torch.float16 if f16 else F32, device=dev)
     y = torch.empty((T * B, H), dtype=BF16, device=dev)
     rc = _lib.lib().asr_gru_fwd(stream(), ptr(gi), _is_bf16(gi), ptr(whh16), ptr(bhh), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
-                                T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len))
+                                T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len), int(f16))
     check(rc, "asr_gru_fwd")
     LAST_SYNC[0] = sync
     return y, hseq, hseq16, gates
@@ -439,7 +452,8 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None, x_le
     carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
     _hook("before")
     rc = _lib.lib().asr_gru_bwd(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(whhT16), ptr(dgi), ptr(dgh),
-                                ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len), ptr(dy_ws))
+                                ptr(carry), ptr(db_ih), ptr(db_hh), T, B, H, ndir, ptr(sync), GRU_MODE[0], ptr(x_len), ptr(dy_ws),
+                                int(gates.dtype == torch.float16))
     check(rc, "asr_gru_bwd")
     _hook("after")
     LAST_SYNC[0] = sync

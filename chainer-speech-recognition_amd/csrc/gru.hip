@@ -1344,7 +1344,9 @@ constexpr int PS_RING = 4;
 __host__ __device__ inline size_t ps_exchange_bytes(int nrec_pad, int H) { return (size_t)PS_RING * nrec_pad * (H / 32) * H * 8; }
 constexpr size_t kPsOffset = 4096 + kShardBytes;      // behind the control words and the sharded counters
 
-template <int NT, bool LOCAL>
+// G16: the saved gates arrive as IEEE half (fwd_persistent_io_kernel<.., G16>): ONE LDS-DMA instruction brings r | z | n | q of a
+// step (4 gates x 4 rows x 64 B) instead of two, the slot image is [4 gates][4 rows][32 units] half.
+template <int NT, bool LOCAL, bool G16 = false>
 __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ hseq, const uint16_t* __restrict__ whhT,
                                                         uint16_t* __restrict__ dgi, uint16_t* __restrict__ dgh, float* __restrict__ db_ih,
@@ -1383,6 +1385,10 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     const int lrow = (lane & 31) >> 3, lyrow = (lane - 32) >> 2;
     const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4 +
                        (size_t)(lane >> 5) * H;
+    // G16: lane = (gate lane / 16, row (lane % 16) / 4, units 8 (lane % 4) ..)
+    const int lrow16 = (lane & 15) >> 2;
+    const uint16_t* lgp16 = reinterpret_cast<const uint16_t*>(gates) + (((size_t)tfirst * B + b0 + (lrow16 < Bl ? lrow16 : 0)) * ndir + d) * 4 * H +
+                            j0 + (lane & 3) * 8 + (size_t)(lane >> 4) * H;
     const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
                        (size_t)d * H + j0 + (lane & 7) * 4;
     const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lane >= 32 && lane < 48 && lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
@@ -1392,14 +1398,16 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     auto issue = [&](int sq) {              // called with sq = 0, 1, 2, ... in order
         if (sq < T) {
             char* sl = opring + (sq % BIO_GD) * BIO_SLOT;
-            if (lrow < Bl) {
+            if (G16) {
+                if (lrow16 < Bl) __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp16, (lds_ptr_t)sl, 16, 0, 0);
+            } else if (lrow < Bl) {
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)sl, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(sl + 1024), 16, 0, 0);
             }
             if (lane < 32 ? (lrow < Bl && sq < T - 1) : (lane < 48 && lyrow < Bl))
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)l2p, (lds_ptr_t)(sl + 2048), 16, 0, 0);
         }
-        lgp += lgs; l2p += l2s;
+        lgp += lgs; lgp16 += lgs; l2p += l2s;
     };
     // ---- storer (wave 9): dgi = (ar, az, an) and dgh = (ar, az, aq): 3 gates x 4 rows x 64 B = 48 pieces of 16 B each
     auto store_step = [&](int sp) {
@@ -1486,7 +1494,12 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
         if (gate_wave) {
             const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
             const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
-            r = of[0]; z = of[128]; n = of[256]; qq = of[384];
+            if (G16) {
+                const _Float16* oh = reinterpret_cast<const _Float16*>(sl) + b * 32 + u0;
+                r = (float)oh[0]; z = (float)oh[128]; n = (float)oh[256]; qq = (float)oh[384];
+            } else {
+                r = of[0]; z = of[128]; n = of[256]; qq = of[384];
+            }
             hp = s < T - 1 ? of[512] : 0.f;
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
             dyc = dyy + carry;                          // dh = dy + z dh' + (the exchanged sum)
@@ -1545,8 +1558,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
         if (is_loader) {
             issue(s + BIO_GD);              // the slot step s read above (before barrier R); waits until step s + 2 has landed
             const int left = T - 1 - (s + 2);
-            if (left >= BIO_GD - 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (left == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            // (in flight afterwards: the issues of the two youngest steps, 3 LDS-DMA instructions each -- 2 with half gates)
+            if (left >= BIO_GD - 2) { if (G16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else if (left == 1) { if (G16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else if (is_storer) {
             if (s > 0) store_step(s - 1);
@@ -1648,7 +1662,12 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 // Raw barriers (s_barrier + lgkmcnt(0)): __syncthreads() would also wait for the loader's LDS-DMA in flight.
 // GI16: the input projections arrive in bf16 (asr_gemm_nt with a bf16 output: half the bytes written by the projection and
 // read here, ONE LDS-DMA instruction per step instead of two): ring slot = [3 gates][8 rows][16 units] bf16 = 768 B.
-template <int KSW, bool LOCAL, bool GI16, bool RING>
+// G16: the saved gates (r, z, n, q) go to memory as IEEE half (r, z, n lie in [-1, 1], q = gh_n is O(1): 11 significant bits, i.e.
+// 2^-11 relative rounding -- eight times finer than the bf16 every activation of the path carries) instead of float32: the storer
+// wave converts on its way from the LDS staging ring to memory (the gate waves, i.e. the step's critical chain, are untouched),
+// 2 store instructions per step instead of 3 and half the gate bytes in the CU's memory queue beside the hand-off (what-if builds of
+// round 2: -5 % per recurrence).  The backward kernel that reads them is bwd_ps_kernel<.., G16 = true>.
+template <int KSW, bool LOCAL, bool GI16, bool RING, bool G16 = false>
 __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
@@ -1719,9 +1738,37 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         }
     };
     // storer: 5 arrays x 8 rows x 64 B = 160 pieces: piece p = lane + 64 i (i < 3, p < 160): array p / 32, row (p % 32) / 4
+    // G16: the state's 32 pieces as they are, then 4 gate arrays x 8 rows x 32 B of halves = 64 pieces (two LDS reads each)
     auto store_step = [&](int sp) {
         const long long tq = tfirst + tstep * sp;
         const float* src = oring + (size_t)(sp & 1) * 5 * 8 * 16;
+        if (G16) {
+            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+            typedef float float2_t __attribute__((ext_vector_type(2)));
+            uint16_t* gates16 = reinterpret_cast<uint16_t*>(gates);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pp = lane + 64 * i;
+                if (pp < 32) {
+                    const int row = pp >> 2, c4 = (pp & 3) * 4;
+                    if (row < Bl)
+                        *reinterpret_cast<f32x4_asm*>(hseq + ((size_t)tq * B + b0 + row) * hs + (size_t)d * H + j0 + c4) = lds_read16_raw(src + pp * 4);
+                } else if (pp < 96) {
+                    const int q = pp - 32, arr = 1 + (q >> 4), row = (q & 15) >> 1, c8 = (q & 1) * 8;
+                    if (row < Bl) {
+                        const float* ls = src + arr * 128 + row * 16 + c8;
+                        const f32x4_asm v0 = lds_read16_raw(ls), v1 = lds_read16_raw(ls + 4);
+                        union { half2_t h[4]; uint4 u; } pk;
+                        pk.h[0] = __builtin_convertvector((float2_t){v0[0], v0[1]}, half2_t);
+                        pk.h[1] = __builtin_convertvector((float2_t){v0[2], v0[3]}, half2_t);
+                        pk.h[2] = __builtin_convertvector((float2_t){v1[0], v1[1]}, half2_t);
+                        pk.h[3] = __builtin_convertvector((float2_t){v1[2], v1[3]}, half2_t);
+                        *reinterpret_cast<uint4*>(gates16 + (((size_t)tq * B + b0 + row) * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c8) = pk.u;
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int pp = lane + 64 * i, arr = pp >> 5, row = (pp & 31) >> 2, c4 = (pp & 3) * 4;
@@ -3094,6 +3141,27 @@ static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_
     return 4;
 }
 
+// the default pair -- forward with the L2-resident ring hand-off, backward with the partial-sum exchange -- can keep the saved gates
+// in IEEE half (kernel comments: G16); every other kernel form reads / writes float32 gates
+static bool fwd_ring_form(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
+    if (fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return false;
+    static int ring_env = -1;
+    if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }
+    const int Gio = (B + 7) / 8, ksw = (H / 32 + 3) / 4;
+    return (mode == 0 || mode == 8) && ndir * Gio <= 8 && ksw >= 2 && ring_env != 0;
+}
+static bool bwd_ps_form(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
+    const int ksw = (3 * H / 32 + 3) / 4;
+    return can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12 && (mode == 0 || mode == 8 || mode == 9 || mode == 10) && H % 128 == 0 &&
+           H <= 1024 && ndir * ((B + 3) / 4) <= 16;
+}
+extern "C" int asr_gru_gates_f16_ok(int T, int B, int H, int ndir, int mode) {
+    if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
+    static int dummy;
+    const int fmode = (mode == 9 || mode == 10) ? 0 : mode;
+    return fwd_ring_form(T, B, H, ndir, fmode, &dummy) && bwd_ps_form(T, B, H, ndir, mode, &dummy) ? 1 : 0;
+}
+
 extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode) {
     if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
     if (mode == 9 || mode == 10) mode = 0;
@@ -3102,12 +3170,14 @@ extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mo
 }
 
 extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
-                           void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
-                           int mode, const int* x_len) {
+                           void* hseq_bf16, void* gates_any, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
+                           int mode, const int* x_len, int gates_f16) {
+    float* gates = reinterpret_cast<float*>(gates_any);
     if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     if (mode == 9 || mode == 10) mode = 0;      // (those select backward kernels)
+    if (gates_f16 && !fwd_ring_form(T, B, H, ndir, mode, sync_ws)) return ASR_ERR_UNSUPPORTED;       // (ask asr_gru_gates_f16_ok)
     const float* gi = reinterpret_cast<const float*>(gi_any);
     if (gi_bf16 && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
     hipStream_t st = (hipStream_t)stream;
@@ -3160,6 +3230,7 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
         static int ring_env = -1;
         if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }      // (0: the payload is polled in the bf16 sequence itself)
         const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
+        if (gates_f16 && !use_ring) return ASR_ERR_UNSUPPORTED;
         if (use_ring) {
             if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)8 * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
         } else if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
@@ -3171,14 +3242,22 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
         hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G, R>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
                            (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge_k : 0);         \
     } while (0)
+#define ASR_FWDIO16_(K, G)                                                                                                \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true, G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true, G, true, true>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge_k);                 \
+    } while (0)
 #define ASR_FWDIO(K)                                                                                                      \
     do {                                                                                                                  \
-        if (use_ring) { if (gi_bf16) ASR_FWDIO_(K, true, true, true); else ASR_FWDIO_(K, true, false, true); }            \
+        if (use_ring && gates_f16) { if (gi_bf16) ASR_FWDIO16_(K, true); else ASR_FWDIO16_(K, false); }                   \
+        else if (use_ring) { if (gi_bf16) ASR_FWDIO_(K, true, true, true); else ASR_FWDIO_(K, true, false, true); }       \
         else if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true, false); else ASR_FWDIO_(K, true, false, false); }        \
         else { if (gi_bf16) ASR_FWDIO_(K, false, true, false); else ASR_FWDIO_(K, false, false, false); }                 \
     } while (0)
         if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
 #undef ASR_FWDIO_
+#undef ASR_FWDIO16_
 #undef ASR_FWDIO
     } else if (grouped) {
         const int G = (B + RG - 1) / RG;
@@ -3227,11 +3306,13 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     return ASR_OK;
 }
 
-extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq,
+extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_any, const float* hseq,
                            const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih,
                            float* db_hh, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len,
-                           void* dy_ws) {
-    if (!dy_bf16 || !gates || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
+                           void* dy_ws, int gates_f16) {
+    if (!dy_bf16 || !gates_any || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
+    const float* gates = reinterpret_cast<const float*>(gates_any);
+    if (gates_f16 && !(bwd_ps_form(T, B, H, ndir, mode, sync_ws) && db_ih && db_hh)) return ASR_ERR_UNSUPPORTED;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -3281,12 +3362,16 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
         const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
         if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, ps_exchange_bytes(nrec_pad, H), st)) return ASR_ERR_LAUNCH;
         const dim3 wgrid(nrec_pad * (H / 32)), wblock(640);
-#define ASR_BWDPS(NT_)                                                                                                    \
+#define ASR_BWDPS_(NT_, G)                                                                                                \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)bwd_ps_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kExclusiveLds); \
-        hipLaunchKernelGGL((bwd_ps_kernel<NT_, true>), wgrid, wblock, kExclusiveLds, st, (const uint16_t*)dy_bf16, gates, hseq,    \
+        (void)hipFuncSetAttribute((const void*)bwd_ps_kernel<NT_, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kExclusiveLds); \
+        hipLaunchKernelGGL((bwd_ps_kernel<NT_, true, G>), wgrid, wblock, kExclusiveLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                            (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh, (unsigned*)sync_ws, \
                            T, B, H, ndir, mode == 10 ? 1 : 0);                                                            \
+    } while (0)
+#define ASR_BWDPS(NT_)                                                                                                    \
+    do {                                                                                                                  \
+        if (gates_f16) ASR_BWDPS_(NT_, true); else ASR_BWDPS_(NT_, false);                                                \
     } while (0)
         switch (H / 128) {
             case 1: ASR_BWDPS(1); break;
@@ -3297,6 +3382,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates
             default: return ASR_ERR_UNSUPPORTED;
         }
 #undef ASR_BWDPS
+#undef ASR_BWDPS_
         ASR_LAUNCH_CHECK();
         return ASR_OK;
     }

@@ -311,11 +311,15 @@ int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode);
  * asr_gru_fwd overwrites the update-gate columns of gi on the dead rows (gi is scratch of the caller's projection GEMM: it is
  * MODIFIED when x_len is given) so that z == 1.0f exactly, asr_gru_bwd drops dy on the dead rows into dy_ws ((T*B, H) bf16,
  * required with x_len) -- every recurrence kernel form serves ragged batches unchanged. */
+/* gates: (T*B, ndir, 4, H) = r | z | n | q saved for the backward pass, float32 -- or IEEE half (gates_f16 = 1: 2^-11 relative
+ * rounding, half the bytes the forward storer writes and the backward loader reads beside the per-step hand-off) where the default
+ * kernel pair serves the shape: ask asr_gru_gates_f16_ok (the calls return -3 otherwise); both calls must agree. */
+int asr_gru_gates_f16_ok(int T, int B, int H, int ndir, int mode);
 int asr_gru_fwd(void* stream, void* gi, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
-                float* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len);
-int asr_gru_bwd(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const void* whhT_bf16,
+                void* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len, int gates_f16);
+int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates, const float* hseq, const void* whhT_bf16,
                 void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh, int T, int B, int H,
-                int ndir, void* sync_ws, int mode, const int* x_len, void* dy_ws);
+                int ndir, void* sync_ws, int mode, const int* x_len, void* dy_ws, int gates_f16);
 
 /* ---------------------------------------------------------------------------------------- SRU scan
  * Replaces the CUDA kernels `forward` / `backward` of asr/nn/sru.py:17-73,75-191 (SRUFunction.forward_gpu :327-367,

@@ -72,14 +72,15 @@ class GRUMatched(torch.autograd.Function):
     """(Bi)GRU layer with the device's rounding points (csrc/gru.hip): cuDNN gate convention, directions summed.
 
     x (T, B, I) bf16-valued; w_ih (ndir, 3H, I), w_hh (ndir, 3H, H), b_ih, b_hh (ndir, 3H) float32 masters.
-    gi_bf16: the input projections are written in bf16 (asr_gru_fwd_accepts_bf16_gi).  ps_units: 32 when the partial-sum backward
+    gi_bf16: the input projections are written in bf16 (asr_gru_fwd_accepts_bf16_gi); gates_f16: the gates saved for the backward
+    pass are kept in IEEE half (asr_gru_gates_f16_ok).  ps_units: 32 when the partial-sum backward
     kernel serves the shape (H % 128 == 0: every 32-unit producer publishes its share of dgh . W_hh rounded to bf16), else 0.
     x_len (B) or None: rows are live for t < x_len[b]; beyond, the state is frozen (the reverse direction therefore starts from a
     zero state at x_len[b] - 1), the output is zero and no gradient flows -- NStepBiGRU's per-sequence lengths (asr/nn/nn.py:3).
     """
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, gi_bf16, ps_units, x_len):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, gi_bf16, ps_units, x_len, gates_f16=False):
         T, B, I = x.shape
         ndir, H = w_hh.shape[0], w_hh.shape[2]
         wih, whh = rnd(w_ih), rnd(w_hh)
@@ -106,6 +107,8 @@ class GRUMatched(torch.autograd.Function):
                 R[t], Z[t], N[t], Q[t], HP[t] = r, z, n, gh[:, 2 * H:], h
                 h = hn
                 hsum[t] += hn
+            if gates_f16:       # the default kernel pair keeps the saved gates in IEEE half (asr_gru_gates_f16_ok); the state stays float32
+                R, Z, N, Q = (a.to(torch.float16).to(torch.float32) for a in (R, Z, N, Q))
             saved.append((R, Z, N, Q, HP))
         y = rnd(hsum)
         if live is not None:
@@ -158,7 +161,7 @@ class GRUMatched(torch.autograd.Function):
             gb_ih[d] = dgi.sum(dim=(0, 1))
             gb_hh[d] = dgh.sum(dim=(0, 1))
         gx = rnd(gx_acc).reshape(T, B, I)
-        return gx, gw_ih, gw_hh, gb_ih, gb_hh, None, None, None
+        return gx, gw_ih, gw_hh, gb_ih, gb_hh, None, None, None, None
 
 
 def gru_f32(x, w_ih, w_hh, b_ih, b_hh, x_len=None):
@@ -185,12 +188,12 @@ def gru_f32(x, w_ih, w_hh, b_ih, b_hh, x_len=None):
     return y if ndir == 1 else y[..., :H] + y[..., H:]
 
 
-def gru(x, w_ih, w_hh, b_ih, b_hh, x_len=None, matched=False, gi_bf16=True, ps_units=None):
+def gru(x, w_ih, w_hh, b_ih, b_hh, x_len=None, matched=False, gi_bf16=True, ps_units=None, gates_f16=False):
     if not matched:
         return gru_f32(x, w_ih, w_hh, b_ih, b_hh, x_len)
     if ps_units is None:
         ps_units = 32 if w_hh.shape[2] % 128 == 0 else 0
-    return GRUMatched.apply(x, w_ih, w_hh, b_ih, b_hh, bool(gi_bf16), int(ps_units), x_len)
+    return GRUMatched.apply(x, w_ih, w_hh, b_ih, b_hh, bool(gi_bf16), int(ps_units), x_len, bool(gates_f16))
 
 
 # ------------------------------------------------------------------------------------------------------------------ helpers

@@ -17,7 +17,7 @@ from . import nn as onn
 
 class DS2Oracle(torch.nn.Module):
     def __init__(self, state, num_conv_layers, num_rnn_layers, bidirectional=True, matched=False, gi_bf16=True, ps_units=None,
-                 fused_logit_bias=False):
+                 fused_logit_bias=False, gates_f16=False):
         """state: dict name -> float32 CPU tensor with the names of asr.model.ds2.Model.state_dict().
         matched: restate the step with bf16 roundings where the HIP path rounds (oracle/bf16.py) -- gi_bf16 / ps_units say which
         recurrence kernels serve the shape (asr_gru_fwd_accepts_bf16_gi; partial-sum backward at H % 128 == 0), fused_logit_bias
@@ -25,6 +25,7 @@ class DS2Oracle(torch.nn.Module):
         super().__init__()
         self.nconv, self.nrnn, self.ndir = num_conv_layers, num_rnn_layers, 2 if bidirectional else 1
         self.matched, self.gi_bf16, self.ps_units, self.fused_logit_bias = bool(matched), bool(gi_bf16), ps_units, bool(fused_logit_bias)
+        self.gates_f16 = bool(gates_f16)
         self.p = torch.nn.ParameterDict({k.replace(".", "__"): torch.nn.Parameter(v.clone().float()) for k, v in state.items()})
 
     def g(self, name):
@@ -46,7 +47,7 @@ class DS2Oracle(torch.nn.Module):
         for i in range(self.nrnn):
             pre = "rnn_blocks._sequential_%d." % (2 * i)
             w_ih, w_hh, b_ih, b_hh = (self.g(pre + n) for n in ("w_ih", "w_hh", "b_ih", "b_hh"))
-            h = Q.gru(h, w_ih, w_hh, b_ih, b_hh, x_len, on, self.gi_bf16, self.ps_units)
+            h = Q.gru(h, w_ih, w_hh, b_ih, b_hh, x_len, on, self.gi_bf16, self.ps_units, self.gates_f16)
         for j, idx in enumerate((0, 3)):
             W, b = self.g("dense_blocks._sequential_%d.W" % idx), self.g("dense_blocks._sequential_%d.b" % idx)
             h = Q.linear(h, W[:, :, 0], b, on)

@@ -47,7 +47,7 @@ def _layer_and_reference(device, T, B, I, H, ndir, seed, x_len, ps_units=None):
         p = {n: Q.rnd(v).clone().requires_grad_(True) if (n.startswith("w") and not matched) else v.clone().requires_grad_(True)
              for n, v in P.items()}
         xr = x.clone().requires_grad_(True)
-        yr = Q.gru(xr, p["w_ih"], p["w_hh"], p["b_ih"], p["b_hh"], x_len, matched, gi_bf16, ps_units)
+        yr = Q.gru(xr, p["w_ih"], p["w_hh"], p["b_ih"], p["b_hh"], x_len, matched, gi_bf16, ps_units, _ops.gru_gates_f16(T, B, H, ndir))
         yr.backward(gy)
         refs.append(dict(y=yr.detach(), dx=xr.grad, w_ih=p["w_ih"].grad, w_hh=p["w_hh"].grad, b_ih=p["b_ih"].grad, b_hh=p["b_hh"].grad))
     return got, refs[0], refs[1]
@@ -155,7 +155,8 @@ def test_model_with_lengths_matches_the_oracle(device, B, T, H):
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2) == BF16
     for matched, tol in ((False, 0.2), (True, 5e-3)):
-        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=True)
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=True,
+                               gates_f16=_ops.gru_gates_f16(T, B, H, 2))
         loss_ref = omodel.ctc_mean_loss(ref(x, x_len), labels, x_len, l_len)
         loss_ref.backward()
         assert abs(loss.item() - loss_ref.item()) <= (2e-2 if not matched else 1e-3) * abs(loss_ref.item()), (matched, loss.item(), loss_ref.item())

@@ -368,6 +368,17 @@ def test_gru_full_size_against_fp32_oracle(device):
     errs = _gru_case(device, 1000, 32, 384, 512, 2, gi_dtype=BF16, tol=dict(y=8e-3, dx=1e-2, dwih=1e-2, dbih=1e-2, dbhh=1e-2, dwhh=1e-2))
     _ops.gru_check_sync()
     print("full-size GRU, bf16 input projections, vs fp32 oracle:", {k: "%.2e" % v for k, v in errs.items()})
+    # the saved gates in IEEE half (a switch, off by default: no speed in it) against float32 -- same bars
+    _ops.GRU_GATES_F16[0] = True
+    try:
+        assert _ops.gru_gates_f16(1000, 32, 512, 2)
+        errs16 = _gru_case(device, 1000, 32, 384, 512, 2, gi_dtype=BF16, tol=dict(y=8e-3, dx=1e-2, dwih=1e-2, dbih=1e-2, dbhh=1e-2, dwhh=1e-2))
+        _ops.gru_check_sync()
+    finally:
+        _ops.GRU_GATES_F16[0] = False
+    print("full-size GRU, saved gates in IEEE half (switch on), vs fp32 oracle:", {k: "%.2e" % v for k, v in errs16.items()})
+    for k in errs:
+        assert errs16[k] < 1.25 * errs[k] + 2e-4, (k, errs16[k], errs[k])       # half gates cost (next to) nothing in accuracy
 
 
 def _gru_case(device, T, B, I, H, ndir, tol=None, gi_dtype=F32):

@@ -63,7 +63,8 @@ def test_forward_backward_matches_oracle(device, B, T, bidir, V, H):
     gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2 if bidir else 1) == torch.bfloat16
     report = {}
     for matched in (True, False):
-        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=fused)
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=fused,
+                               gates_f16=_ops.gru_gates_f16(T, B, H, 2 if bidir else 1))
         logits_ref = ref(x)
         loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
         loss_ref.backward()
@@ -632,7 +633,8 @@ def test_configs0_literal_shape(device, bidir):
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     gi_bf16 = _ops.gru_gi_dtype(T, B, 512, 2 if bidir else 1) == torch.bfloat16
     for matched in (True, False):
-        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, 1, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=False)
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, 1, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=False,
+                               gates_f16=_ops.gru_gates_f16(T, B, 512, 2 if bidir else 1))
         loss_ref = omodel.ctc_mean_loss(ref(x), labels, x_len, l_len)
         loss_ref.backward()
         errs = {name: _rel(p.grad.cpu(), ref.g(name).grad) for name, p in model.named_parameters()}

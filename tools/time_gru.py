@@ -38,7 +38,7 @@ def main(T=1000, B=32, H=512, ndir=2, iters=3):
         else: res['fwd_maxdiff'] = max(float((o.float() - r).abs().max()) for o, r in zip(fo, fref))
         if ref is None: ref = [o.float().clone() for o in out[:2]]
         else: res['maxdiff_vs_step'] = max(float((o.float() - r).abs().max()) for o, r in zip(out[:2], ref))
-        if mode == 8:       # the default form with the input projections in bf16
+        if mode == 8 and _ops.gru_gi_dtype(T, B, H, ndir) == torch.bfloat16:       # the default form with the input projections in bf16
             gi16 = gi.to(torch.bfloat16)
             fn = lambda: _ops.gru_fwd(gi16, whh16, bhh, T, B, H, ndir)
             fn(); torch.cuda.synchronize()
