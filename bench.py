@@ -248,6 +248,24 @@ def cpu_baseline(cfg, T, V, dev=None, seconds_budget=25.0):
     torch.set_num_threads(cores)
     out["one_thread"] = {"value": 1.0 / one_thread, "unit": "utterances/s", "cores": 1,
                          "sample": "1 train step of B=1 utterance after 1 warm-up; %.2f s/step" % one_thread}
+    # SURVEY 8d's C1 shape (BASELINE configs[0]: 2 x conv + ONE GRU layer, B=4, T=200, V=119) on all threads
+    from asr.model import ds2 as _ds2
+    c1 = _ds2.configure()
+    c1.vocab_size, c1.num_rnn_layers, c1.bidirectional = 119, 1, False
+    m1 = _ds2.Model(c1)
+    m1.rnn_blocks.layers[0]._initialize_params(c1.ndim_conv * 6)
+    m1.dense_blocks.layers[0]._initialize_params(c1.ndim_rnn)
+    m1.dense_blocks.layers[7].norm._initialize_params(119)
+    ref1 = omodel.DS2Oracle({k: v.detach().clone() for k, v in m1.state_dict().items()}, 2, 1, False)
+    xc, lc, xlc, llc = omodel.synthetic_batch(4, 200, 119, Lmin=10, Lmax=30, seed=0)
+    m1s, v1s = [torch.zeros_like(q) for q in ref1.parameters()], [torch.zeros_like(q) for q in ref1.parameters()]
+    omodel.train_step(ref1, m1s, v1s, 1, xc, lc, xlc, llc)
+    t0 = time.time()
+    for k in range(3):
+        omodel.train_step(ref1, m1s, v1s, 2 + k, xc, lc, xlc, llc)
+    c1dt = (time.time() - t0) / 3
+    out["c1"] = {"value": 4.0 / c1dt, "unit": "utterances/s", "cores": cores,
+                 "sample": "3 train steps of BASELINE configs[0] (2 x conv + 1 GRU-512, B=4, T=200, V=119) after 1 warm-up; %.3f s/step" % c1dt}
     try:
         with open("/proc/cpuinfo") as f:
             names = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
@@ -406,6 +424,38 @@ def time_gram_ctc(dev, T=1000, B=32, V=3000, L=120, iters=10):
     res["workload"] = "BASELINE configs[3]: Gram-CTC loss + gradient, T=%d, B=%d, V=%d, L<=%d (N<=%d nodes, 7 diagonals), 30%% bigrams absent" \
                       % (T, B, V, L, 3 * L + 1)
     return res
+
+
+def time_sru(dev, T=1000, B=32, D=512, iters=20):
+    """the reference's only native kernel (asr/nn/sru.py:7-193) as an operator: forward / backward scans at T=1000, B=32, D=512 against
+    the algorithmic bytes T B D (2 + 12 + 4 + 2) / T B D (2 + 12 + 4 + 2 + 6 + 2) and the ~6.3 TB/s a streaming kernel reaches"""
+    from asr import _ops
+    x = torch.randn(T, B, D, device=dev).to(torch.bfloat16)
+    U = torch.randn(T * B, 3 * D, device=dev)
+    bias = torch.randn(2 * D, device=dev) * 0.3
+    c0 = torch.randn(B, D, device=dev)
+    gH = torch.randn(T, B, D, device=dev).to(torch.bfloat16)
+    gcT = torch.randn(B, D, device=dev)
+    gb = torch.zeros(2 * D, device=dev)
+    H, C, cT = _ops.sru_fwd(x, U, bias, c0, None, True)
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    f = timed(lambda: _ops.sru_fwd(x, U, bias, c0, None, True))
+    b = timed(lambda: _ops.sru_bwd(x, U, bias, C, c0, None, gH, gcT, gb, True))
+    fb, bb = T * B * D * 20.0, T * B * D * 28.0
+    return {"workload": "SRU scans (tanh), T=%d, B=%d, D=%d: asr_sru_fwd / asr_sru_bwd, time-chunked" % (T, B, D),
+            "fwd_ms": f, "bwd_ms": b, "fwd_GBps": fb / f / 1e6, "bwd_GBps": bb / b / 1e6, "achievable_GBps": 6300.0,
+            "fwd_frac": fb / f / 1e6 / 6300.0, "bwd_frac": bb / b / 1e6 / 6300.0}
 
 
 def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
@@ -807,6 +857,7 @@ def main():
                                            "utterance's last frame)" % (int(0.6 * T), T, float(xlr.float().mean().item())),
                                "ms_per_step": dtr / 5 * 1e3, "utterances_per_s": B * 5 / dtr, "final_loss": float(lossr.item())}
         extra["gram_ctc"] = time_gram_ctc(dev, T, B, V, 120)
+        extra["sru"] = time_sru(dev, T, B, 512)
         del model, opt
         torch.cuda.empty_cache()
         extra["cnn_4conv"] = time_cnn_config(args, 4, dev)

@@ -108,6 +108,15 @@ SIGNATURES = {
     "asr_gather_abort": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "asr_step_control": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2 + [c_int]),
     "asr_adam_ctl": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 4 + [c_void_p]),
+    "asr_crelu_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int]),
+    "asr_crelu_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int]),
+    "asr_softmax_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int]),
+    "asr_softmax_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int, c_int]),
+    "asr_avgpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
+    "asr_avgpool_h_bwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int]),
+    "asr_unpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int, c_int]),
+    "asr_unpool_h_bwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int, c_int]),
+    "asr_gaussian_noise": (c_int, [c_void_p] * 3 + [c_longlong, c_float, ctypes.c_uint]),
     "asr_sgd_ctl": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 3 + [c_void_p]),
 }
 

@@ -746,3 +746,74 @@ def pack_input_pad(x, strides_tbhc, T, B, H, C, Cpad):
     rc = _lib.lib().asr_pack_input_pad(stream(), x.data_ptr(), _is_bf16(x), *strides_tbhc, T, B, H, C, Cpad, ptr(out))
     check(rc, "asr_pack_input_pad")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the rest of asr.nn's function layers
+def crelu_fwd(x):
+    """x (..., C) bf16 contiguous -> (..., 2C): [relu(x) | relu(-x)] along the channels"""
+    assert x.dtype == BF16 and x.is_contiguous()
+    C = x.shape[-1]
+    y = torch.empty(x.shape[:-1] + (2 * C,), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_crelu_fwd(stream(), ptr(x), ptr(y), x.numel() // C, C), "asr_crelu_fwd")
+    return y
+
+
+def crelu_bwd(x, dy):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_lib.lib().asr_crelu_bwd(stream(), ptr(x), ptr(dy.contiguous()), ptr(dx), x.numel() // C, C), "asr_crelu_bwd")
+    return dx
+
+
+def softmax_fwd(x, log_form):
+    assert x.dtype == BF16 and x.is_contiguous()
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.lib().asr_softmax_fwd(stream(), ptr(x), ptr(y), x.numel() // C, C, int(bool(log_form))), "asr_softmax_fwd")
+    return y
+
+
+def softmax_bwd(y, dy, log_form):
+    C = y.shape[-1]
+    dx = torch.empty_like(y)
+    check(_lib.lib().asr_softmax_bwd(stream(), ptr(y), ptr(dy.contiguous()), ptr(dx), y.numel() // C, C, int(bool(log_form))), "asr_softmax_bwd")
+    return dx
+
+
+def avgpool_h_fwd(x, k):
+    """x (T, B, H, C) bf16 -> (T, B, (H - k) // k + 1, C): mean over whole windows of k rows"""
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    T, B, H, C = x.shape
+    y = torch.empty((T, B, (H - k) // k + 1, C), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_avgpool_h_fwd(stream(), ptr(x), ptr(y), T * B, H, C, k), "asr_avgpool_h_fwd")
+    return y
+
+
+def avgpool_h_bwd(dy, H, k):
+    T, B, _, C = dy.shape
+    dx = torch.empty((T, B, H, C), dtype=BF16, device=dy.device)
+    check(_lib.lib().asr_avgpool_h_bwd(stream(), ptr(dy.contiguous()), ptr(dx), T * B, H, C, k), "asr_avgpool_h_bwd")
+    return dx
+
+
+def unpool_h_fwd(x, k, Hout):
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    T, B, H, C = x.shape
+    y = torch.empty((T, B, Hout, C), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_unpool_h_fwd(stream(), ptr(x), ptr(y), T * B, H, Hout, C, k), "asr_unpool_h_fwd")
+    return y
+
+
+def unpool_h_bwd(dy, H, k):
+    T, B, Hout, C = dy.shape
+    dx = torch.empty((T, B, H, C), dtype=BF16, device=dy.device)
+    check(_lib.lib().asr_unpool_h_bwd(stream(), ptr(dy.contiguous()), ptr(dx), T * B, H, Hout, C, k), "asr_unpool_h_bwd")
+    return dx
+
+
+def gaussian_noise(x, std, seed):
+    assert x.dtype == BF16
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().asr_gaussian_noise(stream(), ptr(x), ptr(y), x.numel(), float(std), int(seed) & 0xffffffff), "asr_gaussian_noise")
+    return y

@@ -690,6 +690,152 @@ def add(a, b):
     return back(_Add.apply(pa, pb))
 
 
+# ---------------------------------------------------------------------------------------------- the rest of asr.nn's function layers
+def _channel_rows(x, axis):
+    """physical tensor whose LAST axis is the logical axis 1 (the channels): the only axis these functions are offered on"""
+    if axis not in (1, 1 - x.dim()):
+        raise NotImplementedError("on the HIP path this function works along axis 1 (the channels), as asr.nn uses it")
+    return _phys_any(x)
+
+
+class _CReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p):
+        ctx.save_for_backward(p)
+        return _ops.crelu_fwd(p)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (p,) = ctx.saved_tensors
+        return _ops.crelu_bwd(p, gy.contiguous())
+
+
+def crelu(x, axis=1):
+    """chainer.functions.crelu (asr/nn/nn.py:18-23): concat(relu(x), relu(-x)) along axis 1"""
+    p, back = _channel_rows(x, axis)
+    return back(_CReLU.apply(p))
+
+
+class _Softmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, log_form):
+        y = _ops.softmax_fwd(p, log_form)
+        ctx.save_for_backward(y)
+        ctx.log_form = log_form
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return _ops.softmax_bwd(y, gy.contiguous(), ctx.log_form), None
+
+
+def softmax(x, axis=1):
+    """chainer.functions.softmax (asr/nn/nn.py:58-63)"""
+    p, back = _channel_rows(x, axis)
+    return back(_Softmax.apply(p, False))
+
+
+def log_softmax(x, axis=1):
+    """chainer.functions.log_softmax (asr/nn/nn.py:42-43)"""
+    p, back = _channel_rows(x, axis)
+    return back(_Softmax.apply(p, True))
+
+
+def _height_pooling_args(ksize, stride, pad, what):
+    kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+    sh, sw = (kh, kw) if stride is None else ((stride, stride) if isinstance(stride, int) else stride)
+    if kw != 1 or sw != 1 or sh != kh or pad not in (0, (0, 0)):
+        raise NotImplementedError("%s on the HIP path: ksize (k, 1), stride (k, 1), pad 0 (pooling over the mel axis, as the recipes pool)" % what)
+    return int(kh)
+
+
+class _AvgPoolH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, k):
+        ctx.meta = (p.shape[2], k)
+        return _ops.avgpool_h_fwd(p, k)
+
+    @staticmethod
+    def backward(ctx, gy):
+        H, k = ctx.meta
+        return _ops.avgpool_h_bwd(gy.contiguous(), H, k), None
+
+
+def average_pooling_2d(x, ksize, stride=None, pad=0):
+    """chainer.functions.average_pooling_2d (asr/nn/nn.py:77-84): whole windows only (Chainer's average pooling has no cover_all)"""
+    k = _height_pooling_args(ksize, stride, pad, "average_pooling_2d")
+    return logical4(_AvgPoolH.apply(phys4(x), k))
+
+
+def average_pooling_nd(x, ksize, stride=None, pad=0):
+    """chainer.functions.average_pooling_nd on a 4-d array = the 2-d one (asr/nn/nn.py:86-93)"""
+    if x.dim() != 4:
+        raise NotImplementedError("average_pooling_nd on the HIP path: 4-d (B, C, H, T) arrays")
+    return average_pooling_2d(x, ksize, stride, pad)
+
+
+def max_pooling_nd(x, ksize, stride=None, pad=0, cover_all=True):
+    """chainer.functions.max_pooling_nd on a 4-d array = the 2-d one (asr/nn/nn.py:105-113)"""
+    if x.dim() != 4:
+        raise NotImplementedError("max_pooling_nd on the HIP path: 4-d (B, C, H, T) arrays")
+    return max_pooling_2d(x, ksize, stride, pad, cover_all)
+
+
+class _UnpoolH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, k, Hout):
+        ctx.meta = (p.shape[2], k)
+        return _ops.unpool_h_fwd(p, k, Hout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        H, k = ctx.meta
+        return _ops.unpool_h_bwd(gy.contiguous(), H, k), None, None
+
+
+def unpooling_2d(x, ksize, stride=None, pad=0, outsize=None, cover_all=True):
+    """chainer.functions.unpooling_2d (asr/nn/nn.py:123-133) for ksize (k, 1), stride = ksize: every row repeated over its window;
+    output height k (H - 1) + 1 with cover_all, k H without (chainer.utils.conv.get_deconv_outsize), or `outsize`"""
+    k = _height_pooling_args(ksize, stride, pad, "unpooling_2d")
+    p = phys4(x)
+    H = p.shape[2]
+    Hout = (k * (H - 1) + 1 if cover_all else k * H) if outsize is None else int(outsize[0] if isinstance(outsize, (tuple, list)) else outsize)
+    if not (k * (H - 1) < Hout <= k * H):
+        raise ValueError("outsize %d does not fit %d input rows with ksize %d" % (Hout, H, k))
+    return logical4(_UnpoolH.apply(p, k, Hout))
+
+
+def upsampling_2d(x, indexes, ksize, stride=None, pad=0, outsize=None, cover_all=True):
+    raise NotImplementedError("upsampling_2d needs the argmax indexes of a Chainer MaxPooling2D function object "
+                              "(asr/nn/nn.py:135-146 passes `indexes` through); max pooling on the HIP path recomputes them in its backward pass")
+
+
+def spatial_pyramid_pooling_2d(x, pyramid_height, pooling_class):
+    raise NotImplementedError("spatial_pyramid_pooling_2d pools over (height, time) jointly and returns a fixed-size vector per utterance: "
+                              "outside the per-frame acoustic path (asr/nn/nn.py:115-121 is never instantiated by the reference)")
+
+
+class _GaussianNoise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, std, seed):
+        return _ops.gaussian_noise(p, std, seed)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, None, None
+
+
+def gaussian_noise(x, std):
+    """x + N(0, std^2) in train mode (asr/nn/nn.py:220-231: ln_var = log(std^2), mean 0 -- the reference's `mean` is unused)"""
+    if not train_mode[0]:
+        return x
+    p, back = _phys_any(x)
+    _dropout_counter[0] += 1
+    seed = (torch.initial_seed() * 1000003 + 7919 * _dropout_counter[0]) & 0xffffffff
+    return back(_GaussianNoise.apply(p, float(std), seed))
+
+
 # ---------------------------------------------------------------------------------------------- layer normalisation
 class _LayerNorm(torch.autograd.Function):
     @staticmethod

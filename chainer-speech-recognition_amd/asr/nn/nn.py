@@ -66,6 +66,14 @@ def _dropout(x, ratio):
     return x if ratio == 0 else functions.dropout(x, ratio)
 
 
+def _gaussian_noise(x, mean, std):
+    return functions.gaussian_noise(x, std)        # asr/nn/nn.py:220-231 never uses `mean` either
+
+
+def _max_pool_nd(x, ksize, stride, pad, cover_all):
+    return functions.max_pooling_nd(x, ksize, stride, pad)
+
+
 for _name, _fn, _sig, _doc in (
         # activations (asr/nn/nn.py:11-73)
         ("ClippedReLU", functions.clipped_relu, (("z", 20),), None),
@@ -74,8 +82,19 @@ for _name, _fn, _sig, _doc in (
         ("Maxout", functions.maxout, (("pool_size", 0.5),),
          "asr/nn/nn.py:45-50 (the reference's default pool_size=0.5 is unusable; every call site passes 2)"),
         ("Softplus", functions.softplus, (("beta", 1),), None),
+        ("CReLU", functions.crelu, (("axis", 1),), "asr/nn/nn.py:18-23"),
+        ("Softmax", functions.softmax, (("axis", 1),), "asr/nn/nn.py:58-63"),
         # pooling (:95-103)
         ("MaxPooling2D", _max_pool, (("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("cover_all", True)), "asr/nn/nn.py:95-103"),
+        ("MaxPoolingND", _max_pool_nd, (("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("cover_all", True)), "asr/nn/nn.py:105-113"),
+        ("AveragePooling2D", functions.average_pooling_2d, (("ksize", _REQUIRED), ("stride", None), ("pad", 0)), "asr/nn/nn.py:77-84"),
+        ("AveragePoolingND", functions.average_pooling_nd, (("ksize", _REQUIRED), ("stride", None), ("pad", 0)), "asr/nn/nn.py:86-93"),
+        ("SpatialPyramidPooling2D", functions.spatial_pyramid_pooling_2d, (("pyramid_height", _REQUIRED), ("pooling_class", _REQUIRED)),
+         "asr/nn/nn.py:115-121 (not on the HIP path: raises when called)"),
+        ("Unpooling2D", functions.unpooling_2d, (("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("outsize", None), ("cover_all", True)),
+         "asr/nn/nn.py:123-133"),
+        ("UpSampling2D", functions.upsampling_2d, (("indexes", _REQUIRED), ("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("outsize", None),
+                                                   ("cover_all", True)), "asr/nn/nn.py:135-146 (not on the HIP path: raises when called)"),
         # array manipulation (:148-207): views of the physical buffer
         ("BroadcastTo", functions.broadcast_to, (("shape", _REQUIRED),), None),
         ("ExpandDims", functions.expand_dims, (("axis", _REQUIRED),), None),
@@ -86,10 +105,12 @@ for _name, _fn, _sig, _doc in (
         ("Tile", functions.tile, (("reps", _REQUIRED),), None),
         ("Transpose", functions.transpose, (("axes", _REQUIRED),), None),
         # noise (:211-218): identity when the ratio is 0
-        ("Dropout", _dropout, (("ratio", 0.5),), "asr/nn/nn.py:211-218")):
+        ("Dropout", _dropout, (("ratio", 0.5),), "asr/nn/nn.py:211-218"),
+        ("GaussianNoise", _gaussian_noise, (("mean", _REQUIRED), ("std", _REQUIRED)), "asr/nn/nn.py:220-231")):
     globals()[_name] = _function_layer(_name, _fn, _sig, _doc)
 
 HardSigmoid = _plain(functions.hard_sigmoid)
+LogSoftmax = _plain(functions.log_softmax)
 ReLU = _plain(functions.relu)
 Sigmoid = _plain(functions.sigmoid)
 Tanh = _plain(functions.tanh)

@@ -374,6 +374,22 @@ int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, lon
 int asr_sgd_ctl(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,
                 float weight_decay, const float* ctl);
 
+/* ---------------------------------------------------------------------------------------- the rest of asr.nn's function layers
+ * asr/nn/nn.py:18-23 CReLU, :42-43 LogSoftmax, :58-63 Softmax (axis 1 = the channels = the contiguous axis of the physical layout),
+ * :77-93 AveragePooling2D / ND (ksize (k, 1), stride = ksize, pad 0; Chainer's average pooling has no cover_all: Hout = (Hin - k) / k
+ * + 1), :123-133 Unpooling2D (ksize (k, 1), stride = ksize; Hout = k (Hin - 1) + 1 with cover_all, k Hin without), :220-231
+ * GaussianNoise (x + N(0, std^2), counter-based).  No recipe of the reference uses them; rows = every axis but the channels;
+ * x, y, dy, dx bf16. */
+int asr_crelu_fwd(void* stream, const void* x, void* y, long long rows, int C);
+int asr_crelu_bwd(void* stream, const void* x, const void* dy, void* dx, long long rows, int C);
+int asr_softmax_fwd(void* stream, const void* x, void* y, long long rows, int C, int log_form);
+int asr_softmax_bwd(void* stream, const void* y, const void* dy, void* dx, long long rows, int C, int log_form);
+int asr_avgpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int C, int k);
+int asr_avgpool_h_bwd(void* stream, const void* dy, void* dx, long long R, int Hin, int C, int k);
+int asr_unpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int Hout, int C, int k);
+int asr_unpool_h_bwd(void* stream, const void* dy, void* dx, long long R, int Hin, int Hout, int C, int k);
+int asr_gaussian_noise(void* stream, const void* x, void* y, long long n, float stdv, unsigned int seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,3 +417,21 @@ def test_recipe_parameter_names_agree_with_the_oracles_bookkeeping(arch, nconv, 
     mine = sorted({n.rsplit(".", 1)[0] for n, _ in model.named_parameters()})
     theirs = sorted({name for _, name, _ in ocnn.program(arch, cfg) if name is not None})
     assert mine == theirs
+
+
+def test_every_function_layer_of_the_reference_has_a_mirror():
+    """VERDICT r2 (missing 6): the names asr/nn/nn.py defines (:9-231) all exist in asr.nn with the reference's argument names"""
+    import asr.nn as nn
+    for name in ("ClippedReLU", "CReLU", "ELU", "HardSigmoid", "LeakyReLU", "LogSoftmax", "Maxout", "ReLU", "Sigmoid", "Softmax", "Softplus", "Tanh",
+                 "AveragePooling2D", "AveragePoolingND", "MaxPooling2D", "MaxPoolingND", "SpatialPyramidPooling2D", "Unpooling2D", "UpSampling2D",
+                 "BroadcastTo", "ExpandDims", "Flatten", "Reshape", "RollAxis", "Squeeze", "SwapAxes", "Tile", "Transpose", "Dropout", "GaussianNoise",
+                 "Convolution2D", "LayerNormalization", "GLU", "Residual", "Stream", "Module", "Convolution1D", "SRU"):
+        assert hasattr(nn, name), name
+    assert nn.CReLU().axis == 1 and nn.Softmax(axis=1).axis == 1
+    p = nn.Unpooling2D((2, 1), outsize=(9, 1))
+    assert (p.ksize, p.stride, p.pad, p.outsize, p.cover_all) == ((2, 1), None, 0, (9, 1), True)
+    u = nn.UpSampling2D("idx", (2, 1))
+    assert u.indexes == "idx" and u.ksize == (2, 1)
+    g = nn.GaussianNoise(0, 0.5)
+    assert (g.mean, g.std) == (0, 0.5)
+    assert callable(nn.LogSoftmax())

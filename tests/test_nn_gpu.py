@@ -510,3 +510,76 @@ def test_sru_full_size_against_the_oracle(device, use_tanh):
     print("full-size SRU (tanh=%s) vs float64 oracle:" % use_tanh, {k: "%.2e" % v for k, v in errs.items()})
     for k, v in errs.items():
         assert v < 1e-2, (k, v)
+
+
+# ------------------------------------------------------------------------------------------------ the rest of asr.nn's function layers
+def test_crelu_softmax_pooling_layers(device):
+    """asr/nn/nn.py:18-23 CReLU, :42-43 LogSoftmax, :58-63 Softmax, :77-93 AveragePooling2D / ND, :105-113 MaxPoolingND, :123-133
+    Unpooling2D against their torch-CPU statements (Chainer functions in the reference: unpinned boundary), forward and backward"""
+    import asr.nn as nn
+    F = torch.nn.functional
+    x = _img(2, 6, 7, 5) * 2
+    gy_seed = 11
+
+    def both(layer, ref, out_channels=None):
+        xd = x.to(device).requires_grad_(True)
+        y = layer(xd)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        assert tuple(y.shape) == tuple(yr.shape), (y.shape, yr.shape)
+        gy = _bf(torch.randn(yr.shape, generator=torch.Generator().manual_seed(gy_seed)))
+        y.float().backward(gy.to(device))
+        yr.backward(gy)
+        return _rel(y.float().cpu(), yr.detach()), _rel(xd.grad.float().cpu(), xr.grad)
+
+    e = both(nn.CReLU(), lambda t: torch.cat([F.relu(t), F.relu(-t)], dim=1))
+    assert e[0] == 0.0 and e[1] < 1e-6, e
+    e = both(nn.Softmax(), lambda t: torch.softmax(t, dim=1))
+    assert e[0] < 4e-3 and e[1] < 1e-2, e
+    e = both(nn.LogSoftmax(), lambda t: torch.log_softmax(t, dim=1))
+    assert e[0] < 4e-3 and e[1] < 1e-2, e
+    for k in (2, 3, 7):
+        e = both(nn.AveragePooling2D((k, 1)), lambda t: F.avg_pool2d(t, (k, 1), stride=(k, 1)))
+        assert e[0] < 4e-3 and e[1] < 4e-3, (k, e)
+    e = both(nn.AveragePoolingND((2, 1)), lambda t: F.avg_pool2d(t, (2, 1), stride=(2, 1)))
+    assert e[0] < 4e-3 and e[1] < 4e-3, e
+    e = both(nn.MaxPoolingND((3, 1)), lambda t: F.max_pool2d(t, (3, 1), stride=(3, 1), ceil_mode=True))
+    assert e[0] == 0.0 and e[1] < 1e-6, e
+    for cover_all, Hout in ((True, 3 * 6 + 1), (False, 3 * 7)):
+        e = both(nn.Unpooling2D((3, 1), cover_all=cover_all), lambda t: torch.repeat_interleave(t, 3, dim=2)[:, :, :Hout])
+        assert e[0] == 0.0 and e[1] < 4e-3, (cover_all, e)
+    with pytest.raises(NotImplementedError):
+        nn.Softmax(axis=2)(x.to(device))
+    with pytest.raises(NotImplementedError):
+        nn.UpSampling2D(None, (2, 1))(x.to(device))
+    with pytest.raises(NotImplementedError):
+        nn.SpatialPyramidPooling2D(2, None)(x.to(device))
+    # 3-d (B, D, T) and 2-d inputs take the same kernels
+    x3 = _bf(torch.randn(3, 10, 8))
+    y3 = nn.Softmax()(x3.to(device))
+    assert _rel(y3.float().cpu(), torch.softmax(x3, dim=1)) < 4e-3
+
+
+def test_gaussian_noise_layer(device):
+    """asr/nn/nn.py:220-231: x + N(0, std^2) when training (the `mean` argument is unused there too), identity otherwise;
+    the gradient passes through unchanged"""
+    import asr.nn as nn
+    from asr import functions as F
+    torch.manual_seed(0)
+    x = torch.zeros(4, 64, 8, 128)
+    layer = nn.GaussianNoise(0.0, 0.25)
+    xd = x.to(device).requires_grad_(True)
+    y = layer(xd)
+    y.float().sum().backward()
+    d = y.float().cpu()
+    assert abs(float(d.mean())) < 2e-3 and abs(float(d.std()) - 0.25) < 3e-3
+    kurt = float(((d / d.std()) ** 4).mean())
+    assert abs(kurt - 3.0) < 0.05, kurt                      # Gaussian, not uniform
+    assert torch.equal(xd.grad.cpu(), torch.ones_like(x))
+    y2 = layer(xd)
+    assert not torch.equal(y2, y)                            # a fresh draw per call
+    F.train_mode[0] = False
+    try:
+        assert layer(xd) is xd
+    finally:
+        F.train_mode[0] = True

@@ -7,12 +7,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 2 --no-census --no-cpu-baseline"
+ARGS="--steps 4 --warmup 2 --no-census --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py $ARGS > $OUT/stats.log 2>&1
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o k -- python3 $R/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o k -- python3 $R/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline --no-extra > $OUT/fetch.log 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o k -- python3 $R/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline > $OUT/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o k -- python3 $R/bench.py --steps 2 --warmup 1 --no-census --no-cpu-baseline --no-extra > $OUT/write.log 2>&1
 echo "write pass done"
 cd $R
 python3 tools/prof_summary.py stats $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
