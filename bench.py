@@ -786,13 +786,14 @@ def main():
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic_v9.json")
-        if os.path.exists(pmc_path):
+        pmc_path = next((os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic_v9.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        if pmc_path is not None:
             ks = json.load(open(pmc_path))["kernels"]
             sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k or "gru::bwd_ps_kernel" in k]
             if sel:
                 traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
-                traffic_src = "profiles/r02_pmc_traffic_v9.json"
+                traffic_src = "profiles/" + os.path.basename(pmc_path)
         out["roofline"] = {"bound": "latency", "priced_against": "hbm",
                            "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
                            "hop_price_us": "0.8-1.0 (MI355X_MICROARCH.md: one producer -> consumer hop through the L2, <= 4 KB, idle chip)",
