@@ -373,11 +373,20 @@ def _hook(name):
 
 
 GRU_GI_BF16 = [True]        # write the input projections in bf16 where the recurrence kernel takes them (tests may switch it off)
-# saved gates in IEEE half where the default kernel pair serves (asr_hip.h).  OFF by default: measured at T=1000, B=32, H=512 it saves
-# 40 % of the forward storer's bytes and a third of the backward loader's and buys nothing (forward 1.233 -> 1.233 us per step,
-# backward 1.34 -> 1.37): the CU's memory queue is bound by the NUMBER of requests beside the hand-off, and 32-B pieces of half
-# gates make as many as 64-B pieces of float32 ones
-GRU_GATES_F16 = [os.environ.get("ASR_GRU_GATES_F16", "0") != "0"]
+# saved gates in IEEE half, blocked by workgroup, where the default kernel pair serves (asr_hip.h): a row's r | z | n | q of 16 units
+# are ONE 128-B line instead of four 64-B pieces of four lines.  Measured at T=1000, B=32, H=512: forward 1.256 -> 1.210 us per step,
+# backward 1.347 -> 1.329 (half gates in the plain [4][H] layout had bought nothing: the CU's memory queue beside the hand-off is
+# bound by the NUMBER of requests).  ASR_GRU_GATES_F16=0 keeps float32 gates.
+GRU_GATES_F16 = [os.environ.get("ASR_GRU_GATES_F16", "1") != "0"]
+
+
+def gru_gates_standard(gates, H):
+    """the saved gates as float32 (T*B, ndir, 4, H) whatever form gru_fwd kept them in (tests, inspection): the half form is blocked
+    by workgroup, (T*B, ndir, H/16, 4, 16) -- asr_hip.h"""
+    if gates.dtype != torch.float16:
+        return gates
+    rows, ndir = gates.shape[0], gates.shape[1]
+    return gates.reshape(rows, ndir, H // 16, 4, 16).permute(0, 1, 3, 2, 4).reshape(rows, ndir, 4, H).float()
 
 
 def gru_gates_f16(T, B, H, ndir):
@@ -446,6 +455,12 @@ def gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, db_ih=None, db_hh=None, x_le
     dev = dy.device
     x_len = _len_i32(x_len, B, dev)
     dy_ws = torch.empty((T * B, H), dtype=BF16, device=dev) if x_len is not None else None
+    if gates.dtype == torch.float16 and (db_ih is None or db_hh is None):
+        # half gates belong to the partial-sum backward kernel, which sums the bias gradients in registers: give it somewhere to put them
+        scratch = torch.empty((2, ndir * 3 * H), dtype=F32, device=dev)
+        fill_(scratch, 0.0)
+        db_ih = scratch[0] if db_ih is None else db_ih
+        db_hh = scratch[1] if db_hh is None else db_hh
     dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
     sync = _sync_buffer(dev, _lib.lib().asr_gru_sync_bytes(B, H, ndir))

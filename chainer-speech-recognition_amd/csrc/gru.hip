@@ -1344,8 +1344,8 @@ constexpr int PS_RING = 4;
 __host__ __device__ inline size_t ps_exchange_bytes(int nrec_pad, int H) { return (size_t)PS_RING * nrec_pad * (H / 32) * H * 8; }
 constexpr size_t kPsOffset = 4096 + kShardBytes;      // behind the control words and the sharded counters
 
-// G16: the saved gates arrive as IEEE half (fwd_persistent_io_kernel<.., G16>): ONE LDS-DMA instruction brings r | z | n | q of a
-// step (4 gates x 4 rows x 64 B) instead of two, the slot image is [4 gates][4 rows][32 units] half.
+// G16: the saved gates arrive as IEEE half in the blocked layout (fwd_persistent_io_kernel<.., G16>): ONE LDS-DMA instruction brings
+// r | z | n | q of a step (4 rows x 256 contiguous bytes) instead of two (8 x 128-B runs each).
 template <int NT, bool LOCAL, bool G16 = false>
 __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
                                                         const float* __restrict__ hseq, const uint16_t* __restrict__ whhT,
@@ -1385,10 +1385,11 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     const int lrow = (lane & 31) >> 3, lyrow = (lane - 32) >> 2;
     const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4 +
                        (size_t)(lane >> 5) * H;
-    // G16: lane = (gate lane / 16, row (lane % 16) / 4, units 8 (lane % 4) ..)
-    const int lrow16 = (lane & 15) >> 2;
-    const uint16_t* lgp16 = reinterpret_cast<const uint16_t*>(gates) + (((size_t)tfirst * B + b0 + (lrow16 < Bl ? lrow16 : 0)) * ndir + d) * 4 * H +
-                            j0 + (lane & 3) * 8 + (size_t)(lane >> 4) * H;
+    // G16 (blocked layout [T*B][ndir][H / 16][4 gates][16 units] half): the 32 units of this workgroup are two adjacent blocks = 256
+    // contiguous bytes per row: lane = (row lane / 16, 16-B piece lane % 16)
+    const int lrow16 = lane >> 4;
+    const uint16_t* lgp16 = reinterpret_cast<const uint16_t*>(gates) + ((((size_t)tfirst * B + b0 + (lrow16 < Bl ? lrow16 : 0)) * ndir + d) * (H >> 4) +
+                                                                        (j0 >> 4)) * 64 + (lane & 15) * 8;
     const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
                        (size_t)d * H + j0 + (lane & 7) * 4;
     const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lane >= 32 && lane < 48 && lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
@@ -1495,8 +1496,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
             const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
             if (G16) {
-                const _Float16* oh = reinterpret_cast<const _Float16*>(sl) + b * 32 + u0;
-                r = (float)oh[0]; z = (float)oh[128]; n = (float)oh[256]; qq = (float)oh[384];
+                // slot image [4 rows][2 blocks][4 gates][16 units] half
+                const _Float16* oh = reinterpret_cast<const _Float16*>(sl) + b * 128 + (u0 >> 4) * 64 + (u0 & 15);
+                r = (float)oh[0]; z = (float)oh[16]; n = (float)oh[32]; qq = (float)oh[48];
             } else {
                 r = of[0]; z = of[128]; n = of[256]; qq = of[384];
             }
@@ -1754,16 +1756,18 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                     if (row < Bl)
                         *reinterpret_cast<f32x4_asm*>(hseq + ((size_t)tq * B + b0 + row) * hs + (size_t)d * H + j0 + c4) = lds_read16_raw(src + pp * 4);
                 } else if (pp < 96) {
-                    const int q = pp - 32, arr = 1 + (q >> 4), row = (q & 15) >> 1, c8 = (q & 1) * 8;
+                    // blocked layout [T*B][ndir][H / 16][4 gates][16 units]: this workgroup's r | z | n | q of a row are ONE 128-B line
+                    // (in the [4][H] layout they were four 32-B pieces of four lines, each completed by three other workgroups)
+                    const int q = pp - 32, row = q >> 3, gate = (q & 7) >> 1, c8 = (q & 1) * 8;
                     if (row < Bl) {
-                        const float* ls = src + arr * 128 + row * 16 + c8;
+                        const float* ls = src + (1 + gate) * 128 + row * 16 + c8;
                         const f32x4_asm v0 = lds_read16_raw(ls), v1 = lds_read16_raw(ls + 4);
                         union { half2_t h[4]; uint4 u; } pk;
                         pk.h[0] = __builtin_convertvector((float2_t){v0[0], v0[1]}, half2_t);
                         pk.h[1] = __builtin_convertvector((float2_t){v0[2], v0[3]}, half2_t);
                         pk.h[2] = __builtin_convertvector((float2_t){v1[0], v1[1]}, half2_t);
                         pk.h[3] = __builtin_convertvector((float2_t){v1[2], v1[3]}, half2_t);
-                        *reinterpret_cast<uint4*>(gates16 + (((size_t)tq * B + b0 + row) * ndir + d) * 4 * H + (size_t)(arr - 1) * H + j0 + c8) = pk.u;
+                        *reinterpret_cast<uint4*>(gates16 + ((((size_t)tq * B + b0 + row) * ndir + d) * (H >> 4) + (j0 >> 4)) * 64 + gate * 16 + c8) = pk.u;
                     }
                 }
             }

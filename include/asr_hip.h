@@ -313,7 +313,8 @@ int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mode);
  * required with x_len) -- every recurrence kernel form serves ragged batches unchanged. */
 /* gates: (T*B, ndir, 4, H) = r | z | n | q saved for the backward pass, float32 -- or IEEE half (gates_f16 = 1: 2^-11 relative
  * rounding, half the bytes the forward storer writes and the backward loader reads beside the per-step hand-off) where the default
- * kernel pair serves the shape: ask asr_gru_gates_f16_ok (the calls return -3 otherwise); both calls must agree. */
+ * kernel pair serves the shape: ask asr_gru_gates_f16_ok (the calls return -3 otherwise); both calls must agree.  The half form is
+ * BLOCKED by workgroup: (T*B, ndir, H/16, 4, 16) -- a row's r | z | n | q of 16 units are one 128-B line -- and private to the pair. */
 int asr_gru_gates_f16_ok(int T, int B, int H, int ndir, int mode);
 int asr_gru_fwd(void* stream, void* gi, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
                 void* gates, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len, int gates_f16);
