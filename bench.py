@@ -778,10 +778,11 @@ def main():
         #   backward: dy bf16 in (H*2), gates in (8H*4), f32 state in (2H*4), dgi out (6H*2), dgh out (6H*2)
         # plus the W_hh slice once per launch (2*3H*H*2)
         gi_bytes = 2 if _ops.gru_gi_dtype(T, B, H, 2) == torch.bfloat16 else 4
-        fwd_bytes = T * B * (6 * H * gi_bytes + 2 * H * 2 * 2 + 2 * H * 4 + 8 * H * 4) + 2 * 3 * H * H * 2
+        gate_bytes = 2 if _ops.gru_gates_f16(T, B, H, 2) else 4          # saved gates: IEEE half where the default kernel pair serves
+        fwd_bytes = T * B * (6 * H * gi_bytes + 2 * H * 2 * 2 + 2 * H * 4 + 8 * H * gate_bytes) + 2 * 3 * H * H * 2
         # (backward, partial-sum exchange: dgh is written once for the weight-gradient GEMM and not read back; the partial sums
         # travel through the L2 only)
-        bwd_bytes = T * B * (H * 2 + 8 * H * 4 + 2 * H * 4 + 6 * H * 2 + 6 * H * 2) + 2 * 3 * H * H * 2
+        bwd_bytes = T * B * (H * 2 + 8 * H * gate_bytes + 2 * H * 4 + 6 * H * 2 + 6 * H * 2) + 2 * 3 * H * H * 2
         alg = 0.5 * (fwd_bytes + bwd_bytes)
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)

@@ -77,7 +77,7 @@ dev = torch.device("cuda:0")
 _ops.GRU_MODE[0] = 1
 torch.manual_seed(1234 + rank)                  # DIFFERENT seeds: only the broadcast can make the ranks agree
 V, B, T = 31, 8, 64
-if kind == "ds2":
+if kind in ("ds2", "ds2+halves"):
     from asr.model import ds2
     cfg = ds2.configure(); cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 128, 32, 2
     model = ds2.Model(cfg).to_gpu(0)
@@ -105,9 +105,17 @@ xd, ld, xl, ll = x[mine].to(dev), labels[mine].to(dev), x_len[mine].to(dev), l_l
 opt._ensure_flat()
 p_start = opt.flat_parameters().detach().cpu().clone()
 losses, norms = [], []
+pipe = None
+if kind == "ds2+halves" and world > 1:          # the two-half-batch schedule (asr/pipeline.py) under the Communicator: two passes, two streams
+    from asr.pipeline import HalfBatches
+    pipe = HalfBatches(dev)
+    opt.set_pipeline(pipe)
 for _ in range(3):
-    loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
-    opt.update(lossfun=lambda: loss)
+    if pipe is not None:
+        loss = pipe.step(opt, lambda sl: connectionist_temporal_classification(model(xd[sl]), ld[sl], 0, xl[sl], ll[sl]), xd.shape[0])
+    else:
+        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+        opt.update(lossfun=lambda: loss)
     losses.append(loss.item())
     norms.append(float(opt._flat["sq"].item()) ** 0.5 / world)       # norm of the MEAN gradient
 torch.cuda.synchronize()
@@ -135,7 +143,7 @@ def _spawn(root, tmp_path, world, kind, optname, port):
     return [torch.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("kind,optname", [("ds2", "adam"), ("ds2", "msgd"), ("cnn+weightnorm", "msgd")])
+@pytest.mark.parametrize("kind,optname", [("ds2", "adam"), ("ds2", "msgd"), ("cnn+weightnorm", "msgd"), ("ds2+halves", "msgd")])
 def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname):
     import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -162,6 +170,8 @@ def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname
     # every slice went exactly once per step
     ks = [k for k, _ in two[0]["launches"]]
     assert sorted(ks) == list(range(len(ks)))
+    if kind == "ds2+halves":        # with two passes on two streams nothing is reduced before the last pass has queued everything
+        assert all(n == two[0]["launches"][0][1] for _, n in two[0]["launches"]), two[0]["launches"]
 
 
 # ---------------------------------------------------------------------------------------------- a rank's recurrence gives up
