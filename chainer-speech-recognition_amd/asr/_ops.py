@@ -316,7 +316,7 @@ def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta,
     return dx
 
 
-GRU_MODE = [0]      # asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 local with flags, 5 narrow backward, 7 forged placement, 8 local with polled payload (= 0)
+GRU_MODE = [int(os.environ.get("ASR_GRU_MODE", "0"))]      # (ASR_GRU_MODE: rehearsals with several processes on one GPU use 1)  asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 local with flags, 5 narrow backward, 7 forged placement, 8 local with polled payload (= 0)
 
 
 _SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky
@@ -497,7 +497,7 @@ def abort_words():
     return [buf[1023:1024] for buf in _SYNC.values()]
 
 
-_ABORT = {}         # device index -> [number of control buffers covered, device table of word addresses, the ORed word]
+_ABORT = {}         # device index -> [addresses of the abort words covered, device table of them, the ORed word]
 
 
 def gather_abort(dev, poison=None):
@@ -505,10 +505,11 @@ def gather_abort(dev, poison=None):
     streams -- eval on the default stream, then two half-batch streams -- has three), queued on the current stream.  poison: an
     element of the local gradient buffer that gets a NaN when a word is raised (data parallelism: every rank then drops the step)."""
     words = [w for w in abort_words() if w.device == dev]
+    ptrs = tuple(w.data_ptr() for w in words)           # (a control buffer that grew was replaced: same count, another address)
     st = _ABORT.get(dev.index)
-    if st is None or st[0] != len(words):
-        table = torch.tensor([w.data_ptr() for w in words] or [0], dtype=torch.int64).to(dev)
-        st = _ABORT[dev.index] = [len(words), table, torch.zeros(1, dtype=torch.int32, device=dev)]
+    if st is None or st[0] != ptrs:
+        table = torch.tensor(list(ptrs) or [0], dtype=torch.int64).to(dev)
+        st = _ABORT[dev.index] = [ptrs, table, torch.zeros(1, dtype=torch.int32, device=dev) if st is None else st[2]]
     check(_lib.lib().asr_gather_abort(stream(), ptr(st[1]), len(words), ptr(st[2]), ptr(poison)), "asr_gather_abort")
     return st[2]
 
