@@ -48,6 +48,7 @@ SIGNATURES = {
     "asr_pack_input_pad": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 5 + [c_void_p]),
     "asr_conv_weight_pack_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
+    "asr_gemm_tn_acc_group": (c_int, [c_void_p, c_int] + [c_void_p] * 9),
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "asr_cast_bf16_many": (c_int, [c_void_p, c_void_p, c_int, c_longlong]),
     "asr_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong]),

@@ -49,6 +49,31 @@ def gemm_tn_acc(a, b, c):
     return c
 
 
+TN_GROUP = [os.environ.get("ASR_TN_GROUP", "1") != "0"]     # 0: one launch per product (comparison)
+
+
+def gemm_tn_acc_group(products):
+    """c += a^T @ b for up to four (a, b, c) triples in one launch (gemm_tn_acc's operand rules for each)."""
+    n = len(products)
+    assert 1 <= n <= 4
+    if not TN_GROUP[0]:
+        for a, b, c in products:
+            gemm_tn_acc(a, b, c)
+        return
+    for a, b, c in products:
+        assert a.dtype == BF16 and b.dtype == BF16 and c.dtype == F32
+        assert a.stride(1) == 1 and b.stride(1) == 1 and c.stride(1) == 1 and a.shape[0] == b.shape[0]
+        assert c.shape == (a.shape[1], b.shape[1])
+    import ctypes
+    ptrs = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in products])
+    ints = lambda f: (ctypes.c_int * n)(*[f(p) for p in products])
+    rc = _lib.lib().asr_gemm_tn_acc_group(stream(), n, ptrs(0), ints(lambda p: p[0].stride(0)), ptrs(1),
+                                          ints(lambda p: p[1].stride(0)), ptrs(2), ints(lambda p: p[2].stride(0)),
+                                          ints(lambda p: p[0].shape[1]), ints(lambda p: p[1].shape[1]),
+                                          ints(lambda p: p[0].shape[0]))
+    check(rc, "asr_gemm_tn_acc_group")
+
+
 def cast_bf16(src, transpose=False, out=None):
     """f32 (rows, cols) -> bf16 copy, optionally transposed; `out`: a contiguous bf16 tensor of the result's size."""
     assert src.dtype == F32 and src.is_contiguous()

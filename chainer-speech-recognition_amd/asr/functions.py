@@ -12,6 +12,7 @@ Conventions
   flat gradient buffer); the Functions return ``None`` for parameters.
 """
 import math
+import os
 
 import torch
 
@@ -26,7 +27,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 # (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
 # One side stream per launching stream: with two half batches on two streams (asr/pipeline.py) a shared side stream would
 # queue the early weight gradients of the second half behind the late ones of the first.
-_SIDE = {"streams": {}, "enabled": True}
+_SIDE = {"streams": {}, "enabled": True, "dirty": set(),
+         "join_before_recurrence": os.environ.get("ASR_SIDE_JOIN", "0") != "0"}
 
 
 def side_stream():
@@ -35,7 +37,7 @@ def side_stream():
     key = torch.cuda.current_stream().cuda_stream
     st = _SIDE["streams"].get(key)
     if st is None:
-        st = _SIDE["streams"][key] = torch.cuda.Stream()
+        st = _SIDE["streams"][key] = torch.cuda.Stream(priority=int(os.environ.get("ASR_SIDE_PRIORITY", "0")))
     return st
 
 
@@ -48,6 +50,25 @@ def join_side_stream():
     cur = torch.cuda.current_stream()
     for st in _SIDE["streams"].values():
         cur.wait_stream(st)
+    _SIDE["dirty"].clear()
+
+
+def _empty_chip_for_recurrence():
+    """ASR_SIDE_JOIN=1 (off by default): the launching stream waits for the side streams before it queues a recurrence.
+    A persistent recurrence wants every CU to itself (132 KB of LDS per workgroup).  Queued while weight-gradient workgroups of
+    the side stream are still resident it is dealt out over whatever CUs come free first: the workgroup -> XCD order the
+    XCD-local hand-off relies on can be lost, the in-launch vote then falls back to the placement-free form and that launch runs
+    1.6 .. 2.2 x longer (traced with tools/step_spread.py: 2.1 / 2.9 instead of 1.3 ms whenever a grouped product whose workgroups
+    live 290 us had been queued BEHIND the input-gradient product).  With the products queued beside that product (see
+    _GRU.backward) and 6 K splits the trace shows every recurrence at its normal length without the join, and the join itself
+    costs 0.3 ms per step (four cross-stream waits, and the recurrence's ramp no longer overlaps the products' tail): 15.05-15.15
+    against 14.73-14.80 ms.  Kept as a switch for set-ups where other kernels share the chip."""
+    if not _SIDE["join_before_recurrence"] or not _SIDE["dirty"]:
+        return
+    cur = torch.cuda.current_stream()
+    for st in _SIDE["dirty"]:
+        cur.wait_stream(st)
+    _SIDE["dirty"].clear()
 
 
 class _OnSide(object):
@@ -61,6 +82,7 @@ class _OnSide(object):
         if self.side is None:
             return self
         self.side.wait_stream(torch.cuda.current_stream())
+        _SIDE["dirty"].add(self.side)
         for t in self.tensors:
             if t is not None:
                 t.record_stream(self.side)
@@ -979,6 +1001,7 @@ class _GRU(torch.autograd.Function):
     def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir, x_len):
         wih16, wih16t, whh16, whh16t = copies
         gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), _ops.gru_gi_dtype(T, B, H, ndir))
+        _empty_chip_for_recurrence()
         y, hseq, hseq16, gates = _ops.gru_fwd(gi, whh16, b_hh.detach().reshape(-1), T, B, H, ndir, x_len)
         ctx.save_for_backward(x2, hseq, hseq16, gates, wih16t, whh16t)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
@@ -991,21 +1014,21 @@ class _GRU(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh = ctx.params
         T, B, H, ndir, need_dx, x_len = ctx.meta
         gy = gy.contiguous()
+        _empty_chip_for_recurrence()
         dgi, dgh = _ops.gru_bwd(gy, gates, hseq, whh16t, T, B, H, ndir, grad_buffer(b_ih).reshape(-1),
                                 grad_buffer(b_hh).reshape(-1), x_len)
-        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None        # the only product on the critical path
         gwih = grad_buffer(w_ih).reshape(ndir * 3 * H, -1)
         gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
         with _OnSide(dgi, dgh, x2, hseq16):
-            _ops.gemm_tn_acc(dgi, x2, gwih)
-            if T > 1:
+            products = [(dgi, x2, gwih)]
+            if T > 1:               # dW_hh[d] = sum_t dgh_t (x) h_{t-1}: the two directions differ by the sign of the shift only
                 for d in range(ndir):
                     a = dgh[:, d * 3 * H:(d + 1) * 3 * H]
                     h = hseq16[:, d * H:(d + 1) * H]
-                    if d == 0:
-                        _ops.gemm_tn_acc(a[B:], h[:-B], gwhh[d])
-                    else:
-                        _ops.gemm_tn_acc(a[:-B], h[B:], gwhh[d])
+                    products.append((a[B:], h[:-B], gwhh[d]) if d == 0 else (a[:-B], h[B:], gwhh[d]))
+            _ops.gemm_tn_acc_group(products)
+        # queued after the side stream's fork, so that the weight gradients start beside it and not behind it
+        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None        # the only product on the critical path
         grads_queued(w_ih, w_hh, b_ih, b_hh)
         return gx, None, None, None, None, None, None, None, None, None, None
 

@@ -871,25 +871,54 @@ __device__ __forceinline__ bf16x4 lds_tr16(const uint16_t* p) {
 // CONV: operand B is the virtual im2col matrix of the activation tensor (see ConvDesc; sgn = +1): row = reduction index
 // (t, b, h) over the output positions, column = (kh, kw, c) -- the weight gradient of a convolution without a column
 // matrix in memory (1.2 GB written and read back per step for the second conv layer otherwise).
+// Several products in one launch (the weight gradients a recurrence boundary releases together: dW_ih 3072 x 512 and the two
+// directions' dW_hh 1536 x 512, K = 32000).  Launched one by one each needs 8 .. 16 K splits to fill the chip and a workgroup's
+// fixed cost -- cold prologue, 16 K atomics -- is then a third of its life (time = 54 us per 2000 k rows + 47 us at 768
+// workgroups); together they are 192 tiles, which fill the chip at 4 .. 6 splits.  Alone 4 splits are fastest (0.286 ms against
+// 0.316 for the three launches, 0.349 at 6 splits); in the train step 6 are (14.73 against 14.80 ms: the next recurrence wants
+// every CU and waits for the last product workgroup, so short-lived workgroups hand the chip over sooner).  n == 0: the plain call.
+struct TnProb {
+    const uint16_t* A;
+    const uint16_t* B;
+    float* C;
+    int lda, ldb, ldc, M, N, K, tiles_n;
+    int tile_end;                        // tiles of this and all earlier products
+};
+struct TnGroup {
+    TnProb p[4];
+    int n;
+};
+
 template <bool CONV>
 __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restrict__ A, int lda,
                                                       const uint16_t* __restrict__ B, int ldb, float* __restrict__ C,
                                                       int ldc, int M, int N, int K, int tiles_n, int k_per_split,
-                                                      ConvDesc cd, long long copy_stride) {
+                                                      ConvDesc cd, long long copy_stride, TnGroup grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
     uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
-    // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); an XCD takes whole K splits -- every tile
-    // of split (slot / tiles) * 8 + xcd, one after the other -- so the rows of A and B of a split are fetched into ONE L2
-    // and shared by all the tiles there (tile-major ids put every column block on its own XCD: each L2 fetched all of A).
-    // Only a locality hint: any placement computes the same thing.
-    const int tiles = ((M + BM - 1) / BM) * tiles_n;
+    // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (round-robin dispatch); an XCD takes a contiguous run of the
+    // split-major (split, tile) pairs -- whole K splits where the split count is a multiple of 8 -- so the rows of A and B of a
+    // split are fetched into ONE L2 and shared by all the tiles there (tile-major ids put every column block on its own XCD: each
+    // L2 fetched all of A).  Only a locality hint: any placement computes the same thing.
+    const bool grouped = !CONV && grp.n > 0;
+    const int tiles = grouped ? grp.p[grp.n - 1].tile_end : ((M + BM - 1) / BM) * tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     C += (size_t)xcd * copy_stride;      // (one copy of the output per XCD when hundreds of K splits share one tile: asr_conv_tn_copies)
-    const int round = slot / tiles, bid = slot - round * tiles;
+    // (split, tile) pairs in split-major order, dealt to the XCDs in eight contiguous runs of gridDim.x / 8
+    const int item = xcd * (int)(gridDim.x >> 3) + slot;
+    const int round = item / tiles;
+    int bid = item - round * tiles;
+    if (grouped) {                       // uniform over the workgroup
+        int which = 0;
+        while (which + 1 < grp.n && bid >= grp.p[which].tile_end) ++which;
+        if (which > 0) bid -= grp.p[which - 1].tile_end;
+        const TnProb& q = grp.p[which];
+        A = q.A; B = q.B; C = q.C; lda = q.lda; ldb = q.ldb; ldc = q.ldc; M = q.M; N = q.N; K = q.K; tiles_n = q.tiles_n;
+    }
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = (round * 8 + xcd) * k_per_split;
+    const int kbeg = round * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
     if (kbeg >= kend) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1341,15 +1370,18 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
 
 // split K so that about 3 workgroups per CU are in flight: a multiple of 8 splits (one set per XCD) where K allows, each
 // split a multiple of the k tile
-static int tn_splits(int tiles, int K, int& k_per_split, int target = 768) {
+static int tn_splits(int tiles, int K, int& k_per_split, int target = 768, bool below8 = false) {
     int splits = cdiv(target, tiles);   // (3 workgroups per CU; 1024 was 5..17 % slower on the step's shapes, 512 hurt M = 3000)
-    splits = cdiv(splits, 8) * 8;
+    if (!(below8 && splits < 8)) splits = cdiv(splits, 8) * 8;      // below8 (grouped launches): 1..7 splits as they come
     const int max_splits = cdiv(K, 8 * TK);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     k_per_split = cdiv(cdiv(K, splits), TK) * TK;
     return cdiv(K, k_per_split);
 }
+
+// grid of the 128 x 128 TN kernel: the (split, tile) pairs in eight equal contiguous runs, one per XCD
+static int tn_grid(int tiles, int splits) { return 8 * cdiv(tiles * splits, 8); }
 
 // the 256 x 128 LDS-DMA kernel wants whole 16-B chunks (M, lda, ldb multiples of 8, aligned bases) and at least one full tile
 // of rows; ASR_TN256=0 keeps the 128 x 128 kernel (tests, comparison)
@@ -1383,8 +1415,38 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL);
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL, TnGroup{});
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// n <= 4 products C_i += A_i^T B_i (any shapes) in ONE launch; host arrays of n entries each.
+extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                     float* const* C, const int* ldc, const int* M, const int* N, const int* K) {
+    if (!A || !B || !C || !lda || !ldb || !ldc || !M || !N || !K || n < 1 || n > 4) return ASR_ERR_BAD_ARG;
+    TnGroup grp{};
+    int tiles = 0, kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!A[i] || !B[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || K[i] <= 0) return ASR_ERR_BAD_ARG;
+        if (lda[i] < M[i] || ldb[i] < N[i] || ldc[i] < N[i]) return ASR_ERR_BAD_ARG;
+        TnProb& q = grp.p[i];
+        q.A = (const uint16_t*)A[i]; q.B = (const uint16_t*)B[i]; q.C = C[i];
+        q.lda = lda[i]; q.ldb = ldb[i]; q.ldc = ldc[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
+        q.tiles_n = cdiv(N[i], BN);
+        tiles += cdiv(M[i], BM) * q.tiles_n;
+        q.tile_end = tiles;
+        kmax = K[i] > kmax ? K[i] : kmax;
+    }
+    grp.n = n;
+    hipStream_t stream = (hipStream_t)stream_;
+    int k_per_split;
+    static int target = 0;
+    if (!target) { const char* e = getenv("ASR_TN_GROUP_TARGET"); target = e ? atoi(e) : 1152; if (target < 1) target = 1152; }
+    const int splits = tn_splits(tiles, kmax, k_per_split, target, true);
+    const TnProb& q = grp.p[0];
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
+                       q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, ConvDesc{}, 0LL, grp);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -1423,8 +1485,9 @@ extern "C" int asr_conv_tn_acc_copies(void* stream_, const void* g, int ldg, con
     const int tiles_m = cdiv(Co, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, (int)K, k_per_split);
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(8 * tiles_m * tiles_n * cdiv(splits, 8)), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd, copies == 8 ? (long long)Co * ldc : 0LL);
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                       (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd, copies == 8 ? (long long)Co * ldc : 0LL,
+                       TnGroup{});
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

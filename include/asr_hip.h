@@ -119,10 +119,16 @@ int asr_edit_distance(void* stream, const int32_t* ref, const int32_t* ref_len, 
  *   asr_gemm_nt      C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]);  A, B bf16, k-contiguous (fast path: lda/ldb/K multiples
  *                    of 8 and 16-byte aligned bases; anything else takes element loads); C f32 (out_bf16 = 0) or bf16 (1)
  *   asr_gemm_tn_acc  C[M,N] += A[K,M]^T * B[K,N];  A, B bf16 row-major; C f32, accumulated with atomics (split-K)
+ *   asr_gemm_tn_acc_group  n <= 4 such products (any shapes) in ONE launch; every argument a host array of n entries:
+ *                    the weight gradients a recurrence releases together (dW_ih and the per-direction dW_hh of
+ *                    chainer.links.NStepBiGRU, asr/nn/nn.py:3 -- cuDNN's RNN backward-weights forms them in one call too).
+ *                    Two products may add into the same output.
  */
 int asr_gemm_nt(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                 int M, int N, int K, int out_bf16);
 int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K);
+int asr_gemm_tn_acc_group(void* stream, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                          float* const* C, const int* ldc, const int* M, const int* N, const int* K);
 
 /* ---------------------------------------------------------------------------------------- layout / activations
  * Internal activations are (T, B, H, C) bf16 (time-major, channel-last); see DESIGN.md "Data layout in HBM".

@@ -101,6 +101,42 @@ def test_gemm_tn_strided_views(device):
     assert _rel(c.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N,I,B", [(96, 40, 24, 16, 8), (2016, 1536, 512, 384, 32), (700, 130, 70, 264, 4)])
+def test_gemm_tn_acc_group(device, K, M, N, I, B):
+    """the grouped launch against float64 on the three products the GRU backward hands it: (K, 2M)^T (K, I), and per direction
+    (K - B, M)^T (K - B, N) on shifted strided views (direction 0 pairs rows t with t - 1, direction 1 t with t + 1); small
+    integers at the first shape (exact); two products into ONE output; grouped == one by one."""
+    from asr import _ops
+    g = torch.Generator().manual_seed(K + I)
+    exact = K == 96
+    draw = (lambda *s: torch.randint(-4, 5, s, generator=g).float()) if exact else (lambda *s: _bf(torch.randn(*s, generator=g)))
+    dgi, x, dgh, h = draw(K, 2 * M), draw(K, I), draw(K, 2 * M), draw(K, 2 * N)
+    c0 = [torch.zeros(s) if exact else torch.randn(*s, generator=g) for s in ((2 * M, I), (M, N), (M, N))]
+    dev = lambda t: t.to(device, BF16)
+    d_dgi, d_x, d_dgh, d_h = dev(dgi), dev(x), dev(dgh), dev(h)
+    def views(a, hh):
+        return [(a[B:, :M], hh[:-B, :N]), (a[:-B, M:], hh[B:, N:])]
+    c = [t.to(device) for t in c0]
+    prods = [(d_dgi, d_x, c[0])] + [(a, b, c[1 + d]) for d, (a, b) in enumerate(views(d_dgh, d_h))]
+    _ops.gemm_tn_acc_group(prods)
+    ref = [c0[0].double() + dgi.double().T @ x.double()] + [c0[1 + d].double() + a.double().T @ b.double()
+                                                            for d, (a, b) in enumerate(views(dgh, h))]
+    for got, want in zip(c, ref):
+        if exact:
+            assert torch.equal(got.cpu().double(), want)
+        else:
+            assert _rel(got.cpu(), want) < 1e-5
+    one = [t.to(device) for t in c0]
+    for (a, b, _), o in zip(prods, one):
+        _ops.gemm_tn_acc(a, b, o)
+    for got, o in zip(c, one):
+        assert _rel(got.cpu(), o.cpu().double()) < 1e-6
+    both = torch.zeros(M, N, device=device)                         # two products adding into one output
+    (a0, b0), (a1, b1) = views(d_dgh, d_h)
+    _ops.gemm_tn_acc_group([(a0, b0, both), (a1, b1, both)])
+    assert _rel(both.cpu(), (ref[1] - c0[1].double()) + (ref[2] - c0[2].double())) < 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,Hin,T,Cout,pad_h,first", [(2, 3, 12, 37, 16, 0, True), (3, 8, 13, 50, 24, 0, False),
                                                           (2, 16, 9, 33, 32, 1, False)])
 def test_conv_as_im2col_gemm(device, B, Cin, Hin, T, Cout, pad_h, first):

@@ -29,10 +29,19 @@ def tn(a, b, c):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = o_tn(a, b, c); e1.record()
     log.append(("tn", a.shape[1], b.shape[1], a.shape[0], "f32acc", e0, e1)); return r
+o_tng = _ops.gemm_tn_acc_group
+def tng(products):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); r = o_tng(products); e1.record()
+    fl = sum(2.0 * a.shape[1] * b.shape[1] * a.shape[0] for a, b, _ in products)
+    log.append(("tn", -1, len(products), fl, " ".join("%dx%dx%d" % (a.shape[1], b.shape[1], a.shape[0]) for a, b, _ in products), e0, e1)); return r
 _ops.gemm_nt, _ops.gemm_tn_acc = nt, tn
+if _ops.TN_GROUP[0]: _ops.gemm_tn_acc_group = tng
 step(); torch.cuda.synchronize()
 tot = {"nt": 0.0, "tn": 0.0}
 for kind, M, N, K, od, e0, e1 in log:
     ms = e0.elapsed_time(e1); tot[kind] += ms
+    if M < 0:
+        print("tn group of %d: %s  %.3f ms  %6.1f TF/s" % (N, od, ms, K / ms / 1e9)); continue
     print("%s M=%7d N=%5d K=%6d %-8s %.3f ms  %6.1f TF/s" % (kind, M, N, K, od, ms, 2.0 * M * N * K / ms / 1e9))
 print(tot)
