@@ -366,16 +366,6 @@ class _Conv2D(torch.autograd.Function):
         xphys = col if implicit else None        # the implicit forward saved the input, not a column matrix
         Kp = (Kreal + 7) // 8 * 8 if implicit else col.shape[1]
         w_is_param = isinstance(W, torch.nn.Parameter)
-        gx = None
-        if need_dx:         # activation gradient first: it is what the rest of the backward pass waits for
-            if wbwd is not None and not pointwise:      # implicit backward-data: no dcol matrix, no col2im pass
-                gp = _ops.conv_nt(g2.reshape(Tout, B, Hout, Co), wbwd, None, BF16, KH, KW, pad_h, pad_t, -1, T, Hin).reshape(T, B, Hin, Ci)
-            else:
-                dcol = _ops.gemm_nt(g2, w16t, None, BF16)
-                gp = dcol.reshape(T, B, Hin, Ci) if pointwise else _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, pad_h, pad_t, Tout)
-            gx = gp.permute(1, 3, 2, 0)
-            if xdtype == F32:
-                gx = _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
         if w_is_param:
             gW = grad_buffer(W)
         else:       # a derived weight (weight normalisation): hand its gradient back to the tape
@@ -404,11 +394,26 @@ class _Conv2D(torch.autograd.Function):
                     _ops.colsum_acc(g2, gb)
                 elif gy_auto is not None and getattr(ctx, "_asr_mailbox", None) is not None:
                     _ops.colsum_acc(gy_auto, gb)        # the part another consumer of y sent through autograd
-        if w_is_param:
+
+        def input_grad():
+            if not need_dx:
+                return None
+            if wbwd is not None and not pointwise:      # implicit backward-data: no dcol matrix, no col2im pass
+                gp = _ops.conv_nt(g2.reshape(Tout, B, Hout, Co), wbwd, None, BF16, KH, KW, pad_h, pad_t, -1, T, Hin).reshape(T, B, Hin, Ci)
+            else:
+                dcol = _ops.gemm_nt(g2, w16t, None, BF16)
+                gp = dcol.reshape(T, B, Hin, Ci) if pointwise else _ops.col2im(dcol, T, B, Hin, Ci, KH, KW, pad_h, pad_t, Tout)
+            if xdtype == F32:
+                return _ops.bf16_to_f32(gp).permute(1, 3, 2, 0)
+            return gp.permute(1, 3, 2, 0)
+
+        if w_is_param:      # the side stream forks BEFORE the input-gradient product is queued: beside it, not behind it
             with _OnSide(g2, col):
                 weight_grads()
+            gx = input_grad()
             grads_queued(W, b)
-        else:
+        else:               # (derived weight: its gradient goes back to the tape on this stream -- the activation gradient first)
+            gx = input_grad()
             weight_grads()
             grads_queued(b)
         return gx, (None if w_is_param else gW), None, None, None, None, None, None, None, None, None
@@ -484,16 +489,16 @@ class _Dense(torch.autograd.Function):
         W, b = ctx.params
         bias_done = _take_bias_done(ctx)
         gy, gy_auto = _incoming_bf16(ctx, gy, W.shape[0])
-        gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         gW = grad_buffer(W).reshape(W.shape[0], -1)
         gb = grad_buffer(b) if b is not None else None
-        with _OnSide(gy, x2, gy_auto):
+        with _OnSide(gy, x2, gy_auto):      # forked BEFORE the input-gradient product is queued: beside it, not behind it
             _ops.gemm_tn_acc(gy, x2, gW)
             if gb is not None:
                 if not bias_done:
                     _ops.colsum_acc(gy, gb)
                 elif gy_auto is not None:
                     _ops.colsum_acc(gy_auto, gb)        # the part another consumer of y sent through autograd
+        gx = _ops.gemm_nt(gy, w16t, None, BF16) if ctx.need_dx else None
         grads_queued(W, b)
         return gx, None, None, None, None, None
 
