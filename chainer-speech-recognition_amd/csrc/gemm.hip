@@ -478,7 +478,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 // and the tap walk is scalar state of the issuing side); a row outside the tensor or an empty tap gets a voffset beyond the
 // buffer's num_records -- the buffer load then writes zeros, no zero page and no select between pointers.
 // NJ: column tiles per wave = tile width / 16: 8 -> 256 x 128, 4 -> 256 x 64 (N <= 64: no MFMA work on columns that do not exist).
-template <typename OutT, int CONV, int NJ>
+// KT: K is a multiple of 8 but not of the 32-wide K step (the logit gradient's K = V = 3000): the chunks of the last step that lie
+// beyond K are fetched from beyond the buffers' ends, i.e. as zeros -- both operands, so whatever follows a row never meets a number.
+template <typename OutT, int CONV, int NJ, bool KT = false>
 __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B,
                                                                        int ldb, OutT* __restrict__ C, int ldc, const float* __restrict__ bias,
                                                                        int M, int N, int K, int tiles_m, int tiles_n, int total,
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
     char* As = smem;
     char* Bs = smem + 2 * A_STAGE;
     auto g4 = [](int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; };      // g = {0, 2, 3, 1}
-    const int nk = K / B2K;
+    const int nk = KT ? (K + B2K - 1) / B2K : K / B2K;
     // Tile walk: XCD x (= bid % 8 under round-robin dispatch; only a locality hint) owns the CONTIGUOUS tiles [x chunk, (x + 1) chunk),
     // its workgroups stride through them together: ~64-96 consecutive row panels in flight per L2.  For the implicit convolutions that
     // is what keeps the taps' re-reads of the activations (rows of neighbouring time steps = the neighbouring panels) inside one L2:
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
     int it_tile = first, it_k = 0;
     int tw_kh = 0, tw_kw = 0, tw_ci = 0;   // CONV: tap of the next K step to issue (CONV == 2: of this lane's chunk of that step)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, KT ? N * ldb * 2 : -1, 0x00020000);
     auto set_issue = [&](int t) {
         int tm, tn;
         tm = t / tiles_n;
@@ -557,13 +559,17 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
                 lds_dma16(rsrc_a, As + buf * A_STAGE + (i * 256 + wid * 64) * 16, ok ? oa[i] + delta : 0xfffffff0u, 0);
             }
         } else {
+            const bool dead = KT && it_k == nk - 1 && it_k * B2K + (lchunk >> 1) >= K;      // this lane's chunk of the last K step lies beyond K
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                lds_dma16(rsrc_a, As + buf * A_STAGE + (i * 256 + wid * 64) * 16, oa[i], koff);
+                lds_dma16(rsrc_a, As + buf * A_STAGE + (i * 256 + wid * 64) * 16, dead ? 0xfffffff0u : oa[i], koff);
         }
+        {
+            const bool dead = KT && it_k == nk - 1 && it_k * B2K + (lchunk >> 1) >= K;
 #pragma unroll
-        for (int i = 0; i < BP; ++i)
-            lds_dma16(rsrc_b, Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16, ob[i], koff);
+            for (int i = 0; i < BP; ++i)
+                lds_dma16(rsrc_b, Bs + buf * B_STAGE + (i * 256 + wid * 64) * 16, dead ? 0xfffffff0u : ob[i], koff);
+        }
         if (++it_k == nk) {
             it_k = 0;
             it_tile += stride;
@@ -1320,7 +1326,8 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
     static int pmin = -1;
     if (pmin < 0) { const char* e = getenv("ASR_NT_PERSIST_MIN"); pmin = e ? atoi(e) : 256; }      // (one tile per CU: 32000 x 384 x 3072 642 -> 688, x 320 x 3008 532 -> 604 TFLOP/s against the 128 x 128 kernel)
-    if (persist && aligned && (K % B2K) == 0 && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= pmin && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
+    const bool k_tail = (K % B2K) != 0;       // K = 3000 (the logit gradient): the last K step is fetched short, see the kernel's KT
+    if (persist && aligned && (K % 8) == 0 && K >= B2K && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= pmin && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
         (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldb < (1ull << 31) && M < (1 << 24) && N < (1 << 24) &&
         lda < (1 << 23) && ldb < (1 << 23)) {
         static bool attrp = false;
@@ -1331,7 +1338,21 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         }
         const int t2m = cdiv(M, B2M), t2n = cdiv(N, B2N), total = t2m * t2n;
         const int grid = nt_persist_grid(total, 3);
-        if (out_bf16)
+        if (k_tail) {
+            static bool attrk = false;
+            if (!attrk) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<float, 0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<uint16_t, 0, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS_BYTES);
+                attrk = true;
+            }
+            const unsigned a_bytes = (unsigned)((unsigned long long)M * lda * 2);
+            if (out_bf16)
+                hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, 0, 8, true>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                                   (uint16_t*)C, ldc, bias, M, N, K, t2m, t2n, total, a_bytes, ConvDesc{});
+            else
+                hipLaunchKernelGGL((gemm_nt256p_kernel<float, 0, 8, true>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
+                                   (float*)C, ldc, bias, M, N, K, t2m, t2n, total, a_bytes, ConvDesc{});
+        } else if (out_bf16)
             hipLaunchKernelGGL((gemm_nt256p_kernel<uint16_t, 0, 8>), dim3(grid), dim3(256), NT2_LDS_BYTES, stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb,
                                (uint16_t*)C, ldc, bias, M, N, K, t2m, t2n, total, 0xffffffffu, ConvDesc{});
         else

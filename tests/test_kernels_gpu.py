@@ -37,11 +37,13 @@ def test_gemm_nt(device, M, N, K, out_dtype):
     assert _rel(out2, a.double() @ b.double().T) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K,bias_on", [(8000, 3072, 512, True), (7777, 3000, 320, True), (8192, 4100, 64, False), (5000, 6400, 96, True)])
+@pytest.mark.parametrize("M,N,K,bias_on", [(8000, 3072, 512, True), (7777, 3000, 320, True), (8192, 4100, 64, False), (5000, 6400, 96, True),
+                                           (32000, 320, 3000, False), (8192, 4100, 72, True), (5000, 6400, 40, False)])
 @pytest.mark.parametrize("out_dtype", [BF16, F32])
 def test_gemm_nt_many_tiles(device, M, N, K, bias_on, out_dtype):
     """>= 1024 tiles of 256 x 128: the persistent kernel (several tiles per workgroup, K pipeline across tile boundaries, register
-    epilogue); ragged M, N not a multiple of the tile or of 16, one K step only"""
+    epilogue); ragged M, N not a multiple of the tile or of 16, one K step only; K a multiple of 8 but not of the K step (the last
+    step is fetched short: K = 3000 is the logit gradient's shape)"""
     from asr import _ops
     g = torch.Generator().manual_seed(M + N + K)
     a = _bf(torch.randn(M, K, generator=g))
