@@ -59,6 +59,10 @@ def parse():
     return ap.parse_args()
 
 
+# the GEMM-class entries of the census (gemm_tn_acc_group: the grouped weight gradients of a GRU layer, one launch)
+GEMM_OPS = ("gemm_nt", "gemm_tn_acc", "gemm_tn_acc_group", "conv_nt", "conv_tn_acc")
+
+
 class Census(object):
     """Per-op-class device time of ONE extra step, HIP events recorded on the launch stream around every C-ABI call."""
 
@@ -67,7 +71,7 @@ class Census(object):
 
     def wrap(self, ops):
         self._orig = {}
-        for name in ("gemm_nt", "gemm_tn_acc", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd", "layernorm_ctc_bwd",
+        for name in ("gemm_nt", "gemm_tn_acc", "gemm_tn_acc_group", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd", "layernorm_ctc_bwd",
                      "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "adam_ctl",
                      "step_control", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
                      "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd"):
@@ -498,7 +502,7 @@ def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
     asr_functions._SIDE["enabled"] = True
     census.unwrap()
     macs = cnn_macs_per_frame(cfg)
-    gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
+    gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in GEMM_OPS)
     flops = 3 * 2.0 * macs * T * B
     res = {"workload": "BASELINE configs[4] on one GPU: zhang+residual, %s, ndim_h 128, ndim_dense 320, B=%d, T=%d, V=%d, bf16 (see dtype_note)"
                        % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V),
@@ -748,8 +752,8 @@ def main():
             # dominant kernel class: the implicit-GEMM convolutions (forward, backward-data, weight gradient) and the 1x1 /
             # kernel_height "dense" convolutions -- MFMA-bound: 2 flops per multiply-accumulate, x3 for the train step
             macs = cnn_macs_per_frame(cfg)
-            gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
-            launches = sum(tot.get(k, (0.0, 0))[1] for k in ("gemm_nt", "gemm_tn_acc", "conv_nt", "conv_tn_acc"))
+            gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in GEMM_OPS)
+            launches = sum(tot.get(k, (0.0, 0))[1] for k in GEMM_OPS)
             flops = 3 * 2.0 * macs * T * B
             out["roofline"] = {"bound": "mfma", "kernel": "asr::gemm implicit-GEMM convolutions (conv_nt / conv_tn_acc) + gemm_nt / gemm_tn",
                                "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -830,7 +834,7 @@ def main():
         frames = T * B
         macs_fwd = frames * 15.25e6
         # conv_nt / conv_tn_acc: the implicit-GEMM convolutions (forward, backward-data; weight gradient)
-        gemm_ms = tot["gemm_nt"][0] + tot["gemm_tn_acc"][0] + tot.get("conv_nt", (0.0, 0))[0] + tot.get("conv_tn_acc", (0.0, 0))[0]
+        gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in GEMM_OPS)
         rec_flops = 2 * (2 * nl * T) * (B * H * 3 * H * 2)      # recurrent MFMA work runs inside the GRU kernels
         gemm_flops = 3 * 2 * macs_fwd - rec_flops
         out["roofline_gemm"] = {"bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
