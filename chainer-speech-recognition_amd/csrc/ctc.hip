@@ -138,19 +138,28 @@ __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ xs,
 }
 
 // ------------------------------------------------------------------------------------------------ lattice
-// log(sum_j exp(v_j)) with f64 max/offset and f32 transcendental on the (<= 0) differences.
+// log(sum_j exp(v_j)) over the inputs the mask names.  The offset m only has to be NEAR the maximum (the identity holds for any m),
+// so it is found in float32 -- one v_max3_f32 per three inputs instead of a chain of canonicalising v_max_f64 / v_cndmask pairs --
+// and floored at -1e30: dead inputs (-inf) then give exp(-inf) = 0 and an all-dead node log(0) = -inf without a branch.  The
+// differences v_j - m are formed in float64 (exact), the transcendentals in float32 on arguments <= ~1e-3: absolute error ~1e-7
+// as before.  The step of the lattice is one dependent chain (LDS read -> ... -> LDS write, ~0.3 us); this form has 16 instructions
+// on it instead of 35 (v_log_f32 x ln 2 instead of the denormal-safe logf sequence: the sum lies in [1, NK]).
 template <int NK>
 __device__ __forceinline__ double lse_masked(const double* v, int mask) {
-    double m = -INFINITY;
+    float f[NK];
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
-        if (mask & (1 << j)) m = fmax(m, v[j]);
-    if (m == -INFINITY) return m;
+    for (int j = 0; j < NK; ++j) f[j] = (mask & (1 << j)) ? (float)v[j] : -INFINITY;
+    float m32 = -1e30f;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) m32 = __builtin_fmaxf(m32, f[j]);
+    const double m = (double)m32;
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < NK; ++j)
-        if (mask & (1 << j)) acc += __expf((float)(v[j] - m));     // arguments <= 0: absolute error ~1e-7
-    return m + (double)__logf(acc);                                  // acc in [1, NK]
+    for (int j = 0; j < NK; ++j) {
+        const float e = __expf((float)(v[j] - m));
+        acc += (mask & (1 << j)) ? e : 0.f;
+    }
+    return m + (double)(__builtin_amdgcn_logf(acc) * 0.69314718f);       // acc == 0 (no live input): log2 -> -inf
 }
 
 // __syncthreads() is s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier: in the one-node-per-thread loops it made every time step wait for
@@ -201,24 +210,41 @@ __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__
         __syncthreads();
         const int sidx = threadIdx.x;
         const int mk = mask_s[sidx];
+        // Whole blocks of PF steps run without a branch and every step issues exactly one store and one load (the prefetch index is
+        // clamped, not guarded): gfx9 counts loads and stores in ONE in-order counter, and only in straight-line code can the
+        // compiler wait for "all but the 2 (PF - 1) youngest" -- behind a branch it waits for vmcnt(0), i.e. every step paid the
+        // round trip of the alpha store and the prefetch it had just issued.
         float lq[PF];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) lq[j] = j < xl ? lpb[(size_t)j * Sp + sidx] : 0.f;
-        for (int t0 = 0; t0 < xl; t0 += PF) {
+        for (int j = 0; j < PF; ++j) lq[j] = lpb[(size_t)min(j, xl - 1) * Sp + sidx];
+        int t0 = 0;
+        for (; t0 + PF <= xl; t0 += PF) {
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 const int t = t0 + j;
-                if (t < xl) {                      // uniform over the workgroup
-                    double v[NK];
+                double v[NK];
 #pragma unroll
-                    for (int q = 0; q < NK; ++q) v[q] = prev[sidx - koff<NK>(q)];
-                    const double a = lse_masked<NK>(v, mk) + (double)lq[j];
-                    cur[sidx] = a;
-                    outb[(size_t)t * Sp + sidx] = a;
-                    lq[j] = t + PF < xl ? lpb[(size_t)(t + PF) * Sp + sidx] : 0.f;
-                    ASR_LDS_BARRIER();
-                    double* tmp = prev; prev = cur; cur = tmp;
-                }
+                for (int q = 0; q < NK; ++q) v[q] = prev[sidx - koff<NK>(q)];
+                const double a = lse_masked<NK>(v, mk) + (double)lq[j];
+                cur[sidx] = a;
+                outb[(size_t)t * Sp + sidx] = a;
+                lq[j] = lpb[(size_t)min(t + PF, xl - 1) * Sp + sidx];
+                ASR_LDS_BARRIER();
+                double* tmp = prev; prev = cur; cur = tmp;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF - 1; ++j) {         // the last xl % PF steps: their log-probabilities are in lq[0 .. ] already
+            const int t = t0 + j;
+            if (t < xl) {                          // uniform over the workgroup
+                double v[NK];
+#pragma unroll
+                for (int q = 0; q < NK; ++q) v[q] = prev[sidx - koff<NK>(q)];
+                const double a = lse_masked<NK>(v, mk) + (double)lq[j];
+                cur[sidx] = a;
+                outb[(size_t)t * Sp + sidx] = a;
+                ASR_LDS_BARRIER();
+                double* tmp = prev; prev = cur; cur = tmp;
             }
         }
         if (threadIdx.x == 0) {
@@ -245,22 +271,35 @@ __global__ __launch_bounds__(1024) void lattice_kernel(const float* __restrict__
         __syncthreads();
         float lq[PF];
 #pragma unroll
-        for (int j = 0; j < PF; ++j) lq[j] = xl - 2 - j >= 0 ? lpb[(size_t)(xl - 2 - j) * Sp + sidx] : 0.f;
-        for (int t0 = xl - 2; t0 >= 0; t0 -= PF) {
+        for (int j = 0; j < PF; ++j) lq[j] = lpb[(size_t)max(xl - 2 - j, 0) * Sp + sidx];
+        int t0 = xl - 2;
+        for (; t0 - (PF - 1) >= 0; t0 -= PF) {      // whole blocks of PF steps, branch-free (see the forward loop)
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
                 const int t = t0 - j;
-                if (t >= 0) {
-                    double v[NK];
+                double v[NK];
 #pragma unroll
-                    for (int q = 0; q < NK; ++q) v[q] = prev[sidx + koff<NK>(q)];
-                    const double bt = lse_masked<NK>(v, mkd);
-                    outb[(size_t)t * Sp + sidx] = bt;
-                    cur[sidx] = bt + (double)lq[j];
-                    lq[j] = t - PF >= 0 ? lpb[(size_t)(t - PF) * Sp + sidx] : 0.f;
-                    ASR_LDS_BARRIER();
-                    double* tmp = prev; prev = cur; cur = tmp;
-                }
+                for (int q = 0; q < NK; ++q) v[q] = prev[sidx + koff<NK>(q)];
+                const double bt = lse_masked<NK>(v, mkd);
+                outb[(size_t)t * Sp + sidx] = bt;
+                cur[sidx] = bt + (double)lq[j];
+                lq[j] = lpb[(size_t)max(t - PF, 0) * Sp + sidx];
+                ASR_LDS_BARRIER();
+                double* tmp = prev; prev = cur; cur = tmp;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF - 1; ++j) {
+            const int t = t0 - j;
+            if (t >= 0) {
+                double v[NK];
+#pragma unroll
+                for (int q = 0; q < NK; ++q) v[q] = prev[sidx + koff<NK>(q)];
+                const double bt = lse_masked<NK>(v, mkd);
+                outb[(size_t)t * Sp + sidx] = bt;
+                cur[sidx] = bt + (double)lq[j];
+                ASR_LDS_BARRIER();
+                double* tmp = prev; prev = cur; cur = tmp;
             }
         }
     } else if (!backward) {

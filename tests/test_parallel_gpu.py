@@ -73,21 +73,25 @@ from asr.data.synthetic import synthetic_batch
 
 world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
 kind, optname, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
-dev = torch.device("cuda:0")
-_ops.GRU_MODE[0] = 1
+backend = os.environ.get("ASR_TEST_BACKEND", "gloo")
+di = int(os.environ["LOCAL_RANK"])              # gloo: every rank on device 0; nccl: one device per rank
+torch.cuda.set_device(di)
+dev = torch.device("cuda", di)
+if backend == "gloo":
+    _ops.GRU_MODE[0] = 1                        # (two processes' persistent launches would compete for the CUs of the shared device)
 torch.manual_seed(1234 + rank)                  # DIFFERENT seeds: only the broadcast can make the ranks agree
 V, B, T = 31, 8, 64
 if kind in ("ds2", "ds2+halves"):
     from asr.model import ds2
     cfg = ds2.configure(); cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 128, 32, 2
-    model = ds2.Model(cfg).to_gpu(0)
+    model = ds2.Model(cfg).to_gpu(di)
 else:                                           # weight-normalised convolutional recipe with lazily sized layer norms
     from asr.model import cnn
     from asr.model.architectures import build_model
     cfg = cnn.configure()
     cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = V, 3, 16, 24, 2
     cfg.architecture, cfg.weightnorm = "zhang+layernorm", True
-    model = build_model(cfg).to_gpu(0)
+    model = build_model(cfg).to_gpu(di)
 x, labels, x_len, l_len = synthetic_batch(B, T, V, Lmin=3, Lmax=9, seed=0, ragged=True)
 first = slice(0, B // 2)
 mine = slice(rank * (B // world), (rank + 1) * (B // world))
@@ -98,7 +102,7 @@ opt.setup(model); opt.add_hook(GradientClipping(1.0)); opt.add_hook(WeightDecay(
 comm = None
 if world > 1:
     from asr.parallel import Communicator
-    comm = Communicator("gloo", buckets=3)
+    comm = Communicator(backend, buckets=3)
     comm.bcast_data(model)
     opt.set_communicator(comm)
 xd, ld, xl, ll = x[mine].to(dev), labels[mine].to(dev), x_len[mine].to(dev), l_len[mine].to(dev)
@@ -127,12 +131,12 @@ if comm is not None:
 '''
 
 
-def _spawn(root, tmp_path, world, kind, optname, port):
+def _spawn(root, tmp_path, world, kind, optname, port, backend="gloo"):
     procs, outs = [], []
     for r in range(world):
-        out = str(tmp_path / ("%s_%s_w%d_r%d.pt" % (kind.replace("+", "_"), optname, world, r)))
+        out = str(tmp_path / ("%s_%s_%s_w%d_r%d.pt" % (kind.replace("+", "_"), optname, backend, world, r)))
         env = dict(os.environ, ASR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE=str(world),
-                   LOCAL_RANK="0")
+                   LOCAL_RANK=str(r if backend == "nccl" else 0), ASR_TEST_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, "-c", DP_SCRIPT, kind, optname, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
         outs.append(out)
@@ -143,13 +147,23 @@ def _spawn(root, tmp_path, world, kind, optname, port):
     return [torch.load(o) for o in outs]
 
 
-@pytest.mark.parametrize("kind,optname", [("ds2", "adam"), ("ds2", "msgd"), ("cnn+weightnorm", "msgd"), ("ds2+halves", "msgd")])
-def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname):
+def _visible_gpus():
     import torch
+    return torch.cuda.device_count()            # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("kind,optname,backend", [("ds2", "adam", "gloo"), ("ds2", "msgd", "gloo"), ("cnn+weightnorm", "msgd", "gloo"),
+                                                  ("ds2+halves", "msgd", "gloo"), ("ds2", "msgd", "nccl"), ("ds2", "adam", "nccl")])
+def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname, backend):
+    """backend nccl: the same comparison over RCCL with one GPU per rank and the persistent recurrence kernels -- needs two visible
+    GPUs, skipped on the one-GPU test box (where RCCL is covered by the single-rank test above and the control flow by gloo)."""
+    import torch
+    if backend == "nccl" and _visible_gpus() < 2:
+        pytest.skip("RCCL between two ranks needs two GPUs")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29541 + (hash((kind, optname)) % 40)
-    one = _spawn(root, tmp_path, 1, kind, optname, port)[0]
-    two = _spawn(root, tmp_path, 2, kind, optname, port + 50)
+    port = 29541 + (hash((kind, optname, backend)) % 40)
+    one = _spawn(root, tmp_path, 1, kind, optname, port, backend)[0]
+    two = _spawn(root, tmp_path, 2, kind, optname, port + 50, backend)
     # the broadcast made the ranks start from rank 0's parameters (seeds differ), i.e. from the one-rank run's
     assert torch.equal(two[0]["start"], two[1]["start"])
     assert torch.equal(two[0]["start"], one["start"])
