@@ -192,10 +192,13 @@ __global__ __launch_bounds__(SX * SY) void bwd_summary_kernel(const float* __res
     const float* u = U + ((size_t)(t1 - 1) * B + cl.b) * 3 * D + cl.d;
     size_t row = (size_t)(t1 - 1) * xs + col;
     float2 P = make_float2(1.f, 1.f), S = make_float2(0.f, 0.f);
+    const uint16_t* ghp = gH ? gH : reinterpret_cast<const uint16_t*>(C);      // (a missing gH: any valid row, scaled by 0 -- no branch in the loop)
+    const float ghs = gH ? 1.f : 0.f;
 #pragma unroll 4
     for (int t = t1 - 1; t >= t0; --t, u -= us, row -= xs) {
         const float2 fp = ld2(u + D), rp = ld2(u + 2 * D), c = ld2(C + row);
-        const float2 gh = gH ? bf2(gH + row) : make_float2(0.f, 0.f);
+        float2 gh = bf2(ghp + row);
+        gh.x *= ghs; gh.y *= ghs;
         const float fx = fsig(fp.x + bf.x), fy = fsig(fp.y + bf.y);
         const float rx = fsig(rp.x + br.x), ry = fsig(rp.y + br.y);
         const float gx = TANH ? ftanh(c.x) : c.x, gy = TANH ? ftanh(c.y) : c.y;
@@ -233,12 +236,33 @@ __global__ __launch_bounds__(SX * SY) void bwd_apply_kernel(const uint16_t* __re
         uint16_t* gu = gU + ((size_t)(t1 - 1) * B + cl.b) * 3 * D + cl.d;
         size_t row = (size_t)(t1 - 1) * xs + col;
         float2 c = ld2(C + row);
-#pragma unroll 4
+        // No branch inside the loop: gfx9 counts loads and stores in ONE in-order counter, and behind a branch the compiler waits for
+        // vmcnt(0) -- every step then waited for the loads it had just issued (the unrolled steps' loads no longer overlapped).  The
+        // t == 0 state and a missing gH are selected AFTER an always-valid load (clamped address / the x row).
+        const uint16_t* ghp = gH ? gH : x;
+        const float ghs = gH ? 1.f : 0.f;
+        // software pipeline: the operands of step t - 1 are asked for before step t is worked on (the last step asks for its own row
+        // again: always a valid address), so that a lane has two steps of loads in flight across the transcendental chain of a step
+        struct In { float2 z, fp, rp, cp; uint32_t xw, gw; };
+        auto ask = [&](const float* uu, size_t rr, int tt) {
+            In in;
+            in.z = ld2(uu); in.fp = ld2(uu + D); in.rp = ld2(uu + 2 * D);
+            in.xw = *reinterpret_cast<const uint32_t*>(x + rr);
+            in.gw = *reinterpret_cast<const uint32_t*>(ghp + rr);
+            in.cp = ld2(C + (tt == 0 ? rr : rr - xs));
+            return in;
+        };
+        In cur = ask(u, row, t1 - 1);
+#pragma unroll 2
         for (int t = t1 - 1; t >= t0; --t, u -= us, gu -= us, row -= xs) {
-            const float2 z = ld2(u), fp = ld2(u + D), rp = ld2(u + 2 * D);
-            const float2 xr = bf2(x + row);
-            const float2 gh = gH ? bf2(gH + row) : make_float2(0.f, 0.f);
-            const float2 cp = t == 0 ? cinit : ld2(C + row - xs);
+            const bool more = t > t0;
+            const In nxt = ask(more ? u - us : u, more ? row - xs : row, more ? t - 1 : t);
+            const float2 z = cur.z, fp = cur.fp, rp = cur.rp;
+            const float2 xr = make_float2(__uint_as_float(cur.xw << 16), __uint_as_float(cur.xw & 0xffff0000u));
+            float2 gh = make_float2(__uint_as_float(cur.gw << 16), __uint_as_float(cur.gw & 0xffff0000u));
+            gh.x *= ghs; gh.y *= ghs;
+            float2 cp = cur.cp;
+            if (t == 0) cp = cinit;
             const float fx = fsig(fp.x + bf.x), fy = fsig(fp.y + bf.y);
             const float rx = fsig(rp.x + br.x), ry = fsig(rp.y + br.y);
             const float xx = xr.x * mk.x, xy = xr.y * mk.y;
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(SX * SY) void bwd_apply_kernel(const uint16_t* __re
             gc.x = tx * fx; gc.y = ty * fy;                                                                         // :174
             sbfx += gbfx; sbfy += gbfy; sbrx += gbrx; sbry += gbry;
             c = cp;
+            cur = nxt;
         }
         if (k == 0) *reinterpret_cast<float2*>(gc0 + col) = gc;
     }
