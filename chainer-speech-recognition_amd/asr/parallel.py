@@ -19,8 +19,10 @@ When a slice may go
   *right after* it is queued the complete slices are launched behind it on the communication stream.  A collective
   therefore runs in the gap between two recurrences, next to the projection and weight-gradient GEMMs of the NEXT layer
   (which it does not depend on), never beside a recurrence.  What is complete after the last recurrence (the first GRU
-  layer, the convolutions) goes in ``finish_backward``.  A backward pass without recurrences (the convolutional recipes)
-  launches every slice the moment it is complete.
+  layer, the convolutions) no longer has a recurrence to fear: behind the last recurrence of a pass (the count is the previous
+  pass's) slices go the moment they are complete, beside the convolutions' backward pass; only the small slice at the front of
+  the buffer (``make_plan``) is left for ``finish_backward``.  A backward pass without recurrences (the convolutional
+  recipes) launches every slice the moment it is complete.
 """
 import os
 
@@ -48,6 +50,7 @@ class Communicator(object):
         self.measure = False            # bench.py: time the launch stream's stalls on collectives (exposed_ms)
         self.exposed = []
         self._hold_all = False
+        self._rec_count = self._rec_count_prev = 0      # recurrences met in this / the previous backward pass
 
     # -- parameters -------------------------------------------------------------------------------
     def broadcast(self, flat):
@@ -71,17 +74,30 @@ class Communicator(object):
         (begin, end, first parameter index, last parameter index).  The last slice starts at element 0: it takes the reserved
         elements in front of the first parameter along (optimizers.RESERVED: the cross-rank "a recurrence gave up" mark)."""
         total = offsets[-1] + sizes[-1]
-        target = (total + buckets - 1) // buckets
+        # The slice at the FRONT of the buffer is summed last, after the whole backward pass has been queued, with nothing left to
+        # hide it behind: keep it small -- the longest run of leading parameters within 1/32 of the buffer (the convolutions of the
+        # BASELINE model: 0.25 M of 13.9 M parameters) -- and cut the rest into buckets - 1 slices of equal size.
+        n = len(offsets)
+        front = 0                                   # parameters 0 .. front form the last slice
+        if buckets > 1 and n > 1:
+            while front + 1 < n - 1 and offsets[front + 1] + sizes[front + 1] <= total // 32:
+                front += 1
+            rest = total - (offsets[front] + sizes[front])
+            target = (rest + buckets - 2) // (buckets - 1)
+        else:
+            front = n - 1
+            target = total
         plan, end = [], total
-        last = len(offsets) - 1
+        last = n - 1
         acc = 0
-        for i in range(len(offsets) - 1, -1, -1):
+        for i in range(n - 1, front, -1):
             acc += sizes[i]
-            if acc >= target or i == 0:
-                plan.append((offsets[i] if i > 0 else 0, end, i, last))
+            if acc >= target or i == front + 1:
+                plan.append((offsets[i], end, i, last))
                 end = offsets[i]
                 last = i - 1
                 acc = 0
+        plan.append((0, end, 0, last))
         return plan
 
     def begin_backward(self, opt, passes=1):
@@ -102,6 +118,7 @@ class Communicator(object):
         self._new_pass()
         self.launch_log = []
         self._defer, self._met_recurrence = self._recurrent, False
+        self._rec_count = 0
         # two passes on two streams (asr/pipeline.py): the "no collective beside a recurrence" rule would have to hold on BOTH
         # launch streams -- the other half's persistent recurrences keep starting while a collective queued from this pass is
         # resident.  Nothing is launched before finish_backward then.
@@ -143,9 +160,15 @@ class Communicator(object):
     # recurrence boundaries (see the module docstring)
     def _before_recurrence(self):
         self._defer = self._met_recurrence = True
+        self._rec_count += 1
         self._join_pending()
 
     def _after_recurrence(self):
+        # Behind the LAST recurrence of the pass (as many as the previous pass had) nothing wants every CU any more: slices go the
+        # moment they are complete again -- the first GRU layer's gradients are then summed beside the convolutions' backward pass
+        # instead of after it.  Should more recurrences follow after all, each still waits for what is in flight (and defers again).
+        if self._rec_count_prev and self._rec_count == self._rec_count_prev:
+            self._defer = False
         if self.overlap:
             self._launch_complete()
 
@@ -246,6 +269,7 @@ class Communicator(object):
         self._join_pending()
         self._plan = None
         self._recurrent = self._met_recurrence
+        self._rec_count_prev = self._rec_count
 
     def allreduce_scalar_mean(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -210,6 +210,39 @@ def test_baseline_plan_never_reduces_a_slice_before_its_writers(buckets):
         assert sorted(k for k, _, _ in launches[-nslices:]) == list(range(nslices))     # every slice exactly once per step
         assert not any(inside for _, _, inside in launches)
     assert res[0][2] == res[1][2], "ranks issued their collectives in different orders"
+    if buckets in (4, 7):
+        # second step (the number of recurrences is known from the first): behind the last recurrence slices go the moment they are
+        # complete -- everything but the small front slice (the convolutions) is on its way BEFORE the convolutions' gradients
+        # are written, i.e. it is summed beside their backward pass and not after it
+        _, _, launches, nslices, _ = res[0]
+        second = launches[-nslices:]
+        n_params = len(_ds2_parameters())
+        assert [k for k, _, _ in second] == list(range(nslices))
+        assert all(written <= n_params - 4 for k, written, _ in second[:-1]), second
+        assert second[-1][1] == n_params
+        first = launches[:nslices]                  # first step: nothing known yet, the first GRU layer's slice waits for the end
+        assert first[-2][1] == n_params
+
+
+def test_plan_keeps_the_last_slice_small():
+    """the slice at the front of the buffer is summed after everything else has been queued: make_plan gives it the leading parameters
+    within 1/32 of the buffer only (BASELINE model: the two convolutions), the slices tile the buffer and follow parameter bounds"""
+    from asr.parallel import Communicator
+    sizes = [n for _, n in _ds2_parameters()]
+    offs, o = [], 64
+    for n in sizes:
+        offs.append(o)
+        o += n
+    for buckets in (1, 2, 3, 4, 7, 40):
+        plan = Communicator.make_plan(offs, sizes, buckets)
+        assert plan[-1][0] == 0 and plan[0][1] == o and plan[-1][2] == 0
+        for a, c in zip(plan[:-1], plan[1:]):
+            assert a[0] == c[1] and a[2] == c[3] + 1
+        assert len(plan) <= max(1, buckets) + 1
+        if buckets > 1:
+            assert plan[-1][3] == 3 and plan[-1][1] - 64 == sum(sizes[:4])         # conv0.W, conv0.b, conv1.W, conv1.b
+    assert Communicator.make_plan([64], [10], 4) == [(0, 74, 0, 0)]
+    assert Communicator.make_plan([64, 74], [10, 10], 4) == [(74, 84, 1, 1), (0, 74, 0, 0)]
 
 
 def test_bench_starts_its_own_ranks():
