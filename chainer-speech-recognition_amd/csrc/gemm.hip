@@ -1056,6 +1056,141 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
             }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, vector operands
+// The kernel above asks for the operands of k tile kt + 1 while it works on tile kt: ONE tile in flight per workgroup, and a
+// 16-MFMA tile is over long before an L2 answer is back (the what-if build without global loads ran 0.103 instead of 0.144 ms
+// without atomics on 3072 x 512 x 32000); its general loader (element loads, edges) is a forest of ~16 scalar branches per tile,
+// behind which the compiler waits for vmcnt(0) wherever it waits at all.  This one serves the shapes the train step has (M, N, lda,
+// ldb multiples of 8, 16-B aligned bases, operands below 4 GB): buffer loads with the k offset in an SGPR -- no branch and no
+// per-lane address arithmetic; rows beyond the K split and chunks beyond M / N get an offset beyond the buffer, i.e. zeros --
+// and TWO tiles in flight: the registers of tile kt + 2 are asked for before tile kt is worked on, tile kt + 1 is waited for with
+// vmcnt(4) (gfx9 counts loads in order: the four youngest may stay out) and goes to LDS behind the MFMAs.  Same tiling, LDS image,
+// transposing reads, split-K atomics, XCD-aware order and grouped launches as gemm_tn_kernel<false>.
+__global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
+                                                             float* __restrict__ C, int ldc, int M, int N, int K, int tiles_n,
+                                                             int k_per_split, TnGroup grp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
+    uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
+    const bool grouped = grp.n > 0;
+    const int tiles = grouped ? grp.p[grp.n - 1].tile_end : ((M + BM - 1) / BM) * tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int item = xcd * (int)(gridDim.x >> 3) + slot;
+    const int round = item / tiles;
+    int bid = item - round * tiles;
+    if (grouped) {                       // uniform over the workgroup
+        int which = 0;
+        while (which + 1 < grp.n && bid >= grp.p[which].tile_end) ++which;
+        if (which > 0) bid -= grp.p[which - 1].tile_end;
+        const TnProb& q = grp.p[which];
+        A = q.A; B = q.B; C = q.C; lda = q.lda; ldb = q.ldb; ldc = q.ldc; M = q.M; N = q.N; K = q.K; tiles_n = q.tiles_n;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = round * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    if (kbeg >= kend) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // a tile is 32 k rows x 16 chunks of 16 B per operand: chunk id = tid + 256 i -> k row id / 16, chunk id % 16 (as above)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((size_t)K * lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((size_t)K * ldb * 2), 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+    unsigned oa[2], ob[2];
+    int krow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + i * 256, row = id >> 4, c = id & 15;
+        krow[i] = kbeg + row;
+        oa[i] = m0 + c * 8 < M ? (unsigned)(kbeg + row) * (unsigned)(lda * 2) + (unsigned)(m0 + c * 8) * 2u : OOB;
+        ob[i] = n0 + c * 8 < N ? (unsigned)(kbeg + row) * (unsigned)(ldb * 2) + (unsigned)(n0 + c * 8) * 2u : OOB;
+    }
+    const int sa = TK * lda * 2, sb = TK * ldb * 2;             // bytes per k tile (SGPRs)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto ask = [&](uint4 (&ra)[2], uint4 (&rb)[2], int kt) {     // the operands of k tile kt (any kt: beyond the split -> zeros)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool live = krow[i] + kt * TK < kend;
+            const u32x4_t va = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? oa[i] : OOB, kt * sa, 0);
+            const u32x4_t vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? ob[i] : OOB, kt * sb, 0);
+            ra[i] = make_uint4(va[0], va[1], va[2], va[3]);
+            rb[i] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+        }
+    };
+    auto to_lds = [&](const uint4 (&ra)[2], const uint4 (&rb)[2], int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 4, c = id & 15;
+            *reinterpret_cast<uint4*>(As + (buf * TK + row) * TP + c * 8) = ra[i];
+            *reinterpret_cast<uint4*>(Bs + (buf * TK + row) * TP + c * 8) = rb[i];
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int trow0 = 4 * g + q, trow1 = 16 + 4 * g + q, tcol = 4 * p;
+    auto work = [&](int buf) {
+        const uint16_t* Ab = As + buf * TK * TP;
+        const uint16_t* Bb = Bs + buf * TK * TP;
+        Frag a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ac = wm * 64 + i * 16 + tcol;
+            a[i].h[0] = lds_tr16(Ab + trow0 * TP + ac);
+            a[i].h[1] = lds_tr16(Ab + trow1 * TP + ac);
+            const int bc = wn * 64 + i * 16 + tcol;
+            b[i].h[0] = lds_tr16(Bb + trow0 * TP + bc);
+            b[i].h[1] = lds_tr16(Bb + trow1 * TP + bc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    const int nk2 = (nk + 1) & ~1;                 // tiles in pairs: the body below is straight-line code (an odd count works one tile of zeros)
+    uint4 ra0[2], rb0[2], ra1[2], rb1[2];          // set 0: even tiles, set 1: odd tiles
+    ask(ra0, rb0, 0);
+    ask(ra1, rb1, 1);
+    to_lds(ra0, rb0, 0);                           // (waits for tile 0 only: vmcnt(4))
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < nk2; kt += 2) {
+        // even tile kt (LDS buffer 0): tile kt + 1 is in set 1 (in flight or landed), tile kt + 2 is asked for into set 0
+        // (the scheduling barriers keep the order asked for: left alone the compiler sinks the loads behind the MFMAs -- into the
+        // fragment registers they free -- and hoists the LDS stores, with their wait, in front of them: one tile in flight again)
+        ask(ra0, rb0, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        work(0);
+        __builtin_amdgcn_sched_barrier(0);
+        to_lds(ra1, rb1, 1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // odd tile kt + 1 (LDS buffer 1): tile kt + 3 is asked for into set 1
+        ask(ra1, rb1, kt + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        work(1);
+        __builtin_amdgcn_sched_barrier(0);
+        to_lds(ra0, rb0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = n0 + wn * 64 + j * 16 + (lane & 15);
+                if (gm < M && gn < N) atomicAdd(C + (size_t)gm * ldc + gn, acc[i][j][r]);
+            }
+}
+
 // ------------------------------------------------------------------------------------------------ TN, 256 x 128 tile
 // The 128 x 128 TN kernel above stages its operands through registers (global load -> VGPR -> ds_write) and runs 16 MFMAs per
 // barrier.  This one is the NT 256 x 128 kernel's structure on k-strided operands: LDS-DMA straight into a two-stage ring (no
@@ -1404,6 +1539,15 @@ static int tn_splits(int tiles, int K, int& k_per_split, int target = 768, bool 
 // grid of the 128 x 128 TN kernel: the (split, tile) pairs in eight equal contiguous runs, one per XCD
 static int tn_grid(int tiles, int splits) { return 8 * cdiv(tiles * splits, 8); }
 
+// what gemm_tn_vec_kernel asks of a product (ASR_TN_VEC=0 keeps the general kernel: tests, comparison)
+static bool tn_vec_ok(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_TN_VEC"); on = e ? atoi(e) : 1; }
+    if (!on) return false;
+    return (M & 7) == 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
+           (unsigned long long)K * lda * 2 < 0xfffffff0ull && (unsigned long long)K * ldb * 2 < 0xfffffff0ull;
+}
+
 // the 256 x 128 LDS-DMA kernel wants whole 16-B chunks (M, lda, ldb multiples of 8, aligned bases) and at least one full tile
 // of rows; ASR_TN256=0 keeps the 128 x 128 kernel (tests, comparison)
 // Measured (tools/time_nt.py, TFLOP/s, 256 x 128 LDS-DMA kernel at two workgroups per CU against the 128 x 128 kernel at four):
@@ -1436,8 +1580,12 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
-                       (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL, TnGroup{});
+    if (tn_vec_ok(A, lda, B, ldb, M, N, K))
+        hipLaunchKernelGGL(gemm_tn_vec_kernel, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, TnGroup{});
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL, TnGroup{});
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -1448,9 +1596,11 @@ extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A,
     if (!A || !B || !C || !lda || !ldb || !ldc || !M || !N || !K || n < 1 || n > 4) return ASR_ERR_BAD_ARG;
     TnGroup grp{};
     int tiles = 0, kmax = 0;
+    bool vec = true;
     for (int i = 0; i < n; ++i) {
         if (!A[i] || !B[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || K[i] <= 0) return ASR_ERR_BAD_ARG;
         if (lda[i] < M[i] || ldb[i] < N[i] || ldc[i] < N[i]) return ASR_ERR_BAD_ARG;
+        vec = vec && tn_vec_ok(A[i], lda[i], B[i], ldb[i], M[i], N[i], K[i]);
         TnProb& q = grp.p[i];
         q.A = (const uint16_t*)A[i]; q.B = (const uint16_t*)B[i]; q.C = C[i];
         q.lda = lda[i]; q.ldb = ldb[i]; q.ldc = ldc[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
@@ -1466,8 +1616,12 @@ extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A,
     if (!target) { const char* e = getenv("ASR_TN_GROUP_TARGET"); target = e ? atoi(e) : 1152; if (target < 1) target = 1152; }
     const int splits = tn_splits(tiles, kmax, k_per_split, target, true);
     const TnProb& q = grp.p[0];
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
-                       q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, ConvDesc{}, 0LL, grp);
+    if (vec)
+        hipLaunchKernelGGL(gemm_tn_vec_kernel, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, grp);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, ConvDesc{}, 0LL, grp);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
