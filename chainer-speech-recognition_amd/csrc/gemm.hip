@@ -1066,15 +1066,20 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
 // and TWO tiles in flight: the registers of tile kt + 2 are asked for before tile kt is worked on, tile kt + 1 is waited for with
 // vmcnt(4) (gfx9 counts loads in order: the four youngest may stay out) and goes to LDS behind the MFMAs.  Same tiling, LDS image,
 // transposing reads, split-K atomics, XCD-aware order and grouped launches as gemm_tn_kernel<false>.
+// CONV: operand B is the virtual im2col matrix of the activation tensor (as in gemm_tn_kernel<true>: a thread's chunk is one tap and
+// channel group for the whole launch, its reduction rows (t, b, h) step by the k tile with single carries); positions outside the
+// tensor and empty taps take the out-of-buffer offset.
+template <bool CONV>
 __global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
                                                              float* __restrict__ C, int ldc, int M, int N, int K, int tiles_n,
-                                                             int k_per_split, TnGroup grp) {
+                                                             int k_per_split, TnGroup grp, ConvDesc cd, long long copy_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* As = reinterpret_cast<uint16_t*>(smem);             // [2][TK][TP]
     uint16_t* Bs = As + 2 * TK * TP;                              // [2][TK][TP]
-    const bool grouped = grp.n > 0;
+    const bool grouped = !CONV && grp.n > 0;
     const int tiles = grouped ? grp.p[grp.n - 1].tile_end : ((M + BM - 1) / BM) * tiles_n;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    C += (size_t)xcd * copy_stride;      // (one copy of the output per XCD: asr_conv_tn_copies)
     const int item = xcd * (int)(gridDim.x >> 3) + slot;
     const int round = item / tiles;
     int bid = item - round * tiles;
@@ -1101,25 +1106,67 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __r
 
     // a tile is 32 k rows x 16 chunks of 16 B per operand: chunk id = tid + 256 i -> k row id / 16, chunk id % 16 (as above)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((size_t)K * lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((size_t)K * ldb * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)B, 0, CONV ? (int)((size_t)cd.Ts * cd.B * cd.Hs * cd.Cs * 2) : (int)((size_t)K * ldb * 2), 0x00020000);
     constexpr unsigned OOB = 0xfffffff0u;
     unsigned oa[2], ob[2];
     int krow[2];
+    // CONV: this thread's chunk (tid & 15) never changes -> tap and channel are launch invariant; (t, b, h) of its two rows step by TK
+    int cv_dt = 0, cv_dh = 0, cv_ci = 0, cv_t[2] = {0, 0}, cv_b[2] = {0, 0}, cv_h[2] = {0, 0}, inc_h = 0, inc_b = 0, inc_t = 0;
+    bool cv_ok = false;
+    if (CONV) {
+        const int k = n0 + (tid & 15) * 8;
+        const int tap = k / cd.Cs, kh = tap / cd.KW, kw = tap - kh * cd.KW;
+        cv_ci = k - tap * cd.Cs;
+        cv_dt = kw - cd.pt;
+        cv_dh = kh - cd.ph;
+        cv_ok = k < N && kh < cd.KH;
+        inc_h = TK % cd.Hr;
+        const int inc_tb = TK / cd.Hr;
+        inc_b = inc_tb % cd.B;
+        inc_t = inc_tb / cd.B;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int id = tid + i * 256, row = id >> 4, c = id & 15;
         krow[i] = kbeg + row;
         oa[i] = m0 + c * 8 < M ? (unsigned)(kbeg + row) * (unsigned)(lda * 2) + (unsigned)(m0 + c * 8) * 2u : OOB;
         ob[i] = n0 + c * 8 < N ? (unsigned)(kbeg + row) * (unsigned)(ldb * 2) + (unsigned)(n0 + c * 8) * 2u : OOB;
+        if (CONV) {
+            const int gk = kbeg + row;
+            cv_h[i] = gk % cd.Hr;
+            const int tb = gk / cd.Hr;
+            cv_b[i] = tb % cd.B;
+            cv_t[i] = tb / cd.B;
+        }
     }
     const int sa = TK * lda * 2, sb = TK * ldb * 2;             // bytes per k tile (SGPRs)
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    auto ask = [&](uint4 (&ra)[2], uint4 (&rb)[2], int kt) {     // the operands of k tile kt (any kt: beyond the split -> zeros)
+    // the operands of k tile kt (beyond the split -> zeros).  CONV: call with kt = 0, 1, 2, ... in order, each once (the row walk)
+    auto ask = [&](uint4 (&ra)[2], uint4 (&rb)[2], int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool live = krow[i] + kt * TK < kend;
             const u32x4_t va = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? oa[i] : OOB, kt * sa, 0);
-            const u32x4_t vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? ob[i] : OOB, kt * sb, 0);
+            u32x4_t vb;
+            if (CONV) {
+                const int t = cv_t[i], b = cv_b[i], h = cv_h[i];
+                {   // advance to the same row of the next k tile
+                    int hh = h + inc_h;
+                    const int c1 = hh >= cd.Hr;
+                    hh -= c1 ? cd.Hr : 0;
+                    int bb = b + inc_b + c1;
+                    const int c2 = bb >= cd.B;
+                    bb -= c2 ? cd.B : 0;
+                    cv_h[i] = hh; cv_b[i] = bb; cv_t[i] = t + inc_t + c2;
+                }
+                const int ti = t + cv_dt, hi = h + cv_dh;
+                const bool ok = live && cv_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                const unsigned off = (unsigned)((ti * cd.B + b) * cd.Hs + hi) * (unsigned)(cd.Cs * 2) + (unsigned)cv_ci * 2u;
+                vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ok ? off : OOB, 0, 0);
+            } else {
+                vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? ob[i] : OOB, kt * sb, 0);
+            }
             ra[i] = make_uint4(va[0], va[1], va[2], va[3]);
             rb[i] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
         }
@@ -1581,8 +1628,8 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, K, k_per_split);
     if (tn_vec_ok(A, lda, B, ldb, M, N, K))
-        hipLaunchKernelGGL(gemm_tn_vec_kernel, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
-                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, TnGroup{});
+        hipLaunchKernelGGL(gemm_tn_vec_kernel<false>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, TnGroup{}, ConvDesc{}, 0LL);
     else
         hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
                            (const uint16_t*)A, lda, (const uint16_t*)B, ldb, C, ldc, M, N, K, tiles_n, k_per_split, ConvDesc{}, 0LL, TnGroup{});
@@ -1617,8 +1664,8 @@ extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A,
     const int splits = tn_splits(tiles, kmax, k_per_split, target, true);
     const TnProb& q = grp.p[0];
     if (vec)
-        hipLaunchKernelGGL(gemm_tn_vec_kernel, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
-                           q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, grp);
+        hipLaunchKernelGGL(gemm_tn_vec_kernel<false>, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, grp, ConvDesc{}, 0LL);
     else
         hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tn_grid(tiles, splits)), dim3(256), TN_LDS_BYTES, stream,
                            q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, q.tiles_n, k_per_split, ConvDesc{}, 0LL, grp);
@@ -1660,6 +1707,15 @@ extern "C" int asr_conv_tn_acc_copies(void* stream_, const void* g, int ldg, con
     const int tiles_m = cdiv(Co, BM), tiles_n = cdiv(N, BN);
     int k_per_split;
     const int splits = tn_splits(tiles_m * tiles_n, (int)K, k_per_split);
+    // (vector form: the virtual im2col chunks are whole 16-B pieces already -- Cs % 8 == 0 above; the gradient operand must be too)
+    const unsigned long long x_bytes = (unsigned long long)Ts * B * Hs * Cs * 2;
+    if (tn_vec_ok(g, ldg, x, 8, Co, N, (int)K) && x_bytes < 0xfffffff0ull) {
+        hipLaunchKernelGGL(gemm_tn_vec_kernel<true>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
+                           (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, TnGroup{}, cd,
+                           copies == 8 ? (long long)Co * ldc : 0LL);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tn_grid(tiles_m * tiles_n, splits)), dim3(256), TN_LDS_BYTES, stream,
                        (const uint16_t*)g, ldg, (const uint16_t*)x, 0, C, ldc, Co, N, (int)K, tiles_n, k_per_split, cd, copies == 8 ? (long long)Co * ldc : 0LL,
                        TnGroup{});
