@@ -713,16 +713,28 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const uint16_t* __restr
     const long long chunk = (rows + gridDim.x - 1) / gridDim.x;
     const long long r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (rl < nrl)
-        for (long long r = r0 + rl; r < r1; r += nrl) {
-            const uint4 v = *reinterpret_cast<const uint4*>(x + r * ld + c8 * 8);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    auto add = [&](const uint4& v) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xffff));
-                acc[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
-            }
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] += bf16_to_f32((uint16_t)(w[e] & 0xffff));
+            acc[2 * e + 1] += bf16_to_f32((uint16_t)(w[e] >> 16));
         }
+    };
+    if (rl < nrl) {
+        // one workgroup per CU (the atomics) means four waves per CU: eight rows in flight per thread, or the loop is one
+        // dependent load after the other (43 us for the model's 41 MB, 1.3 TB/s)
+        constexpr int RU = 8;
+        long long r = r0 + rl;
+        for (; r + (long long)(RU - 1) * nrl < r1; r += (long long)RU * nrl) {
+            uint4 v[RU];
+#pragma unroll
+            for (int q = 0; q < RU; ++q) v[q] = *reinterpret_cast<const uint4*>(x + (r + (long long)q * nrl) * ld + c8 * 8);
+#pragma unroll
+            for (int q = 0; q < RU; ++q) add(v[q]);
+        }
+        for (; r < r1; r += nrl) add(*reinterpret_cast<const uint4*>(x + r * ld + c8 * 8));
+    }
     if (rl < nrl)
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[rl * cols + c8 * 8 + e] = acc[e];
