@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __r
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool live = krow[i] + kt * TK < kend;
-            const u32x4_t va = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? oa[i] : OOB, kt * sa, 0);
+            const u32x4_t va = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, live ? oa[i] : OOB, (int)((unsigned)kt * (unsigned)sa), 0);
             u32x4_t vb;
             if (CONV) {
                 const int t = cv_t[i], b = cv_b[i], h = cv_h[i];
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __r
                 const unsigned off = (unsigned)((ti * cd.B + b) * cd.Hs + hi) * (unsigned)(cd.Cs * 2) + (unsigned)cv_ci * 2u;
                 vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ok ? off : OOB, 0, 0);
             } else {
-                vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? ob[i] : OOB, kt * sb, 0);
+                vb = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, live ? ob[i] : OOB, (int)((unsigned)kt * (unsigned)sb), 0);
             }
             ra[i] = make_uint4(va[0], va[1], va[2], va[3]);
             rb[i] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
