@@ -103,6 +103,24 @@ def test_gemm_tn_strided_views(device):
     assert _rel(c.cpu(), ref) < 1e-5
 
 
+def test_gemm_tn_operand_beyond_2_gb(device):
+    """the vector TN kernel addresses its operands with 32-bit byte offsets (buffer loads, the k offset in an SGPR): an operand whose
+    rows lie 64 KB apart reaches byte 2.6 G at K = 40000 -- every offset beyond 2^31 must still be the right one"""
+    from asr import _ops
+    g = torch.Generator(device=device).manual_seed(5)
+    K, M, N, ld = 40000, 128, 64, 32768
+    big = torch.randn(K, ld, generator=g, device=device, dtype=F32).to(BF16)
+    a = big[:, 256:256 + M]
+    b = torch.randn(K, N, generator=g, device=device, dtype=F32).to(BF16)
+    c = torch.zeros(M, N, device=device)
+    _ops.gemm_tn_acc(a, b, c)
+    ref = a.double().T @ b.double()
+    assert _rel(c.cpu(), ref.cpu()) < 1e-5
+    last = torch.zeros(M, N, device=device)                  # the last k rows alone (offsets ~2.6 G): a wrapped offset reads other rows
+    _ops.gemm_tn_acc(a[K - 100:], b[K - 100:], last)
+    assert _rel(last.cpu(), (a[K - 100:].double().T @ b[K - 100:].double()).cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("K,M,N,I,B", [(96, 40, 24, 16, 8), (2016, 1536, 512, 384, 32), (700, 130, 70, 264, 4)])
 def test_gemm_tn_acc_group(device, K, M, N, I, B):
     """the grouped launch against float64 on the three products the GRU backward hands it: (K, 2M)^T (K, I), and per direction
