@@ -668,6 +668,23 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     assert _rel(gW.cpu(), gW_ref.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,H,T", [(3, 3, 40, 130), (2, 1, 13, 64), (2, 8, 9, 65), (32, 3, 40, 1000)])
+def test_pack_input_pad_layouts(device, B, C, H, T):
+    """(T, B, H, 8) bf16 rows with zero channels behind C, from the loader's (B, C, H, T) float32 (time innermost: the LDS-tile kernel)
+    and from a time-outermost copy of it (the general gather): both must equal the rounded source exactly"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(B, C, H, T, generator=g)
+    want = torch.zeros(T, B, H, 8)
+    want[..., :C] = x.permute(3, 0, 2, 1).to(BF16).float()
+    xd = x.to(device)
+    got = _ops.pack_input_pad(xd, (xd.stride(3), xd.stride(0), xd.stride(2), xd.stride(1)), T, B, H, C, 8)
+    assert xd.stride(3) == 1 and torch.equal(got.float().cpu().reshape(T, B, H, 8), want)
+    xt = xd.permute(3, 0, 2, 1).contiguous()                  # (T, B, H, C): channels innermost
+    got2 = _ops.pack_input_pad(xt, (xt.stride(0), xt.stride(1), xt.stride(2), xt.stride(3)), T, B, H, C, 8)
+    assert torch.equal(got2.float().cpu().reshape(T, B, H, 8), want)
+
+
 def test_first_layer_weight_gradient_with_padded_channels(device):
     """first conv layer: 3 input channels zero-padded to 8 for the implicit kernels; the weight gradient comes back
     through a scratch with channel pitch 8 (asr_conv_weight_grad_unpack Cs = 8) and must equal the float64 correlation"""
