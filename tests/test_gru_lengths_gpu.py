@@ -17,8 +17,10 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-def _layer_and_reference(device, T, B, I, H, ndir, seed, x_len, ps_units=None):
-    """one (Bi)GRU link on a random padded batch through autograd on the device; returns device results and the two oracles'."""
+def _layer_and_reference(device, T, B, I, H, ndir, seed, x_len, ps_units=None, f32_rows=None):
+    """one (Bi)GRU link on a random padded batch through autograd on the device; returns device results and the two oracles'.
+    f32_rows: run the float32 pack_padded_sequence reference on these utterances only (torch's packed GRU backward takes a minute at
+    BASELINE size); it then returns y and dx of those rows -- utterances do not interact inside a GRU."""
     from asr import nn, _ops
     from asr import functions as F
     g = torch.Generator().manual_seed(seed)
@@ -46,6 +48,13 @@ def _layer_and_reference(device, T, B, I, H, ndir, seed, x_len, ps_units=None):
     for matched in (False, True):
         p = {n: Q.rnd(v).clone().requires_grad_(True) if (n.startswith("w") and not matched) else v.clone().requires_grad_(True)
              for n, v in P.items()}
+        if not matched and f32_rows is not None:
+            rows = torch.as_tensor(f32_rows, dtype=torch.long)
+            xr = x[:, rows].clone().requires_grad_(True)
+            yr = Q.gru(xr, p["w_ih"], p["w_hh"], p["b_ih"], p["b_hh"], x_len[rows], False, gi_bf16, ps_units, False)
+            yr.backward(gy[:, rows])
+            refs.append(dict(y=yr.detach(), dx=xr.grad))
+            continue
         xr = x.clone().requires_grad_(True)
         yr = Q.gru(xr, p["w_ih"], p["w_hh"], p["b_ih"], p["b_hh"], x_len, matched, gi_bf16, ps_units, _ops.gru_gates_f16(T, B, H, ndir))
         yr.backward(gy)
@@ -110,18 +119,22 @@ def test_lengths_equal_truncated_utterances(device):
 
 
 def test_full_size_ragged_batch(device):
-    """SURVEY 8d's ragged variant at BASELINE size: T=1000, B=32, H=512, lengths U{600..1000}, default kernels, against
-    pack_padded_sequence in float32 and the rounding-matched oracle (relative L2)."""
+    """SURVEY 8d's ragged variant at BASELINE size: T=1000, B=32, H=512, lengths U{600..1000}, default kernels, against the
+    rounding-matched oracle (every output and gradient) and pack_padded_sequence in float32 (y and dx of eight utterances; the weight
+    gradients against float32 are covered at the smaller shapes above and, without lengths, by test_gru_full_size_against_fp32_oracle)."""
     T, B, I, H = 1000, 32, 384, 512
     g = torch.Generator().manual_seed(11)
     x_len = torch.randint(600, 1001, (B,), generator=g, dtype=torch.int32)
-    got, f32, matched = _layer_and_reference(device, T, B, I, H, 2, seed=3, x_len=x_len)
-    e32 = {n: _rel(got[n], f32[n]) for n in got}
+    # float32 reference: the shortest and the longest utterance and six more (y and dx of those rows); the rounding-matched oracle: everything
+    order = torch.argsort(x_len)
+    rows = sorted({int(order[0]), int(order[-1])} | {int(i) for i in order[2:-2:5][:6]})
+    got, f32, matched = _layer_and_reference(device, T, B, I, H, 2, seed=3, x_len=x_len, f32_rows=rows)
+    e32 = {n: _rel(got[n][:, rows], f32[n]) for n in f32}
     em = {n: _rel(got[n], matched[n]) for n in got}
     print("ragged full-size BiGRU: vs float32 pack_padded_sequence", {k: "%.2e" % v for k, v in e32.items()})
     print("ragged full-size BiGRU: vs rounding-matched oracle     ", {k: "%.2e" % v for k, v in em.items()})
     for n in got:
-        assert e32[n] < 1.2e-2, (n, e32[n])
+        assert n not in e32 or e32[n] < 1.2e-2, (n, e32[n])
         assert em[n] < 3e-3, (n, em[n])
 
 

@@ -437,6 +437,9 @@ def test_gru_full_size_against_fp32_oracle(device):
         assert errs[k] < 1.25 * errs32[k] + 2e-4, (k, errs[k], errs32[k])       # half gates cost (next to) nothing in accuracy
 
 
+_GRU_REF = {}
+
+
 def _gru_case(device, T, B, I, H, ndir, tol=None, gi_dtype=F32):
     from asr import _ops
     tol = tol or dict(y=6e-3, dx=2e-2, dwih=2e-2, dbih=2e-2, dbhh=2e-2, dwhh=2e-2)
@@ -445,17 +448,24 @@ def _gru_case(device, T, B, I, H, ndir, tol=None, gi_dtype=F32):
     def gate(name, a, b):
         errs[name] = max(errs.get(name, 0.0), _rel(a, b))
         assert errs[name] < tol[name], (name, errs[name], tol[name])
-    g = torch.Generator().manual_seed(T * H)
-    k = 1.0 / np.sqrt(H)
-    P = dict(w_ih=_bf(torch.empty(ndir, 3 * H, I).uniform_(-k, k, generator=g)),
-             w_hh=_bf(torch.empty(ndir, 3 * H, H).uniform_(-k, k, generator=g)),
-             b_ih=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g),
-             b_hh=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g))
-    x = _bf(torch.randn(T, B, I, generator=g))
-    xr = x.clone().requires_grad_(True)
-    y_ref, ref = onn.bigru_sum(xr, P, H, ndir)
-    gy = _bf(torch.randn(T, B, H, generator=g))
-    y_ref.backward(gy)
+    key = (T, B, I, H, ndir)
+    if key not in _GRU_REF:           # (the float32 CPU reference of a shape is the same for every device variant tested on it)
+        g = torch.Generator().manual_seed(T * H)
+        k = 1.0 / np.sqrt(H)
+        P = dict(w_ih=_bf(torch.empty(ndir, 3 * H, I).uniform_(-k, k, generator=g)),
+                 w_hh=_bf(torch.empty(ndir, 3 * H, H).uniform_(-k, k, generator=g)),
+                 b_ih=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g),
+                 b_hh=torch.empty(ndir, 3 * H).uniform_(-k, k, generator=g))
+        x = _bf(torch.randn(T, B, I, generator=g))
+        xr = x.clone().requires_grad_(True)
+        y_ref, ref = onn.bigru_sum(xr, P, H, ndir)
+        gy = _bf(torch.randn(T, B, H, generator=g))
+        y_ref.backward(gy)
+        if T * B * H >= 1 << 22:      # keep only what is expensive to make
+            _GRU_REF.clear()
+            _GRU_REF[key] = (P, x, xr, y_ref, ref, gy)
+    if key in _GRU_REF:
+        P, x, xr, y_ref, ref, gy = _GRU_REF[key]
     xd = x.reshape(T * B, I).to(device, BF16)
     wih = P["w_ih"].reshape(ndir * 3 * H, I).to(device, BF16)
     gi = _ops.gemm_nt(xd, wih, P["b_ih"].reshape(-1).to(device), gi_dtype)
