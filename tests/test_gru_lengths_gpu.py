@@ -138,7 +138,7 @@ def test_full_size_ragged_batch(device):
         assert em[n] < 3e-3, (n, em[n])
 
 
-@pytest.mark.parametrize("B,T,H", [(4, 60, 128), (3, 41, 64)])
+@pytest.mark.parametrize("B,T,H", [(4, 60, 128), (3, 41, 64), (6, 150, 512)])
 def test_model_with_lengths_matches_the_oracle(device, B, T, H):
     """ds2.Model(x, x_length=...) + CTC + backward against the oracles run with the same lengths"""
     from asr import _ops
@@ -167,9 +167,15 @@ def test_model_with_lengths_matches_the_oracle(device, B, T, H):
     _ops.gru_check_sync()
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2) == BF16
-    for matched, tol in ((False, 0.2), (True, 5e-3)):
-        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=True,
-                               gates_f16=_ops.gru_gates_f16(T, B, H, 2))
+    # the default backward kernel at H % 128 == 0 exchanges per-producer partial sums rounded to bf16 (32 units per producer)
+    ps_units = 32 if (H % 128 == 0 and 2 * ((B + 3) // 4) <= 16 and B <= 32) else None
+    # end to end the matched oracle and the device drift apart with width and length (float32 summation order and the fast exp / rcp of
+    # 150 x 512-wide recurrence steps feed back through two layers: tests/test_model_gpu.py, MATCHED_GRAD_DEEP); layer by layer the same
+    # shape agrees to 1e-3 (test_gru_runs_every_utterance_over_its_own_length and tools/debug/ragged_b6.py)
+    tight = 5e-3 if H < 512 else 2e-2
+    for matched, tol in ((False, 0.2), (True, tight)):
+        ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, ps_units=ps_units,
+                               fused_logit_bias=True, gates_f16=_ops.gru_gates_f16(T, B, H, 2))
         loss_ref = omodel.ctc_mean_loss(ref(x, x_len), labels, x_len, l_len)
         loss_ref.backward()
         assert abs(loss.item() - loss_ref.item()) <= (2e-2 if not matched else 1e-3) * abs(loss_ref.item()), (matched, loss.item(), loss_ref.item())

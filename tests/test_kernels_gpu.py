@@ -103,6 +103,27 @@ def test_gemm_tn_strided_views(device):
     assert _rel(c.cpu(), ref) < 1e-5
 
 
+def test_gemm_tn_group_at_model_size(device):
+    """the three weight-gradient products a BASELINE GRU layer releases together (3072 x 512 and twice 1536 x 512 over K = 32000
+    rows, on the shifted strided views of _GRU.backward) in one grouped launch, against float32 products of the same operands on
+    the device, with and without the vector kernel's fast path being possible (an odd leading dimension forces the general kernel)"""
+    from asr import _ops
+    g = torch.Generator(device=device).manual_seed(9)
+    T, B, H, I = 1000, 32, 512, 512
+    K = T * B
+    for pad in (0, 1):                                           # pad = 1: lda / ldb not multiples of 8 -> general kernel
+        dgi = torch.randn(K, 6 * H + pad, generator=g, device=device).to(BF16)[:, :6 * H]
+        dgh = torch.randn(K, 6 * H + pad, generator=g, device=device).to(BF16)[:, :6 * H]
+        x = torch.randn(K, I + pad, generator=g, device=device).to(BF16)[:, :I]
+        h = torch.randn(K, 2 * H + pad, generator=g, device=device).to(BF16)[:, :2 * H]
+        c = [torch.zeros(6 * H, I, device=device), torch.zeros(3 * H, H, device=device), torch.zeros(3 * H, H, device=device)]
+        prods = [(dgi, x, c[0]), (dgh[B:, :3 * H], h[:-B, :H], c[1]), (dgh[:-B, 3 * H:], h[B:, H:], c[2])]
+        _ops.gemm_tn_acc_group(prods)
+        for (a, b, got) in prods:
+            ref = a.float().T @ b.float()
+            assert _rel(got.cpu(), ref.cpu()) < 2e-5, pad
+
+
 def test_gemm_tn_operand_beyond_2_gb(device):
     """the vector TN kernel addresses its operands with 32-bit byte offsets (buffer loads, the k offset in an SGPR): an operand whose
     rows lie 64 KB apart reaches byte 2.6 G at K = 40000 -- every offset beyond 2^31 must still be the right one"""
