@@ -408,7 +408,7 @@ class _Conv2D(torch.autograd.Function):
             return gp.permute(1, 3, 2, 0)
 
         if w_is_param:      # the side stream forks BEFORE the input-gradient product is queued: beside it, not behind it
-            with _OnSide(g2, col):
+            with _OnSide(g2, col, gy_auto):     # (gy_auto: read by the bias column sum of a second autograd consumer, as in _Dense)
                 weight_grads()
             gx = input_grad()
             grads_queued(W, b)

@@ -382,8 +382,6 @@ class _Writer(object):
         heap_addr = self.alloc(b"HEAP" + struct.pack("<B3xQQQ", 0, len(seg), free_at, seg_addr))
         # symbol-table nodes of at most 2 * LEAF_K entries, each allocated at its full size
         nodes = [names[i:i + 2 * LEAF_K] for i in range(0, len(names), 2 * LEAF_K)] or [[]]
-        if len(nodes) > 2 * INTERNAL_K:
-            raise Hdf5Error("more than %d links in one group" % (4 * LEAF_K * INTERNAL_K))
         snods = []
         for part in nodes:
             body = b"SNOD" + struct.pack("<BxH", 1, len(part))
@@ -391,13 +389,33 @@ class _Writer(object):
                 body += struct.pack("<QQII16x", offs[name], children[name], 0, 0)
             body += b"\0" * (8 + 40 * 2 * LEAF_K - len(body))
             snods.append(self.alloc(body))
-        # one leaf-level B-tree node: key 0 = the empty string, key i + 1 = the largest name of child i
-        node = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(snods) if names else 0, UNDEF, UNDEF) + struct.pack("<Q", 0)
-        for part, addr in zip(nodes, snods):
-            if part:
-                node += struct.pack("<QQ", addr, offs[part[-1]])
-        node += b"\0" * (24 + 8 * (2 * INTERNAL_K + 1) + 8 * 2 * INTERNAL_K - len(node))
-        btree_addr = self.alloc(node)
+        # version-1 B-tree over the symbol-table nodes: key 0 = the empty string, key i + 1 = the largest name below child i.  A node
+        # takes 2 * INTERNAL_K children; more than that (Chainer's flattened `_module_*_link_*` names all land in the owner's group,
+        # so a deep recipe can pass 2 * LEAF_K * 2 * INTERNAL_K = 256 links) adds levels, nodes of one level chained by their sibling
+        # addresses as the library writes them
+        level, below = 0, [(addr, offs[part[-1]]) for part, addr in zip(nodes, snods) if part]
+        while True:
+            runs = [below[i:i + 2 * INTERNAL_K] for i in range(0, len(below), 2 * INTERNAL_K)] or [[]]
+            addrs = []
+            for run in runs:
+                node = b"TREE" + struct.pack("<BBHQQ", 0, level, len(run), UNDEF, UNDEF) + struct.pack("<Q", 0)
+                for child, last in run:
+                    node += struct.pack("<QQ", child, last)
+                node += b"\0" * (24 + 8 * (2 * INTERNAL_K + 1) + 8 * 2 * INTERNAL_K - len(node))
+                addrs.append(self.alloc(node))
+            for i, a in enumerate(addrs):           # left / right sibling
+                if i > 0:
+                    self.buf[a + 8:a + 16] = struct.pack("<Q", addrs[i - 1])
+                if i + 1 < len(addrs):
+                    self.buf[a + 16:a + 24] = struct.pack("<Q", addrs[i + 1])
+            # (key 0 of a node that is not the leftmost of its level = the largest name to its left, as the library keeps it)
+            for i in range(1, len(addrs)):
+                self.buf[addrs[i] + 24:addrs[i] + 32] = struct.pack("<Q", runs[i - 1][-1][1])
+            if len(addrs) == 1:
+                btree_addr = addrs[0]
+                break
+            below = [(a, run[-1][1]) for a, run in zip(addrs, runs)]
+            level += 1
         header = self.alloc(_object_header([_message(MSG_SYMBOL_TABLE, struct.pack("<QQ", btree_addr, heap_addr))]))
         return header, btree_addr, heap_addr
 

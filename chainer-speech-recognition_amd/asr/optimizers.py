@@ -42,7 +42,8 @@ class Optimizer(object):
         self.communicator = None
         self.pipeline = None
         self._needs_broadcast = False
-        self._gave_up = [None, None]        # pinned host copy of ctl[5] of the previous step, event of that copy
+        self._gave_up = [None, None]        # pinned host copy of ctl[6] (give-up drops so far), event of that copy
+        self._gave_up_reported = 0.0
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -92,10 +93,6 @@ class Optimizer(object):
         if self.communicator is not None:
             self.communicator.finish_backward(self)
             scale = 1.0 / self.communicator.size
-        # the host learns of a given-up recurrence one step late and without synchronising -- on EVERY rank at the same step (ctl[5]
-        # derives from the reduced reserved element), and only after this step's collectives have been queued / joined: a rank that
-        # raised before finish_backward would leave its peers waiting in an all-reduce
-        self._raise_if_previous_step_gave_up()
         self.t += 1                         # steps ATTEMPTED; the device counts the applied ones (flat["applied"])
         clip, decay = 0.0, 0.0
         for h in self._hooks:
@@ -113,26 +110,36 @@ class Optimizer(object):
         self._watch_gave_up()
         bump_weight_epoch()
         refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
+        # The host learns of a given-up recurrence some steps late and without synchronising (a non-blocking query of an asynchronous
+        # copy of ctl[5]).  WHICH updates are applied is decided on the device alone and identically on every rank: the abort word
+        # is sticky, every step's gather_abort plants the NaN in front of the reduction, step_control drops the step from the REDUCED
+        # element -- until the raising rank clears its word.  The report therefore comes LAST, behind this step's collectives (a rank
+        # raising before finish_backward would leave its peers in an all-reduce) and behind this step's update kernels: a
+        # free-running loop in which the ranks' hosts run ahead of their devices by different amounts raises at different updates on
+        # different ranks, and none of them may skip queueing an update its peers apply.
+        self._raise_if_previous_step_gave_up()
 
     def _watch_gave_up(self):
+        """asynchronous copy of ctl[6] (steps dropped because a recurrence gave up, ever) whenever the previous copy has landed"""
         st = self._gave_up
         if st[0] is None:
             st[0] = torch.zeros(1, dtype=F32).pin_memory()
         if st[1] is None or st[1].query():
-            st[0].copy_(self._flat["ctl"][5:6], non_blocking=True)
+            st[0].copy_(self._flat["ctl"][6:7], non_blocking=True)
             st[1] = torch.cuda.Event()
             st[1].record()
 
     def _raise_if_previous_step_gave_up(self):
         st = self._gave_up
-        if st[1] is not None and st[1].query() and float(st[0][0]) != 0.0:
-            st[0][0] = 0.0
+        if st[1] is not None and st[1].query() and float(st[0][0]) > self._gave_up_reported:
+            self._gave_up_reported = float(st[0][0])
             st[1] = None
             _ops.clear_abort_words(self._flat["G"].device)       # sticky until somebody has been told: now
             _ops.reset_poll_status()
             from ._lib import AsrHipError
-            raise AsrHipError("a persistent GRU kernel gave up an in-launch wait during the previous step (on this rank or on a "
-                              "data-parallel peer): that step was dropped on every rank, parameters and optimiser state are intact")
+            raise AsrHipError("a persistent GRU kernel gave up an in-launch wait during an earlier step (on this rank or on a "
+                              "data-parallel peer): %d step(s) so far were dropped for that reason, on every rank alike; parameters "
+                              "and optimiser state are intact; training may continue" % int(self._gave_up_reported))
 
     def applied_steps(self):
         """number of update steps that were not dropped on the device (synchronises: tests / logging only)"""
@@ -175,7 +182,7 @@ class Optimizer(object):
         applied = old["applied"] if old is not None and old["applied"].device == dev else torch.zeros(1, dtype=torch.int32, device=dev)
         self._flat = dict(P=P, G=G, ids=[id(p) for p in params], ptrs=[p.data_ptr() for p in params], offsets=offs,
                           sizes=sizes, numels=[p.numel() for p in params], applied=applied,
-                          ctl=torch.zeros(8, dtype=F32, device=dev),
+                          ctl=(old["ctl"] if old is not None and old["ctl"].device == dev else torch.zeros(8, dtype=F32, device=dev)),
                           partials=torch.empty(_ops.sqnorm_partials_count(total), dtype=F32, device=dev))
         self._flat["sq"] = self._flat["ctl"][4:5]       # squared norm of the (summed) gradient of the last step
         self._init_state(total, dev, old)

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 //   ctl[3] = t
 //   ctl[4] = the squared gradient norm (sum of the per-workgroup partial sums in a FIXED order: every data-parallel rank
 //            derives bit-identical clipping factors from bit-identical reduced gradients -- float atomics would not)
+//   ctl[5] = 1 when this step was dropped because a recurrence gave up (here or on a data-parallel peer), ctl[6] = how many steps
+//            ever were (the caller zeroes ctl once; the host compares with the count it last reported)
 __global__ __launch_bounds__(256) void sqnorm_partials_kernel(const float* __restrict__ g, long long n, float* __restrict__ partials) {
     __shared__ float scratch[32];
     float s = 0.f;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
     ctl[2] = (float)((double)alpha * sqrt(fix2) / fix1);
     ctl[3] = (float)t;
     ctl[5] = gave_up ? 1.f : 0.f;
+    if (gave_up) ctl[6] += 1.f;         // steps dropped because a recurrence gave up, ever: a host that looks late still sees them
 }
 
 __global__ __launch_bounds__(256) void adam_ctl_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

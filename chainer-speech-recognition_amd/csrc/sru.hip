@@ -192,13 +192,15 @@ __global__ __launch_bounds__(SX * SY) void bwd_summary_kernel(const float* __res
     const float* u = U + ((size_t)(t1 - 1) * B + cl.b) * 3 * D + cl.d;
     size_t row = (size_t)(t1 - 1) * xs + col;
     float2 P = make_float2(1.f, 1.f), S = make_float2(0.f, 0.f);
-    const uint16_t* ghp = gH ? gH : reinterpret_cast<const uint16_t*>(C);      // (a missing gH: any valid row, scaled by 0 -- no branch in the loop)
-    const float ghs = gH ? 1.f : 0.f;
+    // a missing gH (set_materialize_grads(False): only cT received a gradient): the load stays unconditional (any valid row; no branch in
+    // the loop) and the VALUE is selected afterwards -- scaling by 0 would turn the Inf / NaN bit patterns those bytes may hold into NaN
+    const uint16_t* ghp = gH ? gH : reinterpret_cast<const uint16_t*>(C);
+    const bool has_gh = gH != nullptr;
 #pragma unroll 4
     for (int t = t1 - 1; t >= t0; --t, u -= us, row -= xs) {
         const float2 fp = ld2(u + D), rp = ld2(u + 2 * D), c = ld2(C + row);
         float2 gh = bf2(ghp + row);
-        gh.x *= ghs; gh.y *= ghs;
+        gh = has_gh ? gh : make_float2(0.f, 0.f);           // v_cndmask on a kernel-uniform predicate
         const float fx = fsig(fp.x + bf.x), fy = fsig(fp.y + bf.y);
         const float rx = fsig(rp.x + br.x), ry = fsig(rp.y + br.y);
         const float gx = TANH ? ftanh(c.x) : c.x, gy = TANH ? ftanh(c.y) : c.y;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(SX * SY) void bwd_apply_kernel(const uint16_t* __re
         // vmcnt(0) -- every step then waited for the loads it had just issued (the unrolled steps' loads no longer overlapped).  The
         // t == 0 state and a missing gH are selected AFTER an always-valid load (clamped address / the x row).
         const uint16_t* ghp = gH ? gH : x;
-        const float ghs = gH ? 1.f : 0.f;
+        const bool has_gh = gH != nullptr;
         // software pipeline: the operands of step t - 1 are asked for before step t is worked on (the last step asks for its own row
         // again: always a valid address), so that a lane has two steps of loads in flight across the transcendental chain of a step
         struct In { float2 z, fp, rp, cp; uint32_t xw, gw; };
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(SX * SY) void bwd_apply_kernel(const uint16_t* __re
             const float2 z = cur.z, fp = cur.fp, rp = cur.rp;
             const float2 xr = make_float2(__uint_as_float(cur.xw << 16), __uint_as_float(cur.xw & 0xffff0000u));
             float2 gh = make_float2(__uint_as_float(cur.gw << 16), __uint_as_float(cur.gw & 0xffff0000u));
-            gh.x *= ghs; gh.y *= ghs;
+            gh = has_gh ? gh : make_float2(0.f, 0.f);       // selected, never scaled: x may hold Inf / NaN patterns (0 * Inf = NaN)
             float2 cp = cur.cp;
             if (t == 0) cp = cinit;
             const float fx = fsig(fp.x + bf.x), fy = fsig(fp.y + bf.y);

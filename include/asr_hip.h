@@ -370,7 +370,7 @@ int asr_clip_decay_sgd(void* stream, float* p, const float* g, float* v, long lo
  * another data-parallel rank: reserved_index >= 0 names an element of g that belongs to no parameter; asr_gather_abort ORs any
  * number of abort words (device array of n device addresses) into *any_word and, when one is raised, plants a NaN in *poison
  * (that element of the LOCAL gradient buffer, before it is summed over the ranks), so every rank drops the same step and every
- * rank can tell why. */
+ * rank can tell why; ctl[6] (zeroed once by the caller) counts such steps, so a host that reads ctl late misses none. */
 int asr_sqnorm_partials_count(long long n);
 int asr_gather_abort(void* stream, const long long* word_ptrs, int n, int* any_word, float* poison);
 int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,

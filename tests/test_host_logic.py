@@ -368,6 +368,39 @@ def test_hdf5_container_round_trip(tmp_path, compression, shuffle):
         assert np.array_equal(back[k], v), k
 
 
+def test_hdf5_group_with_more_links_than_one_btree_node_takes(tmp_path):
+    """Chainer's flattened `_module_*_link_*` names all land in the owner's group; past 2 LEAF_K x 2 INTERNAL_K = 256 links
+    a single leaf B-tree node no longer holds the symbol-table nodes.  The writer adds levels: 700 links = 88 symbol-table nodes = 3
+    leaf nodes (chained by sibling addresses, keys ascending) under one level-1 root; everything reads back, in name order."""
+    import struct
+    import numpy as np
+    from asr import hdf5_lite
+    table = {"g/_module_%03d_link_%d" % (i // 2, i % 2): np.full((2,), i, np.float32) for i in range(700)}
+    table["top"] = np.arange(3, dtype=np.int32)
+    raw = hdf5_lite.dumps(table)
+    path = str(tmp_path / "many.hdf5")
+    open(path, "wb").write(raw)
+    back = hdf5_lite.read(path)
+    assert list(back) == sorted(table, key=lambda s: [c.encode("utf-8") for c in s.split("/")])
+    for k, v in table.items():
+        assert np.array_equal(back[k], v), k
+    # structure: the group's root node is at level 1 with 3 children; the leaves are chained left to right
+    rd = hdf5_lite._Reader(raw)
+    trees = [i for i in range(0, len(raw) - 4, 8) if raw[i:i + 4] == b"TREE" and raw[i + 4] == 0]
+    roots = [i for i in trees if raw[i + 5] == 1]
+    assert len(roots) == 1 and struct.unpack_from("<H", raw, roots[0] + 6)[0] == 3
+    leaves = [struct.unpack_from("<Q", raw, roots[0] + 24 + 8 + 16 * i)[0] for i in range(3)]
+    undef = 0xFFFFFFFFFFFFFFFF
+    assert [struct.unpack_from("<QQ", raw, a + 8) for a in leaves] == [(undef, leaves[1]), (leaves[0], leaves[2]), (leaves[1], undef)]
+    assert [struct.unpack_from("<H", raw, a + 6)[0] for a in leaves] == [32, 32, 24]
+    try:
+        import h5py
+    except ImportError:
+        return
+    with h5py.File(path, "r") as f:
+        assert len(f["g"]) == 700 and np.array_equal(np.asarray(f["g/_module_349_link_1"]), table["g/_module_349_link_1"])
+
+
 def test_hdf5_reader_on_a_file_written_by_the_hdf5_library():
     """an independent producer: SciPy ships a MATLAB v7.3 file, i.e. HDF5 written by the HDF5 library itself (superblock behind a
     512-byte user block, version-1 object headers, local heap, B-tree, symbol-table node, old-style data layout message):

@@ -481,6 +481,44 @@ def test_sru_chunked_scans_equal_the_column_scans(device, T, Bn, D, use_tanh, ma
         assert _rel(a, b) < tol, (name, _rel(a, b))
 
 
+@pytest.mark.parametrize("T,Bn,D,use_tanh", [(96, 4, 64, True), (40, 3, 128, False), (300, 2, 64, True)])
+def test_sru_gradient_through_the_last_cell_state_only(device, T, Bn, D, use_tanh):
+    """SRUFunction sets set_materialize_grads(False) (as the reference does, asr/nn/sru.py:372-376 treats a missing gH as zeros): a loss
+    that reads only c_T hands the backward kernels gH = None.  The chunked scans then load a stand-in row (float32 cell states / x read as
+    bf16 pairs) whose bit patterns include Inf and NaN -- the value must be SELECTED to zero, not scaled by it (0 * Inf = NaN spreads into
+    every earlier chunk, gU, gc0 and the bias gradient; about 1 in 256 low halves of a float32 is such a pattern, so every shape here has
+    dozens).  chunked == column scans == float64 oracle with gH = 0."""
+    from asr import _ops
+    from asr.nn.sru import sru
+    from asr.link import Parameter
+    torch.manual_seed(3 * T + D)
+    X = _bf(torch.randn(Bn, D, T))
+    W = _bf(torch.randn(3 * D, D) * (0.6 / np.sqrt(D)))
+    Bias = torch.randn(2 * D) * 0.3
+    c0 = torch.randn(Bn, D)
+    gcT = torch.randn(Bn, D)
+    res = []
+    for chunked in (True, False):
+        _ops.SRU_CHUNKED[0] = chunked
+        try:
+            Xd = X.to(device).requires_grad_(True)
+            Wp, Bp = Parameter(W.to(device)), Parameter(Bias.to(device))
+            c0d = c0.to(device).requires_grad_(True)
+            H, C, cT = sru(Xd, Wp, Bp, c0d, use_tanh)
+            (cT * gcT.to(device)).sum().backward()
+            torch.cuda.synchronize()
+            res.append([t.detach().float().cpu() for t in (Xd.grad, Wp.grad, Bp.grad, c0d.grad)])
+        finally:
+            _ops.SRU_CHUNKED[0] = True
+    for name, a, b in zip(("gX", "gW", "gB", "gc0"), *res):
+        assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all()), name
+        assert _rel(a, b) < 4e-3, (name, _rel(a, b))
+    args = (X.double().numpy(), W.double().numpy(), Bias.double().numpy(), c0.double().numpy())
+    gX, gW, gb, gc = onn.sru_bwd(*args, np.zeros((Bn, D, T)), gcT.double().numpy(), use_tanh)
+    for name, a, r in zip(("gX", "gW", "gB", "gc0"), res[0], (gX, gW, gb, gc)):
+        assert _rel(a, r) < 1e-2, (name, _rel(a, r))
+
+
 @pytest.mark.parametrize("use_tanh", [True, False])
 def test_sru_full_size_against_the_oracle(device, use_tanh):
     """T=1000, B=32, D=512 (the size tools/time_sru.py measures): H, C, c_T and every gradient against oracle.nn.sru_fwd / sru_bwd

@@ -230,6 +230,29 @@ _ops._sync_buffer(dev, 8192)
 def step():
     loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
     opt.update(lossfun=lambda: loss)
+if len(sys.argv) > 2 and sys.argv[2] == "free":
+    # ADVICE r3: a free-running loop -- no synchronisation between steps, the two hosts look at their asynchronous copies at different
+    # times (rank 0 does not look at all during three updates, as a host far ahead of its device would not).  Whichever update a rank
+    # raises at, it must have queued exactly the updates its peer queued: parameters, Adam state and the applied count stay identical.
+    import time
+    raised_at, check = [], opt._raise_if_previous_step_gave_up
+    for i in range(14):
+        if i == 3 and rank == 1:
+            list(_ops._SYNC.values())[0][1023:1024].fill_(1)
+        opt._raise_if_previous_step_gave_up = (lambda: None) if (rank == 0 and 4 <= i <= 6) else check
+        if rank == 1 and i % 3 == 0:
+            time.sleep(0.01)
+        try:
+            step()
+        except _lib.AsrHipError:
+            raised_at.append(i)
+    torch.cuda.synchronize()
+    torch.save({"raised_at": raised_at, "applied": opt.applied_steps(), "end": opt.flat_parameters().detach().cpu(),
+                "dropped": float(opt._flat["ctl"][6].item()), "hooks_clear": link._GRAD_LISTENER[0] is None and _ops.RECURRENCE_HOOKS["before"] is None},
+               out_path)
+    comm.barrier()
+    torch.distributed.destroy_process_group()
+    sys.exit(0)
 events = []
 step(); torch.cuda.synchronize()
 events.append(("applied", opt.applied_steps()))
@@ -256,20 +279,41 @@ torch.distributed.destroy_process_group()
 '''
 
 
-def test_a_given_up_recurrence_on_one_rank_drops_the_step_on_every_rank(tmp_path):
+def _run_abort_script(tmp_path, port, *extra):
     import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs, outs = [], []
     for r in range(2):
         out = str(tmp_path / ("abort_r%d.pt" % r))
-        env = dict(os.environ, ASR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")
-        procs.append(subprocess.Popen([sys.executable, "-c", ABORT_SCRIPT, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                      text=True))
+        env = dict(os.environ, ASR_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", ABORT_SCRIPT, out] + list(extra), env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
         outs.append(out)
     for p in procs:
         so, se = p.communicate(timeout=600)
         assert p.returncode == 0, se[-3000:]
-    res = [torch.load(o) for o in outs]
+    return [torch.load(o) for o in outs]
+
+
+def test_ranks_that_learn_of_a_dropped_step_at_different_updates_stay_identical(tmp_path):
+    """the host's reaction to a given-up recurrence may come at a different update on every rank (non-blocking query of an
+    asynchronous copy) -- it must not change which updates a rank queues.  14 free-running steps, rank 1's abort word forged before step
+    3, rank 0 blind during updates 4..6."""
+    import torch
+    res = _run_abort_script(tmp_path, 29657, "free")
+    assert torch.equal(res[0]["end"], res[1]["end"]), "ranks diverged"
+    assert res[0]["applied"] == res[1]["applied"] and 3 <= res[0]["applied"] < 14, (res[0]["applied"], res[1]["applied"])
+    assert res[0]["dropped"] == res[1]["dropped"] == 14 - res[0]["applied"]
+    for r in res:
+        assert r["raised_at"], "every rank must be told"
+        assert r["hooks_clear"]
+    assert min(res[0]["raised_at"]) >= 7 and min(res[1]["raised_at"]) >= 3, (res[0]["raised_at"], res[1]["raised_at"])
+    assert res[0]["raised_at"] != res[1]["raised_at"]          # (the situation the finding describes did occur)
+
+
+def test_a_given_up_recurrence_on_one_rank_drops_the_step_on_every_rank(tmp_path):
+    import torch
+    res = _run_abort_script(tmp_path, 29655)
     for r in res:
         assert r["events"] == [("applied", 1), ("applied", 1), ("ctl5", 1.0), ("applied", 2)], r["events"]
         assert r["unchanged"], "a rank applied the step although a peer's recurrence had given up"
