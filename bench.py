@@ -86,7 +86,7 @@ class Census(object):
             e0.record()
             r = fn(*a, **k)
             e1.record()
-            self.events.append((name, e0, e1))
+            self.events.append((name, e0, e1, gemm_shape(name, a, k, r) if name in GEMM_OPS else None))
             return r
         return inner
 
@@ -97,10 +97,79 @@ class Census(object):
     def totals(self):
         torch.cuda.synchronize()
         out = {}
-        for name, e0, e1 in self.events:
+        for name, e0, e1, _ in self.events:
             ms, n = out.get(name, (0.0, 0))
             out[name] = (ms + e0.elapsed_time(e1), n + 1)
         return out
+
+    def gemm_shapes(self):
+        """one entry per distinct GEMM-class product of the step: ms per call against BOTH floors (half of these
+        shapes are HBM-bound, a line priced against MFMA only cannot show it) -- flops / 2.5 PFLOP/s (dense bf16 MFMA peak) and
+        algorithmic bytes (each operand read once, the result written once) / 6.3 TB/s (what a streaming copy reaches on MI355X);
+        `frac` = the larger floor / the measured time = fraction of the roof that binds that shape"""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, e0, e1, sh in self.events:
+            if sh is None:
+                continue
+            key = (name,) + sh["key"]
+            ent = agg.setdefault(key, {"op": name, "form": sh["form"], "M": sh["M"], "N": sh["N"], "K": sh["K"], "out": sh["out"], "calls": 0,
+                                       "ms": 0.0, "flops": sh["flops"], "bytes": sh["bytes"]})
+            ent["calls"] += 1
+            ent["ms"] += e0.elapsed_time(e1)
+        out = []
+        for ent in agg.values():
+            ms = ent["ms"] / ent["calls"]
+            f_ms = ent["flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
+            b_ms = ent["bytes"] / (HBM_ACHIEVABLE_GBPS * 1e9) * 1e3
+            out.append({"op": ent["op"], "form": ent["form"], "M": ent["M"], "N": ent["N"], "K": ent["K"], "out": ent["out"], "calls": ent["calls"],
+                        "ms_per_call": round(ms, 4), "mfma_floor_ms": round(f_ms, 4), "hbm_floor_ms": round(b_ms, 4),
+                        "bound": "mfma" if f_ms >= b_ms else "hbm", "frac": round(max(f_ms, b_ms) / ms, 3),
+                        "tflops": round(ent["flops"] / (ms * 1e-3) / 1e12, 1), "gbps": round(ent["bytes"] / (ms * 1e-3) / 1e9, 0)})
+        out.sort(key=lambda e: -e["ms_per_call"] * e["calls"])
+        return out
+
+
+HBM_ACHIEVABLE_GBPS = 6300.0        # MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy (79 % of the 8 TB/s specification)
+
+
+def gemm_shape(name, a, k, result):
+    """(M, N, K), flops and algorithmic bytes of one GEMM-class C-ABI call from the arguments of its asr._ops wrapper"""
+    esz = lambda t: t.element_size()
+    if name == "gemm_nt":
+        A, Bm = a[0], a[1]
+        M, K = A.shape
+        N = Bm.shape[0]
+        ob = esz(result)
+        return {"key": (M, N, K, ob), "form": "NT", "M": M, "N": N, "K": K, "out": "f32" if ob == 4 else "bf16", "flops": 2.0 * M * N * K,
+                "bytes": 2.0 * (M * K + N * K) + float(ob) * M * N}
+    if name == "gemm_tn_acc":
+        A, Bm = a[0], a[1]
+        K, M = A.shape
+        N = Bm.shape[1]
+        return {"key": (M, N, K, 4), "form": "TN (split-K, f32 atomics)", "M": M, "N": N, "K": K, "out": "f32 +=", "flops": 2.0 * M * N * K,
+                "bytes": 2.0 * K * (M + N) + 4.0 * M * N}
+    if name == "gemm_tn_acc_group":
+        prods = a[0]
+        fl = sum(2.0 * p[0].shape[1] * p[1].shape[1] * p[0].shape[0] for p in prods)
+        by = sum(2.0 * p[0].shape[0] * (p[0].shape[1] + p[1].shape[1]) + 4.0 * p[0].shape[1] * p[1].shape[1] for p in prods)
+        desc = tuple((p[0].shape[1], p[1].shape[1], p[0].shape[0]) for p in prods)
+        return {"key": desc, "form": "TN grouped: " + " + ".join("%dx%dx%d" % d for d in desc), "M": sum(d[0] for d in desc), "N": desc[0][1],
+                "K": desc[0][2], "out": "f32 +=", "flops": fl, "bytes": by}
+    if name == "conv_nt":
+        x, W2, _, _, KH, KW, _, _, sgn, Tr, Hr = a[:11]
+        Ts, Bn, Hs, Cs = x.shape
+        M, N, K = Tr * Bn * Hr, W2.shape[0], KH * KW * Cs
+        ob = esz(result)
+        return {"key": (M, N, K, ob, int(sgn)), "form": "implicit conv NT (%s)" % ("forward" if sgn > 0 else "backward-data"), "M": M, "N": N, "K": K,
+                "out": "f32" if ob == 4 else "bf16", "flops": 2.0 * M * N * K, "bytes": 2.0 * x.numel() + 2.0 * W2.numel() + float(ob) * M * N}
+    if name == "conv_tn_acc":
+        g2, x, scratch, KH, KW = a[:5]
+        Ts, Bn, Hs, Cs = x.shape
+        M, N, K = g2.shape[1], KH * KW * Cs, g2.shape[0]
+        return {"key": (M, N, K, 4), "form": "implicit conv TN (weight gradient)", "M": M, "N": N, "K": K, "out": "f32 +=", "flops": 2.0 * M * N * K,
+                "bytes": 2.0 * g2.numel() + 2.0 * x.numel() + 4.0 * M * N}
+    return None
 
 
 def time_ctc(lib_mod, ops, T, B, V, L, x_len, l_len, labels, dev):
@@ -462,7 +531,38 @@ def time_sru(dev, T=1000, B=32, D=512, iters=20):
             "fwd_frac": fb / f / 1e6 / 6300.0, "bwd_frac": bb / b / 1e6 / 6300.0}
 
 
-def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
+def settled_steps(step, steps, max_warmup=12):
+    """`extra_configs` timing (one kept line had a 2.3 x outlier -- hipMalloc calls of the caching allocator inside a
+    five-step region entered after two warm-ups, see asr/functions.py: _OnSide).  Warm-up runs until the allocator is quiescent -- two
+    consecutive FREE-RUNNING steps (no synchronisation in between, as in the timed region) without a device allocation --, then `steps`
+    free-running steps bracketed by synchronisations; an event per step boundary gives the per-step spread without touching the region.
+    The line reports the device allocations that happened inside the region (0 is the healthy value)."""
+    def allocs():
+        return torch.cuda.memory_stats().get("num_device_alloc", 0)
+    warm, quiet = 0, 0
+    torch.cuda.synchronize()
+    while warm < max_warmup and quiet < 2:
+        a0 = allocs()
+        step()
+        warm += 1
+        quiet = quiet + 1 if allocs() == a0 else 0
+    torch.cuda.synchronize()
+    a0 = allocs()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    last = None
+    for i in range(steps):
+        last = step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return {"ms_per_step": dt / steps * 1e3, "min_ms": per[0], "median_ms": per[len(per) // 2], "max_ms": per[-1], "warmup_steps": warm,
+            "device_allocations_in_timed_region": allocs() - a0}, last
+
+
+def time_cnn_config(args, nconv, dev, steps=10):
     """BASELINE configs[4] on ONE GPU: one train step of the `zhang+residual` recipe (4 conv layers / the wide 8-layer branch), B=32,
     T=1000, V=119: ms per step, utterances/s and the MFMA fraction of its GEMM-class time"""
     import copy
@@ -490,7 +590,8 @@ def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
         loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
         opt.update(lossfun=lambda: loss)
         return loss
-    dt, _, loss = timed_region(step, steps, warmup, None, torch.cuda.synchronize)
+    spread, loss = settled_steps(step, steps)
+    dt = spread["ms_per_step"] * steps * 1e-3
     census = Census()
     census.wrap(_ops)
     asr_functions._SIDE["enabled"] = False
@@ -499,17 +600,22 @@ def time_cnn_config(args, nconv, dev, steps=5, warmup=2):
     census.events = []
     step()
     tot = census.totals()
+    shapes = census.gemm_shapes()
     asr_functions._SIDE["enabled"] = True
     census.unwrap()
     macs = cnn_macs_per_frame(cfg)
     gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in GEMM_OPS)
     flops = 3 * 2.0 * macs * T * B
+    floors = sum(max(e["mfma_floor_ms"], e["hbm_floor_ms"]) * e["calls"] for e in shapes)
+    times = sum(e["ms_per_call"] * e["calls"] for e in shapes)
     res = {"workload": "BASELINE configs[4] on one GPU: zhang+residual, %s, ndim_h 128, ndim_dense 320, B=%d, T=%d, V=%d, bf16 (see dtype_note)"
                        % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V),
-           "ms_per_step": dt / steps * 1e3, "utterances_per_s": B * steps / dt, "steps": steps, "final_loss": float(loss.item()),
+           "ms_per_step": dt / steps * 1e3, "utterances_per_s": B * steps / dt, "steps": steps, "step_spread": spread,
+           "final_loss": float(loss.item()),
            "gflop_per_utterance": 3 * 2.0 * macs * T / 1e9,
            "roofline": {"bound": "mfma", "achieved": flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "ms": gemm_ms, "traffic": None}}
+                        "frac": flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "ms": gemm_ms, "traffic": None,
+                        "frac_of_binding_roof": floors / times if times > 0 else None, "top_shapes": shapes[:6]}}
     del model, opt
     torch.cuda.empty_cache()
     return res
@@ -556,6 +662,9 @@ def spawn_ranks(args):
         raise SystemExit(rc if rc != 0 else 1)
 
 
+REGION = {"device_allocations": None}       # hipMalloc calls of the caching allocator inside the last timed region (healthy: 0)
+
+
 def timed_region(step, steps, warmup, comm, sync, dev=None):
     """the contract's timed region: W untimed steps, barrier + synchronize, K steps, synchronize + barrier, MAX over ranks"""
     import torch.distributed as dist
@@ -565,6 +674,7 @@ def timed_region(step, steps, warmup, comm, sync, dev=None):
     if comm is not None:
         comm.barrier()
     sync()
+    a0 = torch.cuda.memory_stats().get("num_device_alloc", 0) if torch.cuda.is_available() else 0
     t0 = time.perf_counter()
     last = None
     for _ in range(steps):
@@ -574,6 +684,7 @@ def timed_region(step, steps, warmup, comm, sync, dev=None):
         comm.barrier()
     sync()
     dt = time.perf_counter() - t0
+    REGION["device_allocations"] = (torch.cuda.memory_stats().get("num_device_alloc", 0) - a0) if torch.cuda.is_available() else 0
     per_rank = [dt]
     if comm is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if comm.backend == "nccl" else "cpu")
@@ -689,6 +800,7 @@ def main():
     log("rank %d/%d: model built, warm-up %d + timing %d steps" % (rank, world, args.warmup, args.steps))
     dt, per_rank, loss = timed_region(step, args.steps, args.warmup, comm, torch.cuda.synchronize, dev)
     loss_value = loss.item()
+    region_allocs = REGION["device_allocations"]
     exposed_ms = None
     if comm is not None:
         # time the launch stream stood still waiting for collectives (events around every join), per step, this rank and max
@@ -717,6 +829,7 @@ def main():
                       "global_batch": world * B, "parallelism": "dp%d" % world, "optimizer": "clip1+decay1e-5+adam",
                       "final_loss": loss_value,
                       "x_length": "U{600..%d}, length-exact recurrences (x_length passed to the model)" % T if args.ragged else "all %d" % T}}
+    out["device_allocations_in_timed_region"] = region_allocs
     if exposed_ms is not None:
         out["allreduce_exposed_ms_per_step"] = exposed_ms
 
@@ -741,6 +854,7 @@ def main():
         census.events = []
         step()
         tot = census.totals()
+        gemm_shape_table = census.gemm_shapes()
         asr_functions._SIDE["enabled"] = True
         census.unwrap()
         ctc = time_ctc(_lib, _ops, T, B, V, labels.shape[1], x_len, l_len, labels, dev)
@@ -837,9 +951,15 @@ def main():
         gemm_ms = sum(tot.get(k, (0.0, 0))[0] for k in GEMM_OPS)
         rec_flops = 2 * (2 * nl * T) * (B * H * 3 * H * 2)      # recurrent MFMA work runs inside the GRU kernels
         gemm_flops = 3 * 2 * macs_fwd - rec_flops
-        out["roofline_gemm"] = {"bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                "ms": gemm_ms}
+        shapes = gemm_shape_table
+        floors = sum(max(e["mfma_floor_ms"], e["hbm_floor_ms"]) * e["calls"] for e in shapes)
+        times = sum(e["ms_per_call"] * e["calls"] for e in shapes)
+        out["roofline_gemm"] = {"bound": "mfma | hbm per shape (see shapes)", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": floors / times if times > 0 else None,
+                                "frac_note": "time-weighted fraction of the roof that binds each shape: sum over the step's GEMM-class calls of "
+                                             "max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s), divided by their measured time",
+                                "frac_of_mfma_peak": gemm_flops / (gemm_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                "ms": gemm_ms, "shapes": shapes}
         sq, sq_src = sq_profile()
         if sq is not None:
             # MFMA utilisation of the GEMM kernels that ship (north_star: "MFMA utilisation for the GEMM blocks against gfx950 peak"):
@@ -858,10 +978,11 @@ def main():
             loss_r = connectionist_temporal_classification(model(xr, x_length=xlr), lr, 0, xlr, llr)
             opt.update(lossfun=lambda: loss_r)
             return loss_r
-        dtr, _, lossr = timed_region(ragged_step, 5, 2, None, torch.cuda.synchronize)
+        spr, lossr = settled_steps(ragged_step, 10)
         extra["ds2_ragged"] = {"workload": "configs[1] with x_length ~ U{%d..%d} (mean %.0f), length-exact BiGRU (reverse direction starts at each "
                                            "utterance's last frame)" % (int(0.6 * T), T, float(xlr.float().mean().item())),
-                               "ms_per_step": dtr / 5 * 1e3, "utterances_per_s": B * 5 / dtr, "final_loss": float(lossr.item())}
+                               "ms_per_step": spr["ms_per_step"], "utterances_per_s": B * 1e3 / spr["ms_per_step"], "step_spread": spr,
+                               "final_loss": float(lossr.item())}
         extra["gram_ctc"] = time_gram_ctc(dev, T, B, V, 120)
         extra["sru"] = time_sru(dev, T, B, 512)
         del model, opt

@@ -27,17 +27,20 @@ BF16, F32 = torch.bfloat16, torch.float32
 # (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
 # One side stream per launching stream: with two half batches on two streams (asr/pipeline.py) a shared side stream would
 # queue the early weight gradients of the second half behind the late ones of the first.
-_SIDE = {"streams": {}, "enabled": True, "dirty": set(),
+_SIDE = {"streams": {}, "origins": {}, "enabled": True, "dirty": set(), "keep": [],
          "join_before_recurrence": os.environ.get("ASR_SIDE_JOIN", "0") != "0"}
+_KEEP_LIMIT = 512       # tensors held for a side stream by a caller that never joins (see _OnSide)
 
 
 def side_stream():
     if not _SIDE["enabled"]:
         return None
-    key = torch.cuda.current_stream().cuda_stream
+    cur = torch.cuda.current_stream()
+    key = cur.cuda_stream
     st = _SIDE["streams"].get(key)
     if st is None:
         st = _SIDE["streams"][key] = torch.cuda.Stream(priority=int(os.environ.get("ASR_SIDE_PRIORITY", "0")))
+        _SIDE["origins"][key] = cur
     return st
 
 
@@ -46,11 +49,16 @@ def side_streams():
 
 
 def join_side_stream():
-    """called by the optimiser before it reads the gradients: the current stream waits for every side stream"""
+    """called by the optimiser before it reads the gradients: the current stream -- and the stream every side stream was forked from --
+    waits for the side streams; the tensors the side streams were reading are released only now (see _OnSide)"""
     cur = torch.cuda.current_stream()
-    for st in _SIDE["streams"].values():
+    for key, st in _SIDE["streams"].items():
         cur.wait_stream(st)
+        origin = _SIDE["origins"].get(key)
+        if origin is not None and origin.cuda_stream != cur.cuda_stream:
+            origin.wait_stream(st)
     _SIDE["dirty"].clear()
+    del _SIDE["keep"][:]
 
 
 def _empty_chip_for_recurrence():
@@ -72,7 +80,17 @@ def _empty_chip_for_recurrence():
 
 
 class _OnSide(object):
-    """with _OnSide(tensors...): kernels launched inside go to the side stream, after everything queued so far"""
+    """with _OnSide(tensors...): kernels launched inside go to the side stream, after everything queued so far.
+
+    `tensors` live on the launching stream and are read by the side stream.  They are kept ALIVE until join_side_stream() has made
+    the launching stream wait for the side stream -- not handed to Tensor.record_stream().  record_stream defers the reuse of a block
+    until an event on the side stream has completed, and the caching allocator looks at those events only when it is asked for memory:
+    a host that queues a step in 4 ms while the device takes 14 - 38 ms runs many steps ahead, none of the events has completed when the
+    next step asks, and every step in flight gets FRESH blocks from hipMalloc (measured with tools/cnn_step_times.py: 24 - 55 device
+    allocations and 5.6 - 17.8 GB of growth during five free-running steps of each recipe, zero with a synchronisation per step; this
+    is what made `extra_configs.cnn_wide8` 88.9 instead of 38.2 ms per step in one kept bench line -- hipMalloc calls inside a timed
+    region of five steps).  Held references are stream-ordered by construction: after the join, the blocks return to
+    the launching stream's pool behind the wait."""
 
     def __init__(self, *tensors):
         self.tensors = tensors
@@ -83,9 +101,14 @@ class _OnSide(object):
             return self
         self.side.wait_stream(torch.cuda.current_stream())
         _SIDE["dirty"].add(self.side)
+        keep = _SIDE["keep"]
+        if len(keep) > _KEEP_LIMIT:         # nobody joins (a loop of bare backward passes): fall back to the allocator's own bookkeeping
+            for t, st in keep:
+                t.record_stream(st)
+            del keep[:]
         for t in self.tensors:
             if t is not None:
-                t.record_stream(self.side)
+                keep.append((t, self.side))
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self

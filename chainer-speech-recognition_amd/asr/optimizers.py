@@ -42,8 +42,9 @@ class Optimizer(object):
         self.communicator = None
         self.pipeline = None
         self._needs_broadcast = False
-        self._gave_up = [None, None]        # pinned host copy of ctl[6] (give-up drops so far), event of that copy
+        self._gave_up = [None, None, 0]     # pinned host copy of ctl[6] (give-up drops so far), event of that copy, update it was queued behind
         self._gave_up_reported = 0.0
+        self._incident_until = -1           # last update attributed to the incident reported last
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -107,7 +108,6 @@ class Optimizer(object):
         _ops.step_control(G, self._flat["partials"], clip, scale, alpha, beta1, beta2, self._flat["applied"], self._flat["ctl"],
                           any_abort, 0)
         self._step(P, G, decay, self._flat["ctl"])
-        self._watch_gave_up()
         bump_weight_epoch()
         refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
         # The host learns of a given-up recurrence some steps late and without synchronising (a non-blocking query of an asynchronous
@@ -116,11 +116,16 @@ class Optimizer(object):
         # element -- until the raising rank clears its word.  The report therefore comes LAST, behind this step's collectives (a rank
         # raising before finish_backward would leave its peers in an all-reduce) and behind this step's update kernels: a
         # free-running loop in which the ranks' hosts run ahead of their devices by different amounts raises at different updates on
-        # different ranks, and none of them may skip queueing an update its peers apply.
-        self._raise_if_previous_step_gave_up()
+        # different ranks, and none of them may skip queueing an update its peers apply.  The copy looked at is an EARLIER
+        # update's (this update's is queued behind the look): "one update later" at the earliest, on every rank.
+        try:
+            self._raise_if_previous_step_gave_up()
+        finally:
+            self._watch_gave_up()
 
     def _watch_gave_up(self):
-        """asynchronous copy of ctl[6] (steps dropped because a recurrence gave up, ever) whenever the previous copy has landed"""
+        """asynchronous copy of ctl[6] (steps dropped because a recurrence gave up, ever) whenever the previous copy has landed;
+        st[2] = the update the copy in flight was queued behind"""
         st = self._gave_up
         if st[0] is None:
             st[0] = torch.zeros(1, dtype=F32).pin_memory()
@@ -128,18 +133,24 @@ class Optimizer(object):
             st[0].copy_(self._flat["ctl"][6:7], non_blocking=True)
             st[1] = torch.cuda.Event()
             st[1].record()
+            st[2] = self.t
 
     def _raise_if_previous_step_gave_up(self):
         st = self._gave_up
-        if st[1] is not None and st[1].query() and float(st[0][0]) > self._gave_up_reported:
-            self._gave_up_reported = float(st[0][0])
-            st[1] = None
-            _ops.clear_abort_words(self._flat["G"].device)       # sticky until somebody has been told: now
-            _ops.reset_poll_status()
-            from ._lib import AsrHipError
-            raise AsrHipError("a persistent GRU kernel gave up an in-launch wait during an earlier step (on this rank or on a "
-                              "data-parallel peer): %d step(s) so far were dropped for that reason, on every rank alike; parameters "
-                              "and optimiser state are intact; training may continue" % int(self._gave_up_reported))
+        if st[1] is None or not st[1].query() or float(st[0][0]) <= self._gave_up_reported:
+            return
+        count, seen_at = float(st[0][0]), st[2]
+        self._gave_up_reported = count
+        if seen_at <= self._incident_until:
+            return          # drops of the incident already reported: the updates queued before the abort words were cleared
+        self._incident_until = self.t       # this update was queued in front of the clear below: it may be dropped as well
+        st[1] = None
+        _ops.clear_abort_words(self._flat["G"].device)       # sticky until somebody has been told: now
+        _ops.reset_poll_status()
+        from ._lib import AsrHipError
+        raise AsrHipError("a persistent GRU kernel gave up an in-launch wait during an earlier step (on this rank or on a "
+                          "data-parallel peer): every update from that step up to and including this one is dropped, on every "
+                          "rank alike (%d so far); parameters and optimiser state are intact; training may continue" % int(count))
 
     def applied_steps(self):
         """number of update steps that were not dropped on the device (synchronises: tests / logging only)"""

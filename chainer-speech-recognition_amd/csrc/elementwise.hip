@@ -698,14 +698,16 @@ __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const ui
         }
     }
     if (db) {       // threads tid, tid + c8n, ... hold the same channels: one atomic per channel and workgroup
+        // image [e][thread]: a wave writes 64 consecutive floats per e and the folding threads of one e read consecutive ones
+        // (the [thread][16] image was a 16-way bank conflict on every access: 0.88 of this kernel's LDS cycles, profiles/r03_pmc_sq.csv)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[threadIdx.x * 16 + e] = bsum[e];
+        for (int e = 0; e < 16; ++e) red[e * 256 + threadIdx.x] = bsum[e];
         __syncthreads();
         const int t = threadIdx.x;
         if (t < c8n * 16) {
-            const int c8 = t >> 4, e = t & 15;
+            const int e = t / c8n, c8 = t - e * c8n;
             float s = 0.f;
-            for (int u = c8; u < 256; u += c8n) s += red[u * 16 + e];
+            for (int u = c8; u < 256; u += c8n) s += red[e * 256 + u];
             atomicAdd(db + c8 * 16 + e, s);
         }
     }

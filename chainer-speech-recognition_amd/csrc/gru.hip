@@ -937,7 +937,7 @@ __global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_
             ASR_ST(3)
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
-                // nest of divergent branches around narrow reads (measured 0.95 us per step)
+                // nest of divergent branches around narrow reads (measured 0.95 us per step) -- here the index is part of the address
                 const float* pf = reinterpret_cast<const float*>(part) + ((b >> 2) * 16 + u0) * 4 + (b & 3);
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) rcr += pf[ww * 256];
@@ -1351,25 +1351,32 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                                                         const float* __restrict__ hseq, const uint16_t* __restrict__ whhT,
                                                         uint16_t* __restrict__ dgi, uint16_t* __restrict__ dgh, float* __restrict__ db_ih,
                                                         float* __restrict__ db_hh, unsigned* sync, int T, int B, int H, int ndir,
-                                                        int forge) {
+                                                        int forge, int boff, int Bn) {
+    // (boff, Bn): the slab of batch rows this launch serves (see fwd_persistent_io_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* red = reinterpret_cast<float*>(smem);                                      // [8 producer groups][4 rows][2][16] f32 = 4 KB
+    // [8 lane groups][4 rows][2][16] f32, group pitch 144 floats: the eight store instructions of a gate wave (four groups of 16
+    // lanes each) then meet a 2-way bank conflict, which a ds_write_b32 absorbs, instead of a 4-way one (pitch 128)
+    constexpr int RED_PITCH = 144;
+    float* red = reinterpret_cast<float*>(smem);
     // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB: rows 4 .. 15 exist and stay zero, so that every lane reads its
     // fragment unconditionally -- three ds_reads back to back and ONE wait (with 4-row images the reads sat behind exec-mask
     // branches, each followed by its own wait: two LDS round trips more on the chain of every compute wave)
-    uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 4096);
-    char* opring = smem + 4096 + 3072;                                                  // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
+    // The fragment read of lane (row r = lane % 16, chunk q = lane / 16) takes chunk q ^ g4(r) of its row, g4 = {0, 2, 3, 1}[r / 4]: the
+    // sixteen lanes of a ds_read_b128 group then cover all 64 banks (rows are 64 B apart: unswizzled, rows r and r + 4 k met in the same
+    // banks).  g4 = 0 on the live rows 0 .. 3, so the writers store unswizzled, and the rows beyond are zero in every chunk.
+    uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 8 * RED_PITCH * 4);
+    char* opring = smem + 8 * RED_PITCH * 4 + 3072;                                     // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
     unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);         // [2][4: ar az an aq][4 rows][16 pairs]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 4 * 4 * 16);
     constexpr int rows = 4;
     const int nwg = H / 32;
-    const int Gn = (B + rows - 1) / rows, nrec = Gn * ndir, nrec_pad = (nrec + 7) & ~7;
+    const int Gn = (Bn + rows - 1) / rows, nrec = Gn * ndir, nrec_pad = (nrec + 7) & ~7;
     const int rec = LOCAL ? (int)(blockIdx.x % nrec_pad) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
     const int slot = LOCAL ? (int)(blockIdx.x / nrec_pad) : (int)blockIdx.x;
     if (LOCAL && rec >= nrec) return;
     const int d = rec / Gn, g = rec % Gn;
     const int j0 = slot * 32;
-    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int b0 = boff + g * rows, Bl = min(rows, boff + Bn - b0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 8, is_loader = w == 8, is_storer = w == 9;
     const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
@@ -1546,7 +1553,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                         }
                     }
                 }
-                float* rw = red + (gl >> 4) * 128 + (gl & 15);
+                float* rw = red + (gl >> 4) * RED_PITCH + (gl & 15);
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -1570,7 +1577,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             if (s > 0) {
                 const float* rr_ = red + b * 32 + (u0 & 1) * 16 + (u0 >> 1);
 #pragma unroll
-                for (int gq = 0; gq < 8; ++gq) rcr += rr_[gq * 128];
+                for (int gq = 0; gq < 8; ++gq) rcr += rr_[gq * RED_PITCH];
             }
             // (the factors that do not depend on dh were formed at the top of the step, under the hand-off's round trip)
             const float dh = dyc + rcr;
@@ -1596,8 +1603,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
             Frag a[3];
+            const int aq = (lane >> 4) ^ ((0x78 >> ((((lane & 15) >> 2) & 3) * 2)) & 3);
 #pragma unroll
-            for (int gg = 0; gg < 3; ++gg) a[gg].u = *reinterpret_cast<const uint4*>(aimg + (gg * 16 + (lane & 15)) * 32 + 8 * (lane >> 4));
+            for (int gg = 0; gg < 3; ++gg) a[gg].u = *reinterpret_cast<const uint4*>(aimg + (gg * 16 + (lane & 15)) * 32 + 8 * aq);
 #pragma unroll
             for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
@@ -1673,18 +1681,20 @@ template <int KSW, bool LOCAL, bool GI16, bool RING, bool G16 = false>
 __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
-                                                                int T, int B, int H, int ndir, int rows, int forge) {
+                                                                int T, int B, int H, int ndir, int rows, int forge, int boff, int Bn) {
+    // (boff, Bn): this launch serves the batch rows [boff, boff + Bn) of the B rows a time step holds -- batches beyond the resident
+    // limit run as consecutive slabs of <= 32 rows (utterances are independent: asr_gru_fwd)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* part = reinterpret_cast<float4*>(smem);                                   // [2 (step parity)][4 waves][3 gates][64]
     float* opring = reinterpret_cast<float*>(part + 2 * 4 * 3 * 64);                  // [BIO_GD][3 gates][8 rows][16 units]
     float* oring = opring + BIO_GD * 3 * 8 * 16;                                      // [2][5: h r z n q][8 rows][16 units]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 8 * 16);
-    const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
+    const int G_ = LOCAL ? (Bn + rows - 1) / rows : (int)gridDim.y;
     const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
     if (LOCAL && rec >= G_ * ndir) return;
     const int d = rec / G_, g = rec % G_;
     const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
-    const int b0 = g * rows, Bl = min(rows, B - b0);
+    const int b0 = boff + g * rows, Bl = min(rows, boff + Bn - b0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
     const int nks = H >> 5;
@@ -1745,8 +1755,6 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         const long long tq = tfirst + tstep * sp;
         const float* src = oring + (size_t)(sp & 1) * 5 * 8 * 16;
         if (G16) {
-            typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-            typedef float float2_t __attribute__((ext_vector_type(2)));
             uint16_t* gates16 = reinterpret_cast<uint16_t*>(gates);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1757,17 +1765,14 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         *reinterpret_cast<f32x4_asm*>(hseq + ((size_t)tq * B + b0 + row) * hs + (size_t)d * H + j0 + c4) = lds_read16_raw(src + pp * 4);
                 } else if (pp < 96) {
                     // blocked layout [T*B][ndir][H / 16][4 gates][16 units]: this workgroup's r | z | n | q of a row are ONE 128-B line
-                    // (in the [4][H] layout they were four 32-B pieces of four lines, each completed by three other workgroups)
-                    const int q = pp - 32, row = q >> 3, gate = (q & 7) >> 1, c8 = (q & 1) * 8;
+                    // (in the [4][H] layout they were four 32-B pieces of four lines, each completed by three other workgroups).
+                    // The gate waves leave them in LDS as that line already (put_state: IEEE half, [8 rows][4 gates][16 units]): a
+                    // piece is one conflict-free 16-B read -- the float32 [gate][row][unit] image cost two 4-way conflicted reads and
+                    // four conversions per piece on this wave.
+                    const int q = pp - 32, row = q >> 3;
                     if (row < Bl) {
-                        const float* ls = src + (1 + gate) * 128 + row * 16 + c8;
-                        const f32x4_asm v0 = lds_read16_raw(ls), v1 = lds_read16_raw(ls + 4);
-                        union { half2_t h[4]; uint4 u; } pk;
-                        pk.h[0] = __builtin_convertvector((float2_t){v0[0], v0[1]}, half2_t);
-                        pk.h[1] = __builtin_convertvector((float2_t){v0[2], v0[3]}, half2_t);
-                        pk.h[2] = __builtin_convertvector((float2_t){v1[0], v1[1]}, half2_t);
-                        pk.h[3] = __builtin_convertvector((float2_t){v1[2], v1[3]}, half2_t);
-                        *reinterpret_cast<uint4*>(gates16 + ((((size_t)tq * B + b0 + row) * ndir + d) * (H >> 4) + (j0 >> 4)) * 64 + gate * 16 + c8) = pk.u;
+                        const f32x4_asm v = lds_read16_raw(reinterpret_cast<const char*>(src + 128) + q * 16);
+                        *reinterpret_cast<f32x4_asm*>(gates16 + ((((size_t)tq * B + b0 + row) * ndir + d) * (H >> 4) + (j0 >> 4)) * 64 + (q & 7) * 8) = v;
                     }
                 }
             }
@@ -1794,6 +1799,20 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
             pk.x = pack_bf16x2(v0[0], v0[1]); pk.y = pack_bf16x2(v0[2], v0[3]);
             pk.z = pack_bf16x2(v1[0], v1[1]); pk.w = pack_bf16x2(v1[2], v1[3]);
             *reinterpret_cast<uint4*>(hseq16 + ((size_t)tq * B + b0 + (lane >> 1)) * hs + (size_t)d * H + j0 + (lane & 1) * 8) = pk;
+        }
+    };
+    // gate thread (row bb_, unit uu_) -> the storer's staging slot of this step's parity: h float32 [8][16]; the saved gates float32
+    // [4 gates][8][16] -- or, G16, IEEE half as the memory line [8 rows][4 gates][16 units] (the conversions sit behind the payload
+    // store, inside the pause before the next poll)
+    auto put_state = [&](int parity, int bb_, int uu_, float h, float r, float z, float n, float q) {
+        float* od = oring + (size_t)parity * 5 * 8 * 16;
+        od[bb_ * 16 + uu_] = h;
+        if (G16) {
+            _Float16* oh = reinterpret_cast<_Float16*>(od + 128) + bb_ * 64 + uu_;
+            oh[0] = (_Float16)r; oh[16] = (_Float16)z; oh[32] = (_Float16)n; oh[48] = (_Float16)q;
+        } else {
+            float* og = od + 128 + bb_ * 16 + uu_;
+            og[0] = r; og[128] = z; og[256] = n; og[384] = q;
         }
     };
     if (is_loader) {
@@ -2042,12 +2061,14 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
 #pragma unroll
                         for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1][gg].v, acc[gg], 0, 0, 0);
                     }
+                    // K-split partial products -> LDS, image [parity][gate][wave][32 live lanes] float4: a lane's four rows of one gate are
+                    // ONE ds_write_b128 (consecutive lanes, consecutive 16 B: conflict-free), three stores per wave and step.  (The
+                    // reader-major image [gate][row][unit][wave] took twelve ds_write_b32 per wave at a 4-way bank conflict -- the
+                    // 0.42 conflict fraction of profiles/r03_pmc_sq.csv -- to save the gate threads nine reads.)
                     if (lane < 32) {
-                        float* pw = reinterpret_cast<float*>(part) + (s & 1) * 3 * 128 * 4 + (((lane >> 4) * 4) * 16 + (lane & 15)) * 4 + w;
+                        float4* pw = part + (s & 1) * 3 * 128 + w * 32 + lane;
 #pragma unroll
-                        for (int gg = 0; gg < 3; ++gg)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) pw[(gg * 128 + r * 16) * 4] = acc[gg][r];
+                        for (int gg = 0; gg < 3; ++gg) pw[gg * 128] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
                     }
                 }
                 ASR_PF(2)
@@ -2057,11 +2078,15 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 if (gate_wave) {
                     float gh0 = bh[0], gh1 = bh[1], gh2 = bh[2];
                     if (s > 0 && act) {
-                        const float4* pf = part + (s & 1) * 3 * 128 + b * 16 + u;
-                        const float4 v0 = pf[0], v1 = pf[128], v2 = pf[256];
-                        gh0 += (v0.x + v0.y) + (v0.z + v0.w);
-                        gh1 += (v1.x + v1.y) + (v1.z + v1.w);
-                        gh2 += (v2.x + v2.y) + (v2.z + v2.w);
+                        // (row b, unit u) of wave ww: float (b & 3) of lane (b >> 2) * 16 + u -- a gate wave's 64 threads read 64
+                        // consecutive dwords per (gate, wave): conflict-free ds_read_b32, twelve of them in flight together
+                        const float* pf = reinterpret_cast<const float*>(part + (s & 1) * 3 * 128) + ((b >> 2) * 16 + u) * 4 + (b & 3);
+                        const float a0 = pf[0], a1 = pf[128], a2 = pf[256], a3 = pf[384];
+                        const float c0 = pf[512], c1 = pf[640], c2 = pf[768], c3 = pf[896];
+                        const float e0 = pf[1024], e1 = pf[1152], e2 = pf[1280], e3 = pf[1408];
+                        gh0 += (a0 + a1) + (a2 + a3);
+                        gh1 += (c0 + c1) + (c2 + c3);
+                        gh2 += (e0 + e1) + (e2 + e3);
                     }
                     const float r = sigmoidf_(gr + gh0);
                     const float z = sigmoidf_(gz + gh1);
@@ -2083,10 +2108,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                         }
                     }
                     if (s + 1 < T && lane == 0) lds_poke(s_abort + w, s + 1);
-                    if (act) {
-                        float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
-                        od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh2;
-                    }
+                    if (act) put_state(s & 1, b, u, h, r, z, n, gh2);
                     if (s + 1 < T) {
                         poll_pause(poll_delay);
                         if (RING) fetch_ring(ahead, s & (PS_RING - 1)); else fetch_row(ahead, t);
@@ -2196,15 +2218,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
 #pragma unroll
                     for (int gg = 0; gg < 3; ++gg) acc[gg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][gg].v, acc[gg], 0, 0, 0);
                 }
-                // partials laid out for the reader: the four waves' values of one (gate, row, unit) are one float4
-                // [parity][gate][row 8][unit 16][wave 4] -- 12 scalar writes here instead of 12 scalar reads on the gate
-                // threads' critical path (which then read three float4)
-                if (lane < 32) {
-                    float* pw = reinterpret_cast<float*>(part) + (dp ? (s & 1) * 3 * 128 * 4 : 0) + (((lane >> 4) * 4) * 16 + (lane & 15)) * 4 + w;
+                if (lane < 32) {        // (image: see the role-specialised loop)
+                    float4* pw = part + (dp ? (s & 1) * 3 * 128 : 0) + w * 32 + lane;
 #pragma unroll
-                    for (int gg = 0; gg < 3; ++gg)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) pw[(gg * 128 + r * 16) * 4] = acc[gg][r];
+                    for (int gg = 0; gg < 3; ++gg) pw[gg * 128] = make_float4(acc[gg][0], acc[gg][1], acc[gg][2], acc[gg][3]);
                 }
             }
             ASR_ST(3)
@@ -2213,13 +2230,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
             if ((s & 15) == 0 && *s_abort) break;      // (every 16 steps: the LDS read sat on the chain behind the barrier; polls give up at once anyway)
             if (act) {
                 // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
-                // nest of divergent branches around narrow reads (measured 0.95 us per step)
-                const float4* pf = part + (dp ? (s & 1) * 3 * 128 : 0) + b * 16 + u;
+                // nest of divergent branches around narrow reads (measured 0.95 us per step) -- here the index is part of the address
+                const float* pf = reinterpret_cast<const float*>(part + (dp ? (s & 1) * 3 * 128 : 0)) + ((b >> 2) * 16 + u) * 4 + (b & 3);
 #pragma unroll
-                for (int gg = 0; gg < 3; ++gg) {
-                    const float4 v = pf[gg * 128];
-                    gh[gg] += (v.x + v.y) + (v.z + v.w);
-                }
+                for (int gg = 0; gg < 3; ++gg) gh[gg] += (pf[gg * 512] + pf[gg * 512 + 128]) + (pf[gg * 512 + 256] + pf[gg * 512 + 384]);
             }
             ASR_ST(9)
         }
@@ -2259,10 +2273,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 fetch_row(ahead, t);
                 have_ahead = true;
             }
-            if (act) {
-                float* od = oring + (size_t)(s & 1) * 5 * 8 * 16 + b * 16 + u;
-                od[0] = h; od[128] = r; od[256] = z; od[384] = n; od[512] = gh[2];
-            }
+            if (act) put_state(s & 1, b, u, h, r, z, n, gh[2]);
             ASR_ST(6)
             if (!dp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ASR_ST(7)
@@ -3184,10 +3195,28 @@ static bool bwd_ps_form(int T, int B, int H, int ndir, int mode, const void* syn
     return can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12 && (mode == 0 || mode == 8 || mode == 9 || mode == 10) && H % 128 == 0 &&
            H <= 1024 && ndir * ((B + 3) / 4) <= 16;
 }
+// Any batch size on the fast path.  The persistent kernels are resident on every CU at 32 utterances (8 recurrences x 32 workgroups
+// forward, 16 x 16 backward), and a recurrence's step time does not depend on how many of its rows are live.  A larger batch --
+// the reference trains with 128 per bucket, shrinking by 16 (run/ctc/cnn/train.py:72-73,165,208-209) -- runs as consecutive slabs of
+// <= 32 rows through the default kernel pair: utterances are independent, so the results are those of one launch; B = 64 costs two
+// recurrences' time instead of the 8 x of the per-step launches.  0 = no slabs (the batch fits, another kernel form was asked
+// for, or the 32-bit offsets inside the hand-off buffers would not cover the whole batch).
+static int slab_rows(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
+    constexpr int kSlab = 16 * MT;
+    if (B <= kSlab || !(mode == 0 || mode == 8)) return 0;
+    if ((size_t)T * B * ndir * 3 * H * 2 >= ((size_t)1 << 31)) return 0;
+    // the 16-unit x 8-row forward kernel (its ring form, or -- K split too shallow for it, H < 256 -- its flag form, which fills no
+    // sentinels into the whole sequence) and the partial-sum backward kernel: both take (boff, Bn)
+    if (fwd_family(T, kSlab, H, ndir, mode, sync_ws) != 2 || !bwd_ps_form(T, kSlab, H, ndir, mode, sync_ws)) return 0;
+    if (!fwd_ring_form(T, kSlab, H, ndir, mode, sync_ws) && (H / 32 + 3) / 4 >= 2) return 0;       // (ASR_FWD_RING=0: sequence polling)
+    return kSlab;
+}
+
 extern "C" int asr_gru_gates_f16_ok(int T, int B, int H, int ndir, int mode) {
     if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
     static int dummy;
     const int fmode = (mode == 9 || mode == 10) ? 0 : mode;
+    if (const int slab = slab_rows(T, B, H, ndir, mode, &dummy)) return fwd_ring_form(T, slab, H, ndir, fmode, &dummy) ? 1 : 0;
     return fwd_ring_form(T, B, H, ndir, fmode, &dummy) && bwd_ps_form(T, B, H, ndir, mode, &dummy) ? 1 : 0;
 }
 
@@ -3195,7 +3224,54 @@ extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mo
     if (check_dims(T, B, H, ndir) != ASR_OK) return 0;
     if (mode == 9 || mode == 10) mode = 0;
     static int dummy;
+    if (slab_rows(T, B, H, ndir, mode, &dummy)) return 1;
     return fwd_family(T, B, H, ndir, mode, &dummy) == 2 ? 1 : 0;
+}
+
+// The 16-unit x 8-row forward kernel (family 2 of fwd_family: the default) on the batch rows [boff, boff + Bn) of a (T, B, ..) problem.
+static int fwd_io_launch(hipStream_t st, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
+                     float* gates, void* sync_ws, int T, int B, int H, int ndir, int mode, int gates_f16, int boff, int Bn) {
+    const int ksw = (H / 32 + 3) / 4;
+    const int io_rows = 8, io_lds = kPersistLds;
+    const int Gio = (Bn + io_rows - 1) / io_rows;
+    const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
+    // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
+    const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
+    static int ring_env = -1;
+    if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }      // (0: the payload is polled in the bf16 sequence itself)
+    const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
+    if (gates_f16 && !use_ring) return ASR_ERR_UNSUPPORTED;
+    if (!use_ring && (forge & 8) && (boff != 0 || Bn != B)) return ASR_ERR_UNSUPPORTED;      // (slabs: not the form that fills / polls the whole sequence)
+    if (use_ring) {
+        if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)8 * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
+    } else if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
+    const int forge_k = forge | (fwd_poll_delay(H, use_ring) << 8);
+    const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
+#define ASR_FWDIO_(K, L, G, R)                                                                                            \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G, R>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge_k : 0, boff, Bn);         \
+    } while (0)
+#define ASR_FWDIO16_(K, G)                                                                                                \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true, G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true, G, true, true>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge_k, boff, Bn);                 \
+    } while (0)
+#define ASR_FWDIO(K)                                                                                                      \
+    do {                                                                                                                  \
+        if (use_ring && gates_f16) { if (gi_bf16) ASR_FWDIO16_(K, true); else ASR_FWDIO16_(K, false); }                   \
+        else if (use_ring) { if (gi_bf16) ASR_FWDIO_(K, true, true, true); else ASR_FWDIO_(K, true, false, true); }       \
+        else if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true, false); else ASR_FWDIO_(K, true, false, false); }        \
+        else { if (gi_bf16) ASR_FWDIO_(K, false, true, false); else ASR_FWDIO_(K, false, false, false); }                 \
+    } while (0)
+    if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
+#undef ASR_FWDIO_
+#undef ASR_FWDIO16_
+#undef ASR_FWDIO
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
 }
 
 extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
@@ -3206,9 +3282,10 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     if (mode == 9 || mode == 10) mode = 0;      // (those select backward kernels)
-    if (gates_f16 && !fwd_ring_form(T, B, H, ndir, mode, sync_ws)) return ASR_ERR_UNSUPPORTED;       // (ask asr_gru_gates_f16_ok)
+    const int slab = slab_rows(T, B, H, ndir, mode, sync_ws);
+    if (gates_f16 && !fwd_ring_form(T, slab ? slab : B, H, ndir, mode, sync_ws)) return ASR_ERR_UNSUPPORTED;       // (ask asr_gru_gates_f16_ok)
     const float* gi = reinterpret_cast<const float*>(gi_any);
-    if (gi_bf16 && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
+    if (gi_bf16 && !slab && fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return ASR_ERR_UNSUPPORTED;      // (ask asr_gru_fwd_accepts_bf16_gi)
     hipStream_t st = (hipStream_t)stream;
     if (x_len) {        // pin the update gate of the rows beyond each utterance's length (see pin_update_gate_kernel)
         if ((long long)T * B > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
@@ -3222,12 +3299,17 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const bool grouped = persist && can_group(B, H);
-    const int io_rows = 8, io_lds = kPersistLds;
-    const int Gio = (B + io_rows - 1) / io_rows;
+    const int Gio = (B + 7) / 8;
     // wide form also for B <= 16 in the default modes: a half batch (asr/pipeline.py) then makes 8 recurrences of 16
     // workgroups, so that the launch of the other half batch finds a free CU for every workgroup of its own
     const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
-    if (persist && (mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
+    if (slab) {         // consecutive slabs of <= 32 rows through the default kernel (see slab_rows); the launches share sync_ws in stream order
+        for (int boff = 0; boff < B; boff += slab) {
+            const int rc2 = fwd_io_launch(st, gi_any, gi_bf16, whh_bf16, bhh, hseq, hseq_bf16, gates, sync_ws, T, B, H, ndir, mode, gates_f16, boff,
+                                          B - boff < slab ? B - boff : slab);
+            if (rc2 != ASR_OK) return rc2;
+        }
+    } else if (persist && (mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
         // wide form (32 units x 4-row recurrences).  Measured at T=1000, B=32, H=512: with the XCD-local hand-off it ties
         // the 16-unit x 8-row kernel (2.11 vs 2.12 us: the smaller payload is paid back in the 8-wave reduction), with the
         // placement-free hand-off it wins (2.47 vs 2.72 us) -- so it serves mode 2 only; the backward pass is wide in both.
@@ -3253,41 +3335,8 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
         if (ks8 <= 1) ASR_FWDW(1); else if (ks8 <= 2) ASR_FWDW(2); else ASR_FWDW(4);
 #undef ASR_FWDW
     } else if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
-        const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
-        // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
-        const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
-        static int ring_env = -1;
-        if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }      // (0: the payload is polled in the bf16 sequence itself)
-        const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
-        if (gates_f16 && !use_ring) return ASR_ERR_UNSUPPORTED;
-        if (use_ring) {
-            if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)8 * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
-        } else if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
-        const int forge_k = forge | (fwd_poll_delay(H, use_ring) << 8);
-        const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
-#define ASR_FWDIO_(K, L, G, R)                                                                                            \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, L, G, R>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, L ? forge_k : 0);         \
-    } while (0)
-#define ASR_FWDIO16_(K, G)                                                                                                \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, true, G, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL((fwd_persistent_io_kernel<K, true, G, true, true>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq, \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge_k);                 \
-    } while (0)
-#define ASR_FWDIO(K)                                                                                                      \
-    do {                                                                                                                  \
-        if (use_ring && gates_f16) { if (gi_bf16) ASR_FWDIO16_(K, true); else ASR_FWDIO16_(K, false); }                   \
-        else if (use_ring) { if (gi_bf16) ASR_FWDIO_(K, true, true, true); else ASR_FWDIO_(K, true, false, true); }       \
-        else if (local) { if (gi_bf16) ASR_FWDIO_(K, true, true, false); else ASR_FWDIO_(K, true, false, false); }        \
-        else { if (gi_bf16) ASR_FWDIO_(K, false, true, false); else ASR_FWDIO_(K, false, false, false); }                 \
-    } while (0)
-        if (ksw <= 1) ASR_FWDIO(1); else if (ksw <= 2) ASR_FWDIO(2); else if (ksw <= 4) ASR_FWDIO(4); else ASR_FWDIO(8);
-#undef ASR_FWDIO_
-#undef ASR_FWDIO16_
-#undef ASR_FWDIO
+        const int rc2 = fwd_io_launch(st, gi_any, gi_bf16, whh_bf16, bhh, hseq, hseq_bf16, gates, sync_ws, T, B, H, ndir, mode, gates_f16, 0, B);
+        if (rc2 != ASR_OK) return rc2;
     } else if (grouped) {
         const int G = (B + RG - 1) / RG;
         if (!clear_sync(sync_ws, (size_t)ndir * G * 2 * RG * (H / 2) * 8, st)) return ASR_ERR_LAUNCH;
@@ -3346,7 +3395,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
                            void* dy_ws, int gates_f16) {
     if (!dy_bf16 || !gates_any || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const float* gates = reinterpret_cast<const float*>(gates_any);
-    if (gates_f16 && !(bwd_ps_form(T, B, H, ndir, mode, sync_ws) && db_ih && db_hh)) return ASR_ERR_UNSUPPORTED;
+    if (gates_f16 && !((bwd_ps_form(T, B, H, ndir, mode, sync_ws) || slab_rows(T, B, H, ndir, mode, sync_ws)) && db_ih && db_hh)) return ASR_ERR_UNSUPPORTED;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -3391,33 +3440,37 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
     }
     // partial-sum exchange (bwd_ps_kernel): the default where it applies (modes 0 / 8; 9 asks for it, 10 forges a split
     // placement so that its placement-free stores are exercised); measured 1.78 -> 1.59 us per step at T=1000, B=32, H=512
-    if (persist && (mode == 0 || mode == 8 || mode == 9 || mode == 10) && db_ih && db_hh && H % 128 == 0 && H <= 1024 &&
-        ndir * ((B + 3) / 4) <= 16) {
-        const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
-        if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, ps_exchange_bytes(nrec_pad, H), st)) return ASR_ERR_LAUNCH;
-        const dim3 wgrid(nrec_pad * (H / 32)), wblock(640);
+    const int slab = (db_ih && db_hh) ? slab_rows(T, B, H, ndir, mode, sync_ws) : 0;       // (see slab_rows: batches beyond 32 rows)
+    if (slab || (persist && (mode == 0 || mode == 8 || mode == 9 || mode == 10) && db_ih && db_hh && H % 128 == 0 && H <= 1024 &&
+                 ndir * ((B + 3) / 4) <= 16)) {
+        for (int boff = 0; boff < B; boff += slab ? slab : B) {
+            const int Bn = slab ? (B - boff < slab ? B - boff : slab) : B;
+            const int Gw = (Bn + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
+            if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, ps_exchange_bytes(nrec_pad, H), st)) return ASR_ERR_LAUNCH;
+            const dim3 wgrid(nrec_pad * (H / 32)), wblock(640);
 #define ASR_BWDPS_(NT_, G)                                                                                                \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)bwd_ps_kernel<NT_, true, G>, hipFuncAttributeMaxDynamicSharedMemorySize, kExclusiveLds); \
         hipLaunchKernelGGL((bwd_ps_kernel<NT_, true, G>), wgrid, wblock, kExclusiveLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
                            (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh, (unsigned*)sync_ws, \
-                           T, B, H, ndir, mode == 10 ? 1 : 0);                                                            \
+                           T, B, H, ndir, mode == 10 ? 1 : 0, boff, Bn);                                                  \
     } while (0)
 #define ASR_BWDPS(NT_)                                                                                                    \
     do {                                                                                                                  \
         if (gates_f16) ASR_BWDPS_(NT_, true); else ASR_BWDPS_(NT_, false);                                                \
     } while (0)
-        switch (H / 128) {
-            case 1: ASR_BWDPS(1); break;
-            case 2: ASR_BWDPS(2); break;
-            case 3: ASR_BWDPS(3); break;
-            case 4: ASR_BWDPS(4); break;
-            case 8: ASR_BWDPS(8); break;
-            default: return ASR_ERR_UNSUPPORTED;
-        }
+            switch (H / 128) {
+                case 1: ASR_BWDPS(1); break;
+                case 2: ASR_BWDPS(2); break;
+                case 3: ASR_BWDPS(3); break;
+                case 4: ASR_BWDPS(4); break;
+                case 8: ASR_BWDPS(8); break;
+                default: return ASR_ERR_UNSUPPORTED;
+            }
 #undef ASR_BWDPS
 #undef ASR_BWDPS_
-        ASR_LAUNCH_CHECK();
+            ASR_LAUNCH_CHECK();
+        }
         return ASR_OK;
     }
     // wide form (32 units x 4-row recurrences): mode 5 keeps the 16-unit x 8-row kernels for comparison

@@ -289,7 +289,10 @@ int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, con
  * db_ih / db_hh (ndir, 3H) f32 or NULL: bias gradients, ACCUMULATED (sum over all rows of dgi / dgh).
  * sync_ws: asr_gru_sync_bytes(B, H, ndir) bytes of device memory (control words + the in-launch exchange
  * buffer, zeroed by the call) enabling the persistent
- * one-launch-per-layer form.  mode: 0 = automatic (persistent when B <= 32, else one launch per step),
+ * one-launch-per-layer form.  mode: 0 = automatic: persistent; a batch of more than 32 utterances (the reference trains with 128 per
+ * bucket, run/ctc/cnn/train.py:72-73) runs as consecutive slabs of <= 32 rows through the default kernel pair where that pair serves
+ * the shape (H % 128 == 0, offsets below 2 GiB) -- utterances are independent, the results are those of one launch, the time is
+ * ceil(B / 32) recurrences -- and otherwise with one launch per time step,
  * 1 = one launch per time step, 2 = persistent with the placement-free hand-off only (sc1 write-through + agent-scope
  * counter), 3 = the 32-unit grouped kernels, 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
  * find themselves on one XCD (decided inside the launch, falls back to the mode-2 protocol otherwise) signalled through a

@@ -170,9 +170,10 @@ def test_model_with_lengths_matches_the_oracle(device, B, T, H):
     # the default backward kernel at H % 128 == 0 exchanges per-producer partial sums rounded to bf16 (32 units per producer)
     ps_units = 32 if (H % 128 == 0 and 2 * ((B + 3) // 4) <= 16 and B <= 32) else None
     # end to end the matched oracle and the device drift apart with width and length (float32 summation order and the fast exp / rcp of
-    # 150 x 512-wide recurrence steps feed back through two layers: tests/test_model_gpu.py, MATCHED_GRAD_DEEP); layer by layer the same
-    # shape agrees to 1e-3 (test_gru_runs_every_utterance_over_its_own_length and tools/debug/ragged_b6.py)
-    tight = 5e-3 if H < 512 else 2e-2
+    # 150 x 512-wide recurrence steps feed back through two layers); LAYER BY LAYER the same stack at H = 512, ragged, is held to 1e-3 by
+    # tests/test_ds2_layers_gpu.py (teacher-forced, no accumulation).  H = 512 here: 2 x the 0.5e-2 .. 1.2e-2 measured (float atomics of
+    # the split-K weight gradients make the figure move from run to run).
+    tight = 5e-3 if H < 512 else 2.5e-2
     for matched, tol in ((False, 0.2), (True, tight)):
         ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, True, matched=matched, gi_bf16=gi_bf16, ps_units=ps_units,
                                fused_logit_bias=True, gates_f16=_ops.gru_gates_f16(T, B, H, 2))

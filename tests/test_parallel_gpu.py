@@ -232,14 +232,14 @@ def step():
     opt.update(lossfun=lambda: loss)
 if len(sys.argv) > 2 and sys.argv[2] == "free":
     # ADVICE r3: a free-running loop -- no synchronisation between steps, the two hosts look at their asynchronous copies at different
-    # times (rank 0 does not look at all during three updates, as a host far ahead of its device would not).  Whichever update a rank
+    # times (rank 0 does not look at all during four updates, as a host far ahead of its device would not).  Whichever update a rank
     # raises at, it must have queued exactly the updates its peer queued: parameters, Adam state and the applied count stay identical.
     import time
     raised_at, check = [], opt._raise_if_previous_step_gave_up
     for i in range(14):
         if i == 3 and rank == 1:
             list(_ops._SYNC.values())[0][1023:1024].fill_(1)
-        opt._raise_if_previous_step_gave_up = (lambda: None) if (rank == 0 and 4 <= i <= 6) else check
+        opt._raise_if_previous_step_gave_up = (lambda: None) if (rank == 0 and 3 <= i <= 6) else check
         if rank == 1 and i % 3 == 0:
             time.sleep(0.01)
         try:
@@ -298,7 +298,7 @@ def _run_abort_script(tmp_path, port, *extra):
 def test_ranks_that_learn_of_a_dropped_step_at_different_updates_stay_identical(tmp_path):
     """the host's reaction to a given-up recurrence may come at a different update on every rank (non-blocking query of an
     asynchronous copy) -- it must not change which updates a rank queues.  14 free-running steps, rank 1's abort word forged before step
-    3, rank 0 blind during updates 4..6."""
+    3, rank 0 blind during updates 3..6."""
     import torch
     res = _run_abort_script(tmp_path, 29657, "free")
     assert torch.equal(res[0]["end"], res[1]["end"]), "ranks diverged"
