@@ -53,9 +53,6 @@ def parse():
                                                            "the ragged-length step)")
     ap.add_argument("--ragged", action="store_true", help="time the step on the ragged batch of SURVEY 8d (x_length ~ U{600..T}, "
                                                           "length-exact recurrences) instead of full-length utterances")
-    ap.add_argument("--halves", type=int, default=int(os.environ.get("ASR_BENCH_HALVES", "0")),
-                    help="1: the batch as two concurrent half batches (asr/pipeline.py; measured slower at the BASELINE "
-                         "configuration, DESIGN.md section 5), 0: one stream (default)")
     return ap.parse_args()
 
 
@@ -777,20 +774,9 @@ def main():
     if comm is not None:
         opt.set_communicator(comm)
 
-    pipe = None
-    if args.halves and B >= 2:
-        from asr.pipeline import HalfBatches
-        pipe = HalfBatches(dev)
-        opt.set_pipeline(pipe)
-
-    def half_loss(sl):
-        return connectionist_temporal_classification(model(x[sl]), labels[sl], 0, x_len[sl], l_len[sl])
-
     exposed = []
 
     def step():
-        if pipe is not None:
-            return pipe.step(opt, half_loss, B, stagger_us=0)
         loss = connectionist_temporal_classification(model(x, **model_kw), labels, 0, x_len, l_len)
         opt.update(lossfun=lambda: loss)
         if comm is not None:

@@ -14,6 +14,16 @@ LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
 
 _lib = None
 
+
+def debug_flag(key, default):
+    """integer value of `key` in ASR_DEBUG="key=value,key=value" -- the ONE table of what-if switches (csrc/common.hpp: debug_flag lists
+    the keys the library reads; this layer reads tn_group, gru_gates_f16, side_join, side_priority).  Nothing in a normal run sets it."""
+    for item in os.environ.get("ASR_DEBUG", "").split(","):
+        k, _, v = item.strip().partition("=")
+        if k == key and v:
+            return int(v)
+    return default
+
 c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
 c_longlong = ctypes.c_longlong
 

@@ -49,7 +49,7 @@ def gemm_tn_acc(a, b, c):
     return c
 
 
-TN_GROUP = [os.environ.get("ASR_TN_GROUP", "1") != "0"]     # 0: one launch per product (comparison)
+TN_GROUP = [_lib.debug_flag("tn_group", 1) != 0]     # ASR_DEBUG tn_group=0: one launch per product (comparison)
 
 
 def gemm_tn_acc_group(products):
@@ -341,7 +341,7 @@ def layernorm_ctc_bwd(x, gamma, beta, mean, rstd, T, B, dx_dtype, dgamma, dbeta,
     return dx
 
 
-GRU_MODE = [int(os.environ.get("ASR_GRU_MODE", "0"))]      # (ASR_GRU_MODE: rehearsals with several processes on one GPU use 1)  asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 3 grouped, 4 local with flags, 5 narrow backward, 7 forged placement, 8 local with polled payload (= 0)
+GRU_MODE = [int(os.environ.get("ASR_GRU_MODE", "0"))]      # (ASR_GRU_MODE: rehearsals with several processes on one GPU use 1)  asr_hip.h: 0 automatic, 1 per-step launches, 2 persistent placement-free, 4 local with flags, 7 forged placement, 8 local with polled payload (= 0), 9 / 10 partial-sum backward (asked for / forged placement)
 
 
 _SYNC = {}          # (device index, stream) -> one reusable control buffer; its abort word (int 1023) is sticky
@@ -401,8 +401,8 @@ GRU_GI_BF16 = [True]        # write the input projections in bf16 where the recu
 # saved gates in IEEE half, blocked by workgroup, where the default kernel pair serves (asr_hip.h): a row's r | z | n | q of 16 units
 # are ONE 128-B line instead of four 64-B pieces of four lines.  Measured at T=1000, B=32, H=512: forward 1.256 -> 1.210 us per step,
 # backward 1.347 -> 1.329 (half gates in the plain [4][H] layout had bought nothing: the CU's memory queue beside the hand-off is
-# bound by the NUMBER of requests).  ASR_GRU_GATES_F16=0 keeps float32 gates.
-GRU_GATES_F16 = [os.environ.get("ASR_GRU_GATES_F16", "1") != "0"]
+# bound by the NUMBER of requests).  ASR_DEBUG gru_gates_f16=0 keeps float32 gates.
+GRU_GATES_F16 = [_lib.debug_flag("gru_gates_f16", 1) != 0]
 
 
 def gru_gates_standard(gates, H):

@@ -17,6 +17,7 @@ import os
 import torch
 
 from . import _ops
+from ._lib import debug_flag as _lib_debug
 from .link import grad_buffer, grads_queued
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -25,10 +26,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 # ---------------------------------------------------------------------------------------------- side stream
 # Weight-gradient GEMMs do not feed the activation-gradient chain: they run on a second HIP stream, beside the next
 # (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
-# One side stream per launching stream: with two half batches on two streams (asr/pipeline.py) a shared side stream would
-# queue the early weight gradients of the second half behind the late ones of the first.
+# One side stream per launching stream (a data prefetcher or an evaluation pass may launch from streams of their own).
 _SIDE = {"streams": {}, "origins": {}, "enabled": True, "dirty": set(), "keep": [],
-         "join_before_recurrence": os.environ.get("ASR_SIDE_JOIN", "0") != "0"}
+         "join_before_recurrence": _lib_debug("side_join", 0) != 0}
 _KEEP_LIMIT = 512       # tensors held for a side stream by a caller that never joins (see _OnSide)
 
 
@@ -39,7 +39,7 @@ def side_stream():
     key = cur.cuda_stream
     st = _SIDE["streams"].get(key)
     if st is None:
-        st = _SIDE["streams"][key] = torch.cuda.Stream(priority=int(os.environ.get("ASR_SIDE_PRIORITY", "0")))
+        st = _SIDE["streams"][key] = torch.cuda.Stream(priority=_lib_debug("side_priority", 0))
         _SIDE["origins"][key] = cur
     return st
 
@@ -62,7 +62,7 @@ def join_side_stream():
 
 
 def _empty_chip_for_recurrence():
-    """ASR_SIDE_JOIN=1 (off by default): the launching stream waits for the side streams before it queues a recurrence.
+    """ASR_DEBUG side_join=1 (off by default): the launching stream waits for the side streams before it queues a recurrence.
     A persistent recurrence wants every CU to itself (132 KB of LDS per workgroup).  Queued while weight-gradient workgroups of
     the side stream are still resident it is dealt out over whatever CUs come free first: the workgroup -> XCD order the
     XCD-local hand-off relies on can be lost, the in-launch vote then falls back to the placement-free form and that launch runs

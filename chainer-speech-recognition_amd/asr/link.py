@@ -98,7 +98,7 @@ class Link(torch.nn.Module):
 
 def _made_copy(stamp, value):
     """cache entry (stamp, value, origin, streams that have it): a copy made on one stream may be wanted on another one
-    (asr/pipeline.py runs two half batches on two streams).  No event is recorded when the copy is made -- every record is a
+    (asr/data/prefetch.py and evaluation passes launch from streams of their own).  No event is recorded when the copy is made -- every record is a
     marker packet the GPU spends 2-3 us on, forty of them behind the optimiser's refresh launch were a 115 us hole at the
     start of each step -- but only when a second stream first asks for the copy: an event recorded THEN on the stream of
     origin still lies behind the launch that made the copy."""

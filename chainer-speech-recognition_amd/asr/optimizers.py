@@ -40,7 +40,6 @@ class Optimizer(object):
         self._hooks = []
         self._flat = None
         self.communicator = None
-        self.pipeline = None
         self._needs_broadcast = False
         self._gave_up = [None, None, 0]     # pinned host copy of ctl[6] (give-up drops so far), event of that copy, update it was queued behind
         self._gave_up_reported = 0.0
@@ -65,10 +64,6 @@ class Optimizer(object):
             # forward pass would still run on the rank-local weights
             self._broadcast_state()
 
-    def set_pipeline(self, pipeline):
-        """asr.pipeline.HalfBatches whose streams carry gradient kernels the update must wait for"""
-        self.pipeline = pipeline
-
     def update(self, lossfun=None, *args, **kwds):
         if lossfun is not None:
             loss = lossfun(*args, **kwds)
@@ -83,8 +78,6 @@ class Optimizer(object):
                 raise
         self._ensure_flat()
         from .functions import join_side_stream
-        if self.pipeline is not None:
-            self.pipeline.join()            # gradient kernels of the two half batches (asr/pipeline.py)
         join_side_stream()                  # weight-gradient GEMMs issued on the side stream
         P, G = self._flat["P"], self._flat["G"]
         # every abort word of this process ORed into one device word; data parallel: a raised word also plants a NaN in the

@@ -101,8 +101,9 @@ class Communicator(object):
         return plan
 
     def begin_backward(self, opt, passes=1):
-        """`passes` backward passes will write the gradient buffer one after the other in program order (asr/pipeline.py:
-        two half batches, each on its own stream); a slice is reduced only after the LAST pass has announced it."""
+        """`passes` backward passes will write the gradient buffer one after the other in program order (gradient accumulation
+        over several minibatches before one update, end_pass() between them); a slice is reduced only after the LAST pass has
+        announced it."""
         opt._ensure_flat()
         flat = opt._flat
         self._plan = self.make_plan(flat["offsets"], flat["sizes"], self.buckets)
@@ -119,9 +120,8 @@ class Communicator(object):
         self.launch_log = []
         self._defer, self._met_recurrence = self._recurrent, False
         self._rec_count = 0
-        # two passes on two streams (asr/pipeline.py): the "no collective beside a recurrence" rule would have to hold on BOTH
-        # launch streams -- the other half's persistent recurrences keep starting while a collective queued from this pass is
-        # resident.  Nothing is launched before finish_backward then.
+        # several passes: nothing is launched before finish_backward (the earlier passes' recurrences would otherwise meet the
+        # collectives of a slice that is complete for THEIR pass only)
         self._hold_all = self._passes > 1
         self.exposed = []               # (event before, event after) around every join of the launch stream with the collectives
         if self.backend == "nccl" and self._stream is None:

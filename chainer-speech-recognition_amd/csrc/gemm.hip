@@ -1421,22 +1421,21 @@ using namespace asr::gemm;
 //   8192^3                                    963                    765                   953
 // Whole 128-B lines per row and K step are what pays (a 64-B half line per row leaves the other half to be fetched again
 // by the next K step once the tile no longer fits the L1), and only where the 256-wide tile removes a second pass over the
-// activations: the convolutions with more than 128 output channels.  ASR_NT_WIDE overrides (tests, experiments):
+// activations: the convolutions with more than 128 output channels.  ASR_DEBUG nt_wide overrides (tests, experiments):
 // -1 (default) = 64-wide K for those convolutions only; 0 = never; 1 / 2 = 256x256x32 / 256x256x64 wherever the shape allows.
 static int nt_wide_mode() {
     static int mode = -2;
     if (mode == -2) {
-        const char* e = getenv("ASR_NT_WIDE");
-        mode = e ? atoi(e) : -1;
+        mode = debug_flag("nt_wide", -1);
         if (mode < -1 || mode > 4) mode = -1;
     }
     return mode;
 }
 
-// ASR_NT_WIDE_FORCE=1 (tests): take the wide kernel whatever the number of tiles
+// ASR_DEBUG nt_wide_force=1 (tests): take the wide kernel whatever the number of tiles
 static bool nt_wide_force() {
     static int f = -1;
-    if (f < 0) { const char* e = getenv("ASR_NT_WIDE_FORCE"); f = e && atoi(e) ? 1 : 0; }
+    if (f < 0) f = debug_flag("nt_wide_force", 0) ? 1 : 0;
     return f == 1;
 }
 
@@ -1464,10 +1463,10 @@ static int launch_nt_wide(hipStream_t stream, const uint16_t* A, int lda, const 
 // Grid of the persistent kernels: a multiple of 256 workgroups (whole CUs; a multiple of 8 keeps bid % 8 = XCD for every tile a
 // workgroup walks over), chosen for the fewest rounds x the time of a tile when k workgroups share a CU (measured on 8192^3 and
 // 32000 x 1024 x 3072: a tile takes ~0.87 of the three-per-CU time at two per CU; one per CU leaves the fill latency bare).
-// ASR_NT_PERSIST_GRID overrides (experiments).
+// ASR_DEBUG nt_persist_grid overrides (experiments).
 static int nt_persist_grid(int total, int max_per_cu) {
     static int forced = -1;
-    if (forced < 0) { const char* e = getenv("ASR_NT_PERSIST_GRID"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) forced = debug_flag("nt_persist_grid", 0);
     if (forced > 0) return ((total < forced ? total : forced) + 7) & ~7;
     const float tile_time[4] = {0.f, 0.80f, 0.87f, 1.0f};
     int best = 256 * max_per_cu;
@@ -1503,11 +1502,11 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         }
     }
     // persistent form of the 256 x 128 kernel: vector stores want ldc % 8 == 0 and an aligned C (bias: 16-B aligned), 32-bit byte
-    // offsets want operands below 4 GB; ASR_NT_PERSIST=0 keeps the one-tile-per-workgroup kernel (tests, comparison)
+    // offsets want operands below 4 GB; ASR_DEBUG nt_persist=0 keeps the one-tile-per-workgroup kernel (tests, comparison)
     static int persist = -1;
-    if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
+    if (persist < 0) persist = debug_flag("nt_persist", 1);
     static int pmin = -1;
-    if (pmin < 0) { const char* e = getenv("ASR_NT_PERSIST_MIN"); pmin = e ? atoi(e) : 256; }      // (one tile per CU: 32000 x 384 x 3072 642 -> 688, x 320 x 3008 532 -> 604 TFLOP/s against the 128 x 128 kernel)
+    if (pmin < 0) pmin = debug_flag("nt_persist_min", 256);      // (one tile per CU: 32000 x 384 x 3072 642 -> 688, x 320 x 3008 532 -> 604 TFLOP/s against the 128 x 128 kernel)
     const bool k_tail = (K % B2K) != 0;       // K = 3000 (the logit gradient): the last K step is fetched short, see the kernel's KT
     if (persist && aligned && (K % 8) == 0 && K >= B2K && (long long)cdiv(M, B2M) * cdiv(N, B2N) >= pmin && (ldc % 8) == 0 && (((uintptr_t)C) & 15) == 0 &&
         (!bias || (((uintptr_t)bias) & 15) == 0) && (unsigned long long)M * lda < (1ull << 31) && (unsigned long long)N * ldb < (1ull << 31) && M < (1 << 24) && N < (1 << 24) &&
@@ -1586,24 +1585,24 @@ static int tn_splits(int tiles, int K, int& k_per_split, int target = 768, bool 
 // grid of the 128 x 128 TN kernel: the (split, tile) pairs in eight equal contiguous runs, one per XCD
 static int tn_grid(int tiles, int splits) { return 8 * cdiv(tiles * splits, 8); }
 
-// what gemm_tn_vec_kernel asks of a product (ASR_TN_VEC=0 keeps the general kernel: tests, comparison)
+// what gemm_tn_vec_kernel asks of a product (ASR_DEBUG tn_vec=0 keeps the general kernel: tests, comparison)
 static bool tn_vec_ok(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("ASR_TN_VEC"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = debug_flag("tn_vec", 1);
     if (!on) return false;
     return (M & 7) == 0 && (N & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0 &&
            (unsigned long long)K * lda * 2 < 0xfffffff0ull && (unsigned long long)K * ldb * 2 < 0xfffffff0ull;
 }
 
 // the 256 x 128 LDS-DMA kernel wants whole 16-B chunks (M, lda, ldb multiples of 8, aligned bases) and at least one full tile
-// of rows; ASR_TN256=0 keeps the 128 x 128 kernel (tests, comparison)
+// of rows; ASR_DEBUG tn256=0 keeps the 128 x 128 kernel (tests, comparison)
 // Measured (tools/time_nt.py, TFLOP/s, 256 x 128 LDS-DMA kernel at two workgroups per CU against the 128 x 128 kernel at four):
 // convolution weight gradients 128->256: 668 / 638, 128->512: 783 / 745, 256->512: 823 / 737 -- but 3072 x 512 x 32000: 541 / 680,
 // 1536 x 512: 387 / 555 (half the workgroups in flight and twice the atomics per workgroup behind a K split of the same depth).
-// So it serves the implicit convolutions only; ASR_TN256=2 sends the plain products there as well (tests), 0 switches it off.
+// So it serves the implicit convolutions only; ASR_DEBUG tn256=2 sends the plain products there as well (tests), 0 switches it off.
 static bool tn256_ok(int M, int lda, int ldb, const void* A, const void* B, bool conv) {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("ASR_TN256"); on = e ? atoi(e) : 1; }
+    if (on < 0) on = debug_flag("tn256", 1);
     if (!on || (!conv && on != 2)) return false;
     return M >= T2M && (M & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15) == 0;
 }
@@ -1660,7 +1659,7 @@ extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A,
     hipStream_t stream = (hipStream_t)stream_;
     int k_per_split;
     static int target = 0;
-    if (!target) { const char* e = getenv("ASR_TN_GROUP_TARGET"); target = e ? atoi(e) : 1152; if (target < 1) target = 1152; }
+    if (!target) { target = debug_flag("tn_group_target", 1152); if (target < 1) target = 1152; }
     const int splits = tn_splits(tiles, kmax, k_per_split, target, true);
     const TnProb& q = grp.p[0];
     if (vec)
@@ -1763,7 +1762,7 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     // persistent form (K pipeline across tiles, register epilogue): channels a multiple of the K step, whole 16-B stores
     {
         static int persist = -1;
-        if (persist < 0) { const char* e = getenv("ASR_NT_PERSIST"); persist = e ? atoi(e) : 1; }
+        if (persist < 0) persist = debug_flag("nt_persist", 1);
         const unsigned long long xbytes = (unsigned long long)Ts * B * Hs * Cs * 2;
         const int cmode = (Cs % B2K) == 0 ? 1 : (Cs == 8 ? 2 : 0);
         if (persist && cmode && (N % 8) == 0 && Hs < 256 && xbytes < 0xfffffff0ull && (((uintptr_t)out) & 15) == 0 &&

@@ -311,277 +311,7 @@ __device__ __forceinline__ bool wait_counter(unsigned* counter, unsigned target,
     }
 }
 
-template <int KSW>
-__global__ __launch_bounds__(256) void fwd_persistent_kernel(const float* __restrict__ gi,
-                                                             const uint16_t* __restrict__ whh,
-                                                             const float* __restrict__ bhh, float* __restrict__ hseq,
-                                                             uint16_t* hseq16, float* __restrict__ gates,
-                                                             unsigned* sync, int T, int B, int H, int ndir) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MT][3][64]
-    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * MT * 3 * 64);
-    const int d = blockIdx.y, j0 = blockIdx.x * 16, nwg = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nks = H >> 5;
-    const size_t hs = (size_t)ndir * H;
-    unsigned* counter = sync + d * 64;
-    unsigned* abort_word = sync + 1023;
-    const __amdgpu_buffer_rsrc_t h16rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)hseq16, 0, (int)((size_t)T * B * hs * 2), 0x00020000);
-
-    // stationary operand: this wave's K slices of the workgroup's 3 x 16 rows of W_hh
-    Frag bb[KSW][3];
-#pragma unroll
-    for (int i = 0; i < KSW; ++i) {
-        const int ks = w * KSW + i;
-        const int k = ks * 32 + 8 * (lane >> 4);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-            bb[i][g].u = ks < nks ? *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + g) * H + j0 + (lane & 15)) * H + k)
-                                  : make_uint4(0, 0, 0, 0);
-    }
-    // element-wise role: batch row b, hidden units j0 + 2*jp, j0 + 2*jp + 1
-    const int b = tid >> 3, jp = tid & 7, j = j0 + 2 * jp;
-    const bool act = b < B;
-    float bh[3][2];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        bh[g][0] = bhh[(d * 3 + g) * H + j];
-        bh[g][1] = bhh[(d * 3 + g) * H + j + 1];
-    }
-    float hprev[2] = {0.f, 0.f};
-    if (tid == 0) *s_abort = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? s : T - 1 - s;
-        const int tp = d == 0 ? t - 1 : t + 1;
-        const size_t rowi = (size_t)t * B + (act ? b : 0);
-        float2 egi[3];
-        {
-            const float* gir = gi + rowi * (3 * hs) + (size_t)d * 3 * H + j;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) egi[g] = act ? *reinterpret_cast<const float2*>(gir + g * H) : make_float2(0.f, 0.f);
-        }
-        float gh[3][2];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { gh[g][0] = bh[g][0]; gh[g][1] = bh[g][1]; }
-        if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
-            __syncthreads();
-            if (*s_abort) break;
-            f32x4 acc[MT][3];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc[m][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            Frag a[KSW][MT];
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const int ks = w * KSW + i;
-                const int k = ks * 32 + 8 * (lane >> 4);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = m * 16 + (lane & 15);
-                    const bool ok = ks < nks && row < B;
-                    const unsigned off = (unsigned)((((size_t)tp * B + (ok ? row : 0)) * hs + d * H + (ok ? k : 0)) * 2);
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h16rsrc, off, 0, 16 /* sc1 */);
-                    a[i][m].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KSW; ++i)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i][g].v, acc[m][g], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    part[((w * MT + m) * 3 + g) * 64 + lane] = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
-            __syncthreads();
-            if (act) {
-                const int m = b >> 4, row = b & 15, pr = row & 3;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int pl = (row >> 2) * 16 + 2 * jp + e;
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-#pragma unroll
-                        for (int ww = 0; ww < 4; ++ww) {
-                            const float4 v = part[((ww * MT + m) * 3 + g) * 64 + pl];
-                            gh[g][e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
-                        }
-                }
-            }
-        }
-        float r[2], z[2], n[2], h[2];
-        {
-            const float gir[3][2] = {{egi[0].x, egi[0].y}, {egi[1].x, egi[1].y}, {egi[2].x, egi[2].y}};
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                r[e] = sigmoidf_(gir[0][e] + gh[0][e]);
-                z[e] = sigmoidf_(gir[1][e] + gh[1][e]);
-                n[e] = tanhf_(gir[2][e] + r[e] * gh[2][e]);
-                h[e] = (1.0f - z[e]) * n[e] + z[e] * hprev[e];
-                hprev[e] = h[e];
-            }
-        }
-        const size_t o = rowi * hs + d * H + j;
-        if (act) {
-            const unsigned packed = (unsigned)f32_to_bf16(h[0]) | ((unsigned)f32_to_bf16(h[1]) << 16);
-            __hip_atomic_store(reinterpret_cast<unsigned*>(hseq16 + o), packed, ASR_RLX_AGENT);     // sc1 payload
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its payload before the signal
-        __syncthreads();                                    // (barriers stay in uniform control flow)
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
-        if (act) {
-            // what only the backward pass reads goes out after the signal (drained by the next step's wait)
-            *reinterpret_cast<float2*>(hseq + o) = make_float2(h[0], h[1]);
-            float* gs = gates + (rowi * ndir + d) * 4 * H + j;
-            *reinterpret_cast<float2*>(gs) = make_float2(r[0], r[1]);
-            *reinterpret_cast<float2*>(gs + H) = make_float2(z[0], z[1]);
-            *reinterpret_cast<float2*>(gs + 2 * H) = make_float2(n[0], n[1]);
-            *reinterpret_cast<float2*>(gs + 3 * H) = make_float2(gh[2][0], gh[2][1]);
-        }
-    }
-}
-
-template <int KSW>
-__global__ __launch_bounds__(256) void bwd_persistent_kernel(const uint16_t* __restrict__ dy,
-                                                             const float* __restrict__ gates,
-                                                             const float* __restrict__ hseq,
-                                                             const uint16_t* __restrict__ whhT,
-                                                             uint16_t* __restrict__ dgi, uint16_t* dgh, unsigned* sync,
-                                                             int T, int B, int H, int ndir) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                       // [4 waves][MT][64]
-    int* s_abort = reinterpret_cast<int*>(smem + sizeof(float4) * 4 * MT * 64);
-    const int d = blockIdx.y, j0 = blockIdx.x * 16, nwg = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nks = (3 * H) >> 5;
-    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + d * 64;
-    unsigned* abort_word = sync + 1023;
-    const __amdgpu_buffer_rsrc_t dghrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
-
-    Frag bb[KSW];
-#pragma unroll
-    for (int i = 0; i < KSW; ++i) {
-        const int ks = i * 4 + w;
-        const int k = ks * 32 + 8 * (lane >> 4);
-        bb[i].u = ks < nks ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k)
-                           : make_uint4(0, 0, 0, 0);
-    }
-    const int b = tid >> 3, jp = tid & 7, j = j0 + 2 * jp;
-    const bool act = b < B;
-    float carry[2] = {0.f, 0.f};
-    if (tid == 0) *s_abort = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? T - 1 - s : s;
-        const int tn = d == 0 ? t + 1 : t - 1;
-        const int tp = d == 0 ? t - 1 : t + 1;
-        const bool has_prev = d == 0 ? t > 0 : t < T - 1;
-        const size_t rowi = (size_t)t * B + (act ? b : 0);
-        // operands that do not depend on the other workgroups: issue before the wait
-        const unsigned dyp = act ? *reinterpret_cast<const unsigned*>(dy + rowi * H + j) : 0u;
-        const float* gs = gates + (rowi * ndir + d) * 4 * H + j;
-        float2 eg[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) eg[g] = act ? *reinterpret_cast<const float2*>(gs + g * H) : make_float2(0.f, 0.f);
-        const float2 ehp = (act && has_prev) ? *reinterpret_cast<const float2*>(hseq + ((size_t)tp * B + b) * hs + d * H + j)
-                                             : make_float2(0.f, 0.f);
-        float dh[2] = {bf16_to_f32((uint16_t)(dyp & 0xffff)) + carry[0], bf16_to_f32((uint16_t)(dyp >> 16)) + carry[1]};
-        if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
-            __syncthreads();
-            if (*s_abort) break;
-            f32x4 acc[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            Frag a[KSW][MT];
-#pragma unroll
-            for (int i = 0; i < KSW; ++i) {
-                const int ks = i * 4 + w;
-                const int k = ks * 32 + 8 * (lane >> 4);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int row = m * 16 + (lane & 15);
-                    const bool ok = ks < nks && row < B;
-                    const unsigned off = (unsigned)((((size_t)tn * B + (ok ? row : 0)) * gs3 + (size_t)d * 3 * H + (ok ? k : 0)) * 2);
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
-                    a[i][m].u = ok ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < KSW; ++i)
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m].v, bb[i].v, acc[m], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                part[(w * MT + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
-            __syncthreads();
-            if (act) {
-                const int m = b >> 4, row = b & 15, pr = row & 3;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int pl = (row >> 2) * 16 + 2 * jp + e;
-#pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) {
-                        const float4 v = part[(ww * MT + m) * 64 + pl];
-                        dh[e] += pr == 0 ? v.x : (pr == 1 ? v.y : (pr == 2 ? v.z : v.w));
-                    }
-                }
-            }
-        }
-        unsigned pr_, pz_, pn_, pq_;
-        {
-            const float r[2] = {eg[0].x, eg[0].y}, z[2] = {eg[1].x, eg[1].y}, n[2] = {eg[2].x, eg[2].y}, qq[2] = {eg[3].x, eg[3].y};
-            const float hp[2] = {ehp.x, ehp.y};
-            uint16_t ar[2], az[2], an[2], aq[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float dn = dh[e] * (1.0f - z[e]);
-                const float dz = dh[e] * (hp[e] - n[e]);
-                const float dan = dn * (1.0f - n[e] * n[e]);
-                const float daz = dz * z[e] * (1.0f - z[e]);
-                const float dq = dan * r[e];
-                const float dar = dan * qq[e] * r[e] * (1.0f - r[e]);
-                carry[e] = dh[e] * z[e];
-                ar[e] = f32_to_bf16(dar); az[e] = f32_to_bf16(daz); an[e] = f32_to_bf16(dan); aq[e] = f32_to_bf16(dq);
-            }
-            pr_ = (unsigned)ar[0] | ((unsigned)ar[1] << 16); pz_ = (unsigned)az[0] | ((unsigned)az[1] << 16);
-            pn_ = (unsigned)an[0] | ((unsigned)an[1] << 16); pq_ = (unsigned)aq[0] | ((unsigned)aq[1] << 16);
-        }
-        const size_t o = rowi * gs3 + (size_t)d * 3 * H + j;
-        if (act) {
-            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);           // sc1 payload
-            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
-            __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
-        if (act) {
-            *reinterpret_cast<unsigned*>(dgi + o) = pr_;
-            *reinterpret_cast<unsigned*>(dgi + o + H) = pz_;
-            *reinterpret_cast<unsigned*>(dgi + o + 2 * H) = pn_;
-        }
-    }
-}
-
-// Backward, non-grouped persistent form with I/O waves: the counter hand-off of bwd_persistent_kernel (32 workgroups per
-// direction, 16 units each, 4 compute waves splitting K = 3H), but the HBM streams (dy, saved gates, h_prev in; dgi out)
-// are carried by wave 4 (loader, LDS ring, two steps of loads in flight) and wave 5 (storer, one step behind).  Memory
-// operations of a wave retire in issue order, so in the plain kernel every step's hand-off loads queued behind that
-// step's HBM loads.  Bias gradients are summed over time in registers (no column-sum pass over dgi / dgh afterwards).
+// depth (time steps) of the LDS operand rings the loader waves of the persistent kernels fill by LDS-DMA
 constexpr int BIO_GD = 4;
 #define ASR_RLX_WG __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
 
@@ -624,7 +354,7 @@ __device__ __forceinline__ void lds_poke(int* p, int v) { *(lds_vint*)(__attribu
 // value of lane ^ 1 through DPP quad_perm [1,0,3,2]: __shfl_xor compiles to ds_bpermute, an LDS round trip on the chain
 // between the gate math and the payload store
 // the pause in front of a first poll: one s_sleep with an immediate for the values the host hands out (a loop of s_sleep(1) costs
-// the chain ~0.02 us more: 1.369 against 1.347 us per step), the loop for anything else (ASR_GRU_POLL_DELAY)
+// the chain ~0.02 us more: 1.369 against 1.347 us per step), the loop for anything else (ASR_DEBUG gru_poll_delay)
 __device__ __forceinline__ void poll_pause(int n) {
     if (n == 6) __builtin_amdgcn_s_sleep(6);
     else if (n == 3) __builtin_amdgcn_s_sleep(3);
@@ -751,266 +481,6 @@ constexpr int BIO_SLOT = 5 * 512 + 256;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 #define ASR_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-template <int KSW, bool LOCAL>
-__global__ __launch_bounds__(384, 3) void bwd_persistent_io_kernel(const uint16_t* __restrict__ dy,
-                                                                   const float* __restrict__ gates,
-                                                                   const float* __restrict__ hseq,
-                                                                   const uint16_t* __restrict__ whhT,
-                                                                   uint16_t* __restrict__ dgi, uint16_t* dgh,
-                                                                   float* __restrict__ db_ih, float* __restrict__ db_hh,
-                                                                   unsigned* sync, int T, int B, int H, int ndir, int rows,
-                                                                   int forge) {
-    // 384 threads, at most 168 VGPRs (3 waves per SIMD): a 256-thread GEMM workgroup of the side stream fits beside this
-    // workgroup on the same CU and runs in the gaps of the latency-bound recurrence.
-    // Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would also wait for the loader's LDS-DMA in flight.
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part = reinterpret_cast<float4*>(smem);                                   // [4 waves][64]
-    char* opring = smem + 4 * 64 * 16;                                                // [BIO_GD][BIO_SLOT]
-    unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);       // [2][3: ar az an][8 rows][8 pairs]
-    int* s_abort = reinterpret_cast<int*>(oring + 2 * 3 * 8 * 8);
-    // LOCAL: a 1-D grid of 8 x H/16 workgroups; the hardware deals workgroup ids round-robin over the 8 XCDs, so
-    // recurrence (d, g) = id % 8 has all its workgroups on one XCD and may hand off through that XCD's L2
-    const int G_ = LOCAL ? (B + rows - 1) / rows : (int)gridDim.y;
-    const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
-    if (LOCAL && rec >= G_ * ndir) return;
-    const int d = rec / G_, g = rec % G_;
-    const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
-    const int b0 = g * rows, Bl = min(rows, B - b0);      // this recurrence's batch rows (at most 8)
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
-    const int nks = (3 * H) >> 5;
-    constexpr bool PAIRED = KSW % 2 == 0;
-    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* shards = shard_base(sync, rec);
-    unsigned* my_shard = shards + ((j0 >> 4) % NSH) * 32;
-    unsigned* abort_word = sync + 1023;
-    const __amdgpu_buffer_rsrc_t dghrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)dgh, 0, (int)((size_t)T * B * gs3 * 2), 0x00020000);
-    const long long tstep = d == 0 ? -1 : 1;
-    const int tfirst = d == 0 ? T - 1 : 0;
-
-    // ---- loader (wave 4): lanes 0..31 fetch (row lane / 4, units 4 (lane % 4) ..) of each f32 array, lanes 0..15 the
-    // bf16 dy row halves; addresses advance by a constant stride per step
-    const int lrow = lane >> 2, lyrow = lane >> 1;
-    const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 3) * 4;
-    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
-                       (size_t)d * H + j0 + (lane & 3) * 4;          // not dereferenced for the last step
-    const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 1) * 8;
-    const long long lgs = tstep * (long long)B * ndir * 4 * H, lhs = tstep * (long long)B * (long long)hs, lys = tstep * (long long)B * H;
-    auto issue = [&](int sq) {
-        if (sq < T) {
-            char* slot = opring + (sq % BIO_GD) * BIO_SLOT;
-            if (lane < 32 && lrow < Bl) {
-#pragma unroll
-                for (int arr = 0; arr < 4; ++arr)
-                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + (size_t)arr * H), (lds_ptr_t)(slot + arr * 512), 16, 0, 0);
-                if (sq < T - 1) __builtin_amdgcn_global_load_lds((glb_ptr_t)lhp, (lds_ptr_t)(slot + 4 * 512), 16, 0, 0);
-            }
-            if (lane < 16 && lyrow < Bl) __builtin_amdgcn_global_load_lds((glb_ptr_t)lyp, (lds_ptr_t)(slot + 5 * 512), 16, 0, 0);
-        }
-        lgp += lgs; lhp += lhs; lyp += lys;
-    };
-    // ---- storer (wave 5): dgi rows of 16 bf16 = 32 B = 2 pieces; 3 gates x 8 rows x 2 = 48 pieces, one per lane
-    auto store_step = [&](int sp) {
-        const long long tq = tfirst + tstep * sp;
-        const unsigned* src = oring + (size_t)(sp & 1) * 3 * 8 * 8;
-        const int gsel = lane >> 4, row = (lane & 15) >> 1, c4 = (lane & 1) * 4;
-        if (lane < 48 && row < Bl)
-            *reinterpret_cast<uint4*>(dgi + ((size_t)tq * B + b0 + row) * gs3 + (size_t)d * 3 * H + gsel * H + j0 + c4 * 2) =
-                *reinterpret_cast<const uint4*>(src + (gsel * 8 + row) * 8 + c4);
-    };
-    if (is_loader) {
-        for (int s0 = 0; s0 < BIO_GD - 1; ++s0) issue(s0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    Frag bb[KSW];
-    if (is_compute) {
-        __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-        for (int i = 0; i < KSW; ++i) {
-            // PAIRED: this wave's slices come in adjacent pairs (2p, 2p + 1), p = (i / 2) * 4 + w, so that one load
-            // instruction can fetch both (a whole 128-B line per row) -- see the step loop
-            const int ks = PAIRED ? (((i >> 1) * 4 + w) * 2 + (i & 1)) : i * 4 + w;
-            const int k = ks * 32 + 8 * (lane >> 4);
-            bb[i].u = ks < nks ? *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j0 + (lane & 15)) * (3 * H) + k)
-                               : make_uint4(0, 0, 0, 0);
-        }
-    }
-    // gate phase on waves 2 and 3 (they do not share a SIMD with the I/O waves): thread (row (tid - 128) / 16, unit tid % 16)
-    const int b = ((tid - 128) >> 4) & 7, u0 = tid & 15;
-    const int j = j0 + (u0 & ~1);                              // the even unit of the stored pair
-    const bool gate_wave = tid >= 128 && tid < 256;
-    const bool act = gate_wave && b < Bl;
-    constexpr int kPoller = 128;                               // first lane of wave 2
-    float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid == 0) {
-        *s_abort = 0;
-        s_abort[1] = 0;
-        if (LOCAL) {
-            const int v = decide_local(sync, rec, nwg, abort_word, forge);
-            if (v < 0) *s_abort = 1; else s_abort[1] = v;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    ASR_RAW_BARRIER();
-    const bool local = LOCAL && s_abort[1] != 0;
-
-#ifdef ASR_STAMP
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memrealtime();
-#define ASR_ST(i) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += n_ - st_last; st_last = n_; }
-#else
-#define ASR_ST(i)
-#endif
-    for (int s = 0; s < T; ++s) {
-        const int t = d == 0 ? T - 1 - s : s;
-        const int tn = d == 0 ? t + 1 : t - 1;
-        float rcr = 0.f;
-        // this step's operands (in the ring since at least two steps ago) are read before the wait, off the chain
-        float dyy = 0.f, r = 0.f, z = 0.f, n = 0.f, qq = 0.f, hp = 0.f;
-        if (gate_wave) {
-            const char* slot = opring + (s % BIO_GD) * BIO_SLOT;
-            const float* of = reinterpret_cast<const float*>(slot) + b * 16 + u0;
-            r = of[0]; z = of[128]; n = of[256]; qq = of[384];
-            hp = s < T - 1 ? of[512] : 0.f;
-            dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(slot + 5 * 512)[b * 16 + u0]);
-        }
-        if (s > 0) {
-            if (local) {        // one line of per-producer flags, polled by the whole wave 2 with a single load
-                if (w == 2 && !wait_flags(shards, nwg, (unsigned)s, abort_word, lane) && lane == 0) *s_abort = 1;
-            } else if (tid == kPoller && !wait_shards<false>(shards, nwg, (unsigned)s, abort_word)) {
-                *s_abort = 1;   // placement-free form: sharded agent-scope counters (flag stores to one line were slower there)
-            }
-            ASR_ST(0)
-            ASR_RAW_BARRIER();
-            ASR_ST(1)
-            if (*s_abort) break;
-            if (is_compute) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (PAIRED) {
-                    // the MFMA tile has 16 rows and the recurrence 8: lanes of tile rows 8..15 fetch the NEXT K slice of
-                    // rows 0..7 instead of idling, so each load instruction brings two slices (half as many instructions
-                    // and whole 128-B lines); a DPP row rotate moves them to rows 0..7 for the second MFMA.  Tile rows
-                    // 8..15 then hold real but unrelated data: their output rows are never read.
-                    Frag a[(KSW + 1) / 2];
-#pragma unroll
-                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
-                        const int r16 = lane & 15, row = r16 & 7;
-                        const int ks = ((i2 * 4 + w) * 2) + (r16 >> 3);
-                        const int k = ks * 32 + 8 * (lane >> 4);
-                        a[i2].u = make_uint4(0, 0, 0, 0);
-                        if (ks < nks && row < Bl) {      // masked lanes send no request
-                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1: bypasses the L1, served by the L2 */);
-                            a[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
-                        }
-                    }
-#pragma unroll
-                    for (int i2 = 0; i2 < KSW / 2; ++i2) {
-                        Frag a1;
-                        a1.u = swap_half_rows(a[i2].u);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i2].v, bb[2 * i2].v, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v, bb[2 * i2 + 1].v, acc, 0, 0, 0);
-                    }
-                } else {
-                    Frag a[KSW];
-#pragma unroll
-                    for (int i = 0; i < KSW; ++i) {
-                        const int ks = i * 4 + w;
-                        const int k = ks * 32 + 8 * (lane >> 4);
-                        const int row = lane & 15;
-                        // (an out-of-range descriptor offset also returns zeros, but measured 2.3 us slower per step)
-                        a[i].u = make_uint4(0, 0, 0, 0);
-                        if (ks < nks && row < Bl) {
-                            const unsigned off = (unsigned)((((size_t)tn * B + b0 + row) * gs3 + (size_t)d * 3 * H + k) * 2);
-                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dghrsrc, off, 0, 16 /* sc1 */);
-                            a[i].u = make_uint4(v[0], v[1], v[2], v[3]);
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < KSW; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
-                }
-                if (lane < 32) part[w * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);      // live rows 0..7 only
-            }
-            ASR_ST(2)
-            ASR_RAW_BARRIER();
-            ASR_ST(3)
-            if (act) {
-                // one scalar LDS read per partial: selecting a component of a float4 by a runtime index compiles to a
-                // nest of divergent branches around narrow reads (measured 0.95 us per step) -- here the index is part of the address
-                const float* pf = reinterpret_cast<const float*>(part) + ((b >> 2) * 16 + u0) * 4 + (b & 3);
-#pragma unroll
-                for (int ww = 0; ww < 4; ++ww) rcr += pf[ww * 256];
-            }
-        }
-        if (is_loader) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot issued one step ago has landed (read two steps from now)
-            issue(s + BIO_GD - 1);
-        } else if (is_storer) {
-            if (s > 0) store_step(s - 1);
-        } else if (gate_wave) {
-            const float dh = dyy + carry + rcr;
-            const float dn = dh * (1.0f - z);
-            const float dz = dh * (hp - n);
-            const float dan = dn * (1.0f - n * n);
-            const float daz = dz * z * (1.0f - z);
-            const float dq = dan * r;
-            const float dar = dan * qq * r * (1.0f - r);
-            carry = dh * z;
-            const uint16_t ar = f32_to_bf16(dar), az = f32_to_bf16(daz), an = f32_to_bf16(dan), aq = f32_to_bf16(dq);
-            if (act) {      // bias gradients see the bf16-rounded values the weight-gradient GEMMs see
-                sb[0] += bf16_to_f32(ar); sb[1] += bf16_to_f32(az); sb[2] += bf16_to_f32(an); sb[3] += bf16_to_f32(aq);
-            }
-            // neighbouring lanes hold the two units of a pair: the even lane stores r and z, the odd lane q and n
-            const unsigned m1 = (unsigned)ar | ((unsigned)az << 16), m2 = (unsigned)an | ((unsigned)aq << 16);
-            const unsigned o1 = lane_xor1_u32(m1), o2 = lane_xor1_u32(m2);
-            const bool odd = u0 & 1;
-            const unsigned e1 = odd ? o1 : m1, d1 = odd ? m1 : o1, e2 = odd ? o2 : m2, d2 = odd ? m2 : o2;   // e: even unit, d: odd unit
-            const unsigned pr_ = (e1 & 0xffffu) | (d1 << 16), pz_ = (e1 >> 16) | (d1 & 0xffff0000u);
-            const unsigned pn_ = (e2 & 0xffffu) | (d2 << 16), pq_ = (e2 >> 16) | (d2 & 0xffff0000u);
-            const size_t o = ((size_t)t * B + b0 + b) * gs3 + (size_t)d * 3 * H + j;
-            unsigned* od = oring + (size_t)(s & 1) * 3 * 8 * 8 + b * 8 + (u0 >> 1);
-            if (act && !odd) {
-                if (local) {        // plain stores: the line stays in this XCD's L2, where the consumers read it
-                    __builtin_amdgcn_raw_buffer_store_b32(pr_, dghrsrc, (unsigned)(o * 2), 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(pz_, dghrsrc, (unsigned)((o + H) * 2), 0, 0);
-                } else {            // sc1 write-through payload
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o), pr_, ASR_RLX_AGENT);
-                    __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + H), pz_, ASR_RLX_AGENT);
-                }
-                od[0] = pr_;
-            }
-            if (act && odd) {
-                if (local) __builtin_amdgcn_raw_buffer_store_b32(pq_, dghrsrc, (unsigned)((o + 2 * H) * 2), 0, 0);
-                else __hip_atomic_store(reinterpret_cast<unsigned*>(dgh + o + 2 * H), pq_, ASR_RLX_AGENT);
-                od[8 * 8] = pz_; od[2 * 8 * 8] = pn_;
-            }
-            ASR_ST(4)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ASR_ST(5)
-        }
-        ASR_RAW_BARRIER();
-        ASR_ST(6)
-        if (tid == kPoller) {
-            if (local) set_flag(shards + (j0 >> 4), (unsigned)s + 1u, true);
-            else __hip_atomic_fetch_add(my_shard, 1u, ASR_RLX_AGENT);
-        }
-    }
-#ifdef ASR_STAMP
-    if (blockIdx.x < 8 && lane == 0)
-        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(sync + 1024)[((blockIdx.x * 6) + w) * 8 + i] = st_acc[i];
-#endif
-    if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may outlive the workgroup
-    ASR_RAW_BARRIER();
-    if (is_storer && !*s_abort) store_step(T - 1);
-    if (act && db_ih && db_hh) {
-        float* bi = db_ih + (size_t)d * 3 * H + j0 + u0;
-        float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0;
-        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
-        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
-    }
-#undef ASR_ST
-}
 
 // ---- wide form: 32 hidden units per workgroup, recurrences of 4 batch rows ------------------------------------------
 // The hand-off load phase scales with the payload bytes per CU (rows x K x 2 B, whatever the instruction form: section 5
@@ -1666,7 +1136,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 #endif
 }
 
-// Forward twin of bwd_persistent_io_kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
+// The default forward kernel: 16 hidden units per workgroup, batch rows in independent recurrences of at
 // most 8 rows, 4 compute waves (K = H split in 4) + loader (gi ring) + storer (f32 state and the four saved gate arrays,
 // one step behind).  The exchanged payload is the bf16 h row (hseq16), written sc1 by the gate threads themselves.
 // Raw barriers (s_barrier + lgkmcnt(0)): __syncthreads() would also wait for the loader's LDS-DMA in flight.
@@ -2144,7 +1614,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 f32x4 acc[3];
 #pragma unroll
                 for (int gg = 0; gg < 3; ++gg) acc[gg] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (PAIRED) {       // two K slices per load instruction (see bwd_persistent_io_kernel)
+                if (PAIRED) {       // two K slices per load instruction (the 16-row MFMA tile has 8 idle rows: their lanes fetch the next slice)
                     Frag (&a)[NA] = acur;
                     unsigned spins = 0;
                     // the first attempt is issued outside the retry loop: at a loop header the compiler waits vmcnt(0) for
@@ -2521,462 +1991,6 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
     if (is_storer && !*s_abort) store_step(T - 1);
 }
 
-// ================================================================================================ grouped persistent form
-// The recurrence is independent across utterances, so the batch is cut into groups of RG = 8 rows and a group's
-// workgroups only ever talk to each other: 8 workgroups (64 hidden units each, 512 threads) hold the whole W_hh of one
-// direction in registers for those 8 rows.  Per step a workgroup now waits for 8 arrivals instead of 32 and pulls
-// 8 KB (forward, h) / 24 KB (backward, dgh) instead of 32 / 96 KB -- the two terms of the step's latency chain that
-// scaled with the batch.  Waves: 4 over the workgroup's units (16 each = one MFMA tile per gate) x 2 over K; the K = 1
-// half parks its partial tile in LDS, the K = 0 half adds it and does the gate math in the accumulator layout
-// (lane = unit, register = batch row), so no transposition is needed.  Bias gradients are summed over time in registers.
-constexpr int RG = 8;
-
-__device__ __forceinline__ float lane_xor1(float v) { return __shfl_xor(v, 1, 64); }
-
-// Hand-off inside a group: DATA-TAGGED GRANULES (MI355X_MICROARCH.md, R2 "the data IS the flag").  A granule is one
-// naturally aligned 8-byte word {tag = step + 1, two bf16 values}, written by ONE sc1 store and read with 16-byte sc1
-// loads; a wave re-reads its K slice until every tag carries the step it waits for.  No drain, no counter, no poll of a
-// separate word: the chain per step is store -> visible -> load.  The exchange buffer is double-buffered by step
-// parity (a workgroup can only start step s+1 after every workgroup of its group has published step s, i.e. after they
-// all finished reading step s-1) and zeroed by the launch function, so stale tags never match.
-typedef unsigned long long u64;
-
-// returns false on time-out (abort word raised); lanes with !need are ignored
-template <int N>
-__device__ __forceinline__ bool load_granules(const __amdgpu_buffer_rsrc_t& rsrc, const unsigned (&off)[N], bool need,
-                                              unsigned tag, Frag (&out)[N], unsigned* abort_word) {
-    for (unsigned spins = 0;; ++spins) {
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i], 0, 16 /* sc1 */);
-            const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[i] + 16, 0, 16 /* sc1 */);
-            ok = ok && lo[1] == tag && lo[3] == tag && hi[1] == tag && hi[3] == tag;
-            out[i].u = make_uint4(lo[0], lo[2], hi[0], hi[2]);
-        }
-        if (__all(ok || !need)) return true;
-        if ((spins & 63u) == 63u) {
-            if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) return false;
-            if (spins > kSpinLimit) {
-                __hip_atomic_store(abort_word, 1u, ASR_RLX_AGENT);
-                return false;
-            }
-        }
-    }
-}
-
-// Forward group kernel: 8 compute waves + 2 I/O waves, 32 hidden units per workgroup.  Memory operations of a wave
-// retire in issue order, so an HBM load or store issued by a compute wave would sit in front of its hand-off loads and put
-// the HBM latency (3-4 us with the strided gi rows) on the step-to-step chain.  The compute waves therefore touch only
-// the exchange buffer and LDS:
-//   waves 0..7  2 unit tiles x 4 K quarters; K quarter 0, lanes 0..31 also do the gate math (lane = unit, register = row)
-//   wave 8 (loader)  streams gi[t] for steps s+1 .. s+GD into an LDS ring, two steps of loads in flight in registers
-//   wave 9 (storer)  writes what the backward pass / the next layer read later (f32 state, gates, bf16 copy) from an
-//                    LDS double buffer, one step behind
-// All ten waves meet at ONE barrier per step.
-constexpr int GD = 4;                          // depth of the gi ring (steps)
-constexpr int UW = 32;                         // hidden units per workgroup
-
-template <int KSF>      // K steps (of 32) per compute wave = H / 128
-__global__ __launch_bounds__(640) void fwd_group_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
-                                                        const float* __restrict__ bhh, float* __restrict__ hseq,
-                                                        uint16_t* __restrict__ hseq16, float* __restrict__ gates,
-                                                        unsigned* sync, u64* xbuf, int T, int B, int H, int ndir) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part0 = reinterpret_cast<float4*>(smem);                      // [step parity][3 K quarters][2 tiles][3 gates][64 lanes]
-    constexpr int kPartStep = 3 * 2 * 3 * 64;
-    float* giring = reinterpret_cast<float*>(smem + sizeof(float4) * 2 * kPartStep);       // [GD][3 gates][RG][UW]
-    float* oring = giring + GD * 3 * RG * UW;                                               // [2][5][RG][UW]
-    int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * RG * UW);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 1, wk = ((w >> 1) + 3) & 3;   // K quarter 0 = waves 2, 3:
-    // waves are dealt to the four SIMDs cyclically, so the gate-math waves do not share a SIMD with the I/O waves 8, 9
-    const bool is_loader = w == 8, is_storer = w == 9, is_compute = w < 8;
-    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y;
-    const int ublk = blockIdx.x * UW, u0 = ublk + wn * 16, r0 = g * RG;
-    const size_t hs = (size_t)ndir * H;
-    unsigned* abort_word = sync + 1023;
-    const int HG = H >> 1;                                                // granules per row
-    u64* xg = xbuf + (size_t)(d * G + g) * 2 * RG * HG;                    // [parity][RG rows][HG]
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * RG * HG * 8, 0x00020000);
-
-    // ---- I/O lanes work in 16-byte pieces: piece p = (row-array ra = p >> 3, units 4 * (p & 7) .. + 3)
-    const int c4 = (lane & 7) * 4, rsel = lane >> 3;                      // 8 lanes per 128-byte row
-    const long long tstep = d == 0 ? 1 : -1;
-    const int tfirst = d == 0 ? 0 : T - 1;
-    // loader: 3 gates x RG rows = 24 row-arrays, 3 per lane: ra = rsel + 8 * i  ->  gate q = ra / RG, row rr = ra % RG
-    auto gi_load = [&](int s_, float4 (&v)[3]) {
-        const long long t_ = tfirst + tstep * s_;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int ra = rsel + 8 * i, q = ra / RG, rr = ra % RG;
-            const bool ok = s_ < T && r0 + rr < B;
-            v[i] = ok ? *reinterpret_cast<const float4*>(gi + ((size_t)t_ * B + r0 + rr) * (3 * hs) + (size_t)d * 3 * H + q * H + ublk + c4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto gi_put = [&](int s_, const float4 (&v)[3]) {
-        float* dst = giring + (size_t)(s_ % GD) * 3 * RG * UW;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(dst + (rsel + 8 * i) * UW + c4) = v[i];
-    };
-    // storer: 5 arrays x RG rows = 40 row-arrays, 5 per lane (ra = rsel + 8 * i -> array k = i, row rr = rsel)
-    auto store_step = [&](int sp) {
-        const long long tq = tfirst + tstep * sp;
-        const float* src = oring + (size_t)(sp & 1) * 5 * RG * UW;
-        const int rr = rsel;
-        if (r0 + rr < B) {
-            const size_t rowi = (size_t)tq * B + r0 + rr;
-            const float4 hv = *reinterpret_cast<const float4*>(src + (0 * RG + rr) * UW + c4);
-            *reinterpret_cast<float4*>(hseq + rowi * hs + d * H + ublk + c4) = hv;
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(hv.x) | ((unsigned)f32_to_bf16(hv.y) << 16);
-            pk.y = (unsigned)f32_to_bf16(hv.z) | ((unsigned)f32_to_bf16(hv.w) << 16);
-            *reinterpret_cast<uint2*>(hseq16 + rowi * hs + d * H + ublk + c4) = pk;
-            float* gs = gates + (rowi * ndir + d) * 4 * H + ublk + c4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(gs + q * H) = *reinterpret_cast<const float4*>(src + ((1 + q) * RG + rr) * UW + c4);
-        }
-    };
-    float4 la[3], lb[3];
-    if (is_loader) {
-        for (int s0 = 0; s0 < GD - 1; ++s0) {          // steps 0 .. GD-2 are in the ring before the first step runs
-            gi_load(s0, la);
-            gi_put(s0, la);
-        }
-        gi_load(GD - 1, la);                           // in flight: steps GD-1 (la) and GD (lb)
-        gi_load(GD, lb);
-    }
-
-    Frag bb[KSF][3];
-    float bh[3] = {0.f, 0.f, 0.f};
-    const bool role = is_compute && wk == 0 && lane < 32;
-    const int ul = wn * 16 + (lane & 15);                                 // unit inside the workgroup
-    const int unit = ublk + ul, rloc = 4 * ((lane >> 4) & 1), rb = r0 + rloc;
-    if (is_compute) {
-#pragma unroll
-        for (int i = 0; i < KSF; ++i) {
-            const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                bb[i][q].u = *reinterpret_cast<const uint4*>(whh + ((size_t)(d * 3 + q) * H + u0 + (lane & 15)) * H + k);
-        }
-        if (role)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) bh[q] = bhh[(d * 3 + q) * H + unit];
-    }
-    if (__builtin_amdgcn_readfirstlane(wk) == 0 && __builtin_amdgcn_readfirstlane(w) < 8) __builtin_amdgcn_s_setprio(3);
-    float hprev[4] = {0.f, 0.f, 0.f, 0.f};
-    const int arow = lane & 15;
-    const bool aneed = arow < RG && r0 + arow < B;
-    if (tid == 0) *s_abort = 0;
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): one-time operand loads retire here, not inside the step loop
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        f32x4 acc[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4* part = part0 + (s & 1) * kPartStep;        // parity: other K quarters may run one step ahead of quarter 0
-        if (is_compute && s > 0) {
-            Frag a[KSF];
-            unsigned off[KSF];
-#pragma unroll
-            for (int i = 0; i < KSF; ++i) {
-                const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-                off[i] = (unsigned)(((((s - 1) & 1) * RG + (aneed ? arow : 0)) * HG + (k >> 1)) * 8);
-            }
-            if (!load_granules<KSF>(xrsrc, off, aneed, (unsigned)s, a, abort_word)) *s_abort = 1;
-            if (!aneed)
-#pragma unroll
-                for (int i = 0; i < KSF; ++i) a[i].u = make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < KSF; ++i)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i][q].v, acc[q], 0, 0, 0);
-            if (wk > 0)
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    part[(((wk - 1) * 2 + wn) * 3 + q) * 64 + lane] = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-        }
-        __syncthreads();                                   // the one barrier of the step (all ten waves)
-        if (*s_abort) break;
-        if (is_loader) {
-            // the slot of step s-1 is free now: step s+GD-1 goes there; two steps of loads stay in flight (la / lb alternate)
-            if (s & 1) { gi_put(s + GD - 1, lb); gi_load(s + GD + 1, lb); }
-            else       { gi_put(s + GD - 1, la); gi_load(s + GD + 1, la); }
-        } else if (is_storer) {
-            if (s > 0) store_step(s - 1);
-        } else if (wk == 0) {
-            if (s > 0)
-#pragma unroll
-                for (int qk = 0; qk < 3; ++qk)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const float4 v = part[((qk * 2 + wn) * 3 + q) * 64 + lane];
-                        acc[q][0] += v.x; acc[q][1] += v.y; acc[q][2] += v.z; acc[q][3] += v.w;
-                    }
-            const float* gsrc = giring + (size_t)(s % GD) * 3 * RG * UW;
-            float* odst = oring + (size_t)(s & 1) * 5 * RG * UW;
-            float h[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = (rloc + e) & (RG - 1);
-                const float g0 = gsrc[(0 * RG + rr) * UW + ul], g1 = gsrc[(1 * RG + rr) * UW + ul], g2 = gsrc[(2 * RG + rr) * UW + ul];
-                const float qn = acc[2][e] + bh[2];
-                const float r = sigmoidf_(g0 + acc[0][e] + bh[0]);
-                const float z = sigmoidf_(g1 + acc[1][e] + bh[1]);
-                const float n = tanhf_(g2 + r * qn);
-                h[e] = (1.0f - z) * n + z * hprev[e];
-                hprev[e] = h[e];
-                if (lane < 32) {
-                    odst[(0 * RG + rr) * UW + ul] = h[e];
-                    odst[(1 * RG + rr) * UW + ul] = r;
-                    odst[(2 * RG + rr) * UW + ul] = z;
-                    odst[(3 * RG + rr) * UW + ul] = n;
-                    odst[(4 * RG + rr) * UW + ul] = qn;
-                }
-            }
-            // publish h_t: even lanes carry rows e = 0, 1 of units (unit, unit + 1), odd lanes rows e = 2, 3
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = lane_xor1(h[e]);
-            const int odd = lane & 1;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {      // both packings are formed from fixed registers and the lane picks one
-                const unsigned even_pk = (unsigned)f32_to_bf16(h[x]) | ((unsigned)f32_to_bf16(o[x]) << 16);
-                const unsigned odd_pk = (unsigned)f32_to_bf16(o[2 + x]) | ((unsigned)f32_to_bf16(h[2 + x]) << 16);
-                const unsigned pk = odd ? odd_pk : even_pk;
-                const int e = 2 * odd + x;
-                if (role && rb + e < B)
-                    __hip_atomic_store(xg + ((size_t)(s & 1) * RG + rloc + e) * HG + ((unit - odd) >> 1),
-                                       ((u64)(unsigned)(s + 1) << 32) | pk, ASR_RLX_AGENT);
-            }
-        }
-    }
-    // drain: the storer still owes the last step
-    __syncthreads();
-    if (is_storer && !*s_abort) store_step(T - 1);
-}
-
-// Backward group kernel: the mirror image of the forward one, with ONE difference in the hand-off.  K = 3H gives 12 K
-// steps per wave at H = 512; as data-tagged granules that would be 24 sixteen-byte loads (96 VGPRs) in flight per lane
-// next to 48 VGPRs of stationary W_hh^T fragments, which does not fit beside the I/O waves (measured: spills, 17 us per
-// step).  So dgh_t travels COMPACT (bf16, 12 loads per lane) and readiness is a counter per (group, direction):
-//   role waves: publish (sc1 4-byte stores) -> s_waitcnt vmcnt(0) -> LDS arrival count -> the last role wave adds 1 to
-//   the pair's counter (agent scope);   all waves: lane 0 of wave 0 polls the counter (relaxed sc1 loads) -> barrier ->
-//   sc1 loads of the payload.   (first row of the sc1 hand-off table of MI355X_MICROARCH.md, as the non-grouped kernel)
-// Waves 8, 9 stream the saved gates / dy / h_prev in through an LDS ring, wave 10 streams dgi / dgh out.
-constexpr int BGD = 4;                         // ring depth (steps) of the backward operand ring
-
-template <int KSF>      // K steps per compute wave = 3H / 128
-__global__ __launch_bounds__(704) void bwd_group_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ gates,
-                                                        const float* __restrict__ hseq,
-                                                        const uint16_t* __restrict__ whhT, uint16_t* __restrict__ dgi,
-                                                        uint16_t* __restrict__ dgh, float* __restrict__ db_ih,
-                                                        float* __restrict__ db_hh, unsigned* sync, u64* xbuf, int T,
-                                                        int B, int H, int ndir) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* part0 = reinterpret_cast<float4*>(smem);                                 // [parity][3 K quarters][2 tiles][64]
-    constexpr int kPartStep = 3 * 2 * 64;
-    float* opring = reinterpret_cast<float*>(part0 + 2 * kPartStep);                 // [BGD][6 arrays][RG][UW]: dy, r, z, n, q, hp
-    uint16_t* oring = reinterpret_cast<uint16_t*>(opring + BGD * 6 * RG * UW);       // [2][4 arrays][RG][UW] bf16: ar, az, an, aq
-    int* s_abort = reinterpret_cast<int*>(oring + 2 * 4 * RG * UW);
-    unsigned* s_arrive = reinterpret_cast<unsigned*>(s_abort + 1);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wn = w & 1, wk = ((w >> 1) + 3) & 3;
-    const bool is_loader = w == 8 || w == 9, is_storer = w == 10, is_compute = w < 8;
-    const int lhalf = w - 8;                                              // loader 0: r, z, n   loader 1: q, h_prev, dy
-    const int g = blockIdx.y, d = blockIdx.z, G = gridDim.y, nwg = gridDim.x;
-    const int ublk = blockIdx.x * UW, u0 = ublk + wn * 16, r0 = g * RG;
-    const size_t hs = (size_t)ndir * H, gs3 = (size_t)ndir * 3 * H;
-    unsigned* counter = sync + (d * G + g) * 64;
-    unsigned* abort_word = sync + 1023;
-    const int K3 = 3 * H;
-    uint16_t* xg = reinterpret_cast<uint16_t*>(xbuf) + (size_t)(d * G + g) * 2 * RG * K3;      // [parity][RG][3H] bf16
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, 2 * RG * K3 * 2, 0x00020000);
-
-    // ---- I/O pieces of 16 bytes: 8 lanes per 128-byte row of 32 f32 units
-    const int c4 = (lane & 7) * 4, rsel = lane >> 3;
-    const long long tstep = d == 0 ? -1 : 1;                              // backward sweep: reverse of the forward order
-    const int tfirst = d == 0 ? T - 1 : 0;
-    // operand ring arrays: 0 dy, 1 r, 2 z, 3 n, 4 q, 5 h_prev.  Two loader waves share the six streams (3 each).
-#define ASR_OP_LOAD(S_, V0, V1, V2)                                                                                      \
-    {                                                                                                                     \
-        const int s__ = (S_);                                                                                             \
-        const long long t_ = tfirst + tstep * s__;                                                                        \
-        const long long tp_ = d == 0 ? t_ - 1 : t_ + 1;                                                                   \
-        const bool hasp = d == 0 ? t_ > 0 : t_ < T - 1;                                                                   \
-        const bool ok = s__ < T && r0 + rsel < B;                                                                         \
-        const size_t rowi = (size_t)(ok ? t_ : 0) * B + (ok ? r0 + rsel : 0);                                             \
-        const float* gs = gates + (rowi * ndir + d) * 4 * H + ublk + c4;                                                  \
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);                                                              \
-        if (lhalf == 0) {                                                                                                 \
-            V0 = ok ? *reinterpret_cast<const float4*>(gs) : zero;                                                        \
-            V1 = ok ? *reinterpret_cast<const float4*>(gs + H) : zero;                                                    \
-            V2 = ok ? *reinterpret_cast<const float4*>(gs + 2 * H) : zero;                                                \
-        } else {                                                                                                          \
-            V0 = ok ? *reinterpret_cast<const float4*>(gs + 3 * H) : zero;                                                \
-            V1 = (ok && hasp) ? *reinterpret_cast<const float4*>(hseq + ((size_t)tp_ * B + r0 + rsel) * hs + d * H + ublk + c4) : zero; \
-            const uint2 y = ok ? *reinterpret_cast<const uint2*>(dy + rowi * H + ublk + c4) : make_uint2(0u, 0u);        \
-            V2 = make_float4(bf16_to_f32((uint16_t)(y.x & 0xffff)), bf16_to_f32((uint16_t)(y.x >> 16)),                  \
-                             bf16_to_f32((uint16_t)(y.y & 0xffff)), bf16_to_f32((uint16_t)(y.y >> 16)));                  \
-        }                                                                                                                 \
-    }
-#define ASR_OP_PUT(S_, V0, V1, V2)                                                                                       \
-    {                                                                                                                     \
-        float* dst = opring + (size_t)((S_) % BGD) * 6 * RG * UW;                                                         \
-        const int a0 = lhalf == 0 ? 1 : 4, a1 = lhalf == 0 ? 2 : 5, a2 = lhalf == 0 ? 3 : 0;                              \
-        *reinterpret_cast<float4*>(dst + (a0 * RG + rsel) * UW + c4) = V0;                                                \
-        *reinterpret_cast<float4*>(dst + (a1 * RG + rsel) * UW + c4) = V1;                                                \
-        *reinterpret_cast<float4*>(dst + (a2 * RG + rsel) * UW + c4) = V2;                                                \
-    }
-    // storer: dgi = [ar | az | an], dgh = [ar | az | aq]; rows of 32 bf16 = 64 bytes: 4 lanes x 16 bytes
-    auto store_step = [&](int sp) {
-        const long long tq = tfirst + tstep * sp;
-        const uint16_t* src = oring + (size_t)(sp & 1) * 4 * RG * UW;
-        const int c8 = (lane & 3) * 8, rr = (lane >> 2) & (RG - 1), half = lane >> 5;      // half 0: dgi, 1: dgh
-        if (r0 + rr < B) {
-            uint16_t* dst = (half ? dgh : dgi) + ((size_t)tq * B + r0 + rr) * gs3 + (size_t)d * 3 * H + ublk + c8;
-            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src + (0 * RG + rr) * UW + c8);
-            *reinterpret_cast<uint4*>(dst + H) = *reinterpret_cast<const uint4*>(src + (1 * RG + rr) * UW + c8);
-            *reinterpret_cast<uint4*>(dst + 2 * H) = *reinterpret_cast<const uint4*>(src + ((half ? 3 : 2) * RG + rr) * UW + c8);
-        }
-    };
-    float4 la0, la1, la2, lb0, lb1, lb2;
-    la0 = la1 = la2 = lb0 = lb1 = lb2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (is_loader) {
-        for (int s0 = 0; s0 < BGD - 1; ++s0) {
-            ASR_OP_LOAD(s0, la0, la1, la2)
-            ASR_OP_PUT(s0, la0, la1, la2)
-        }
-        ASR_OP_LOAD(BGD - 1, la0, la1, la2)
-        ASR_OP_LOAD(BGD, lb0, lb1, lb2)
-    }
-    Frag bb[KSF];
-    if (is_compute) {
-#pragma unroll
-        for (int i = 0; i < KSF; ++i) {
-            const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-            bb[i].u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + u0 + (lane & 15)) * (3 * H) + k);
-        }
-    }
-    const bool role = is_compute && wk == 0 && lane < 32;
-    const int ul = wn * 16 + (lane & 15);
-    const int unit = ublk + ul, rloc = 4 * ((lane >> 4) & 1);
-    const int arow = lane & 15;
-    const bool aneed = arow < RG && r0 + arow < B;
-    if (__builtin_amdgcn_readfirstlane(wk) == 0 && __builtin_amdgcn_readfirstlane(w) < 8) __builtin_amdgcn_s_setprio(3);
-    float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    float sb[4] = {0.f, 0.f, 0.f, 0.f};          // running bias-gradient sums: r, z, n (input side), q (hidden side)
-    if (tid == 0) { *s_abort = 0; *s_arrive = 0; }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
-    for (int s = 0; s < T; ++s) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4* part = part0 + (s & 1) * kPartStep;
-        if (s > 0) {
-            if (tid == 0 && !wait_counter(counter, (unsigned)nwg * (unsigned)s, abort_word)) *s_abort = 1;
-            __syncthreads();
-            if (*s_abort) break;
-        }
-        if (is_compute && s > 0) {
-            Frag a[KSF];
-#pragma unroll
-            for (int i = 0; i < KSF; ++i) {
-                const int k = (wk * KSF + i) * 32 + 8 * (lane >> 4);
-                const unsigned off = (unsigned)(((((s - 1) & 1) * RG + (aneed ? arow : 0)) * K3 + k) * 2);
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 16 /* sc1 */);
-                a[i].u = aneed ? make_uint4(v[0], v[1], v[2], v[3]) : make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < KSF; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, bb[i].v, acc, 0, 0, 0);
-            if (wk > 0) part[((wk - 1) * 2 + wn) * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        }
-        __syncthreads();
-        if (is_loader) {
-            if (s & 1) { ASR_OP_PUT(s + BGD - 1, lb0, lb1, lb2) ASR_OP_LOAD(s + BGD + 1, lb0, lb1, lb2) }
-            else       { ASR_OP_PUT(s + BGD - 1, la0, la1, la2) ASR_OP_LOAD(s + BGD + 1, la0, la1, la2) }
-        } else if (is_storer) {
-            if (s > 0) store_step(s - 1);
-        } else if (wk == 0) {
-            if (s > 0)
-#pragma unroll
-                for (int qk = 0; qk < 3; ++qk) {
-                    const float4 v = part[(qk * 2 + wn) * 64 + lane];
-                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
-                }
-            const float* osrc = opring + (size_t)(s % BGD) * 6 * RG * UW;
-            uint16_t* odst = oring + (size_t)(s & 1) * 4 * RG * UW;
-            float dar[4], daz[4], dq[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = (rloc + e) & (RG - 1);
-                const float dyv = osrc[(0 * RG + rr) * UW + ul], r = osrc[(1 * RG + rr) * UW + ul], z = osrc[(2 * RG + rr) * UW + ul];
-                const float n = osrc[(3 * RG + rr) * UW + ul], qq = osrc[(4 * RG + rr) * UW + ul], hp = osrc[(5 * RG + rr) * UW + ul];
-                const float dh = dyv + carry[e] + acc[e];
-                const float dn = dh * (1.0f - z);
-                const float dz = dh * (hp - n);
-                const float dan = dn * (1.0f - n * n);
-                daz[e] = dz * z * (1.0f - z);
-                dq[e] = dan * r;
-                dar[e] = dan * qq * r * (1.0f - r);
-                carry[e] = dh * z;
-                const uint16_t br = f32_to_bf16(dar[e]), bz = f32_to_bf16(daz[e]), bn = f32_to_bf16(dan), bq2 = f32_to_bf16(dq[e]);
-                // the bias gradients see the bf16-rounded values the weight-gradient GEMMs see
-                if (r0 + rr < B) { sb[0] += bf16_to_f32(br); sb[1] += bf16_to_f32(bz); sb[2] += bf16_to_f32(bn); sb[3] += bf16_to_f32(bq2); }
-                if (lane < 32) {
-                    odst[(0 * RG + rr) * UW + ul] = br;
-                    odst[(1 * RG + rr) * UW + ul] = bz;
-                    odst[(2 * RG + rr) * UW + ul] = bn;
-                    odst[(3 * RG + rr) * UW + ul] = bq2;
-                }
-            }
-            float o_r[4], o_z[4], o_q[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o_r[e] = lane_xor1(dar[e]); o_z[e] = lane_xor1(daz[e]); o_q[e] = lane_xor1(dq[e]); }
-            const int odd = lane & 1;
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                auto pack = [&](float own0, float own1, float oth0, float oth1) -> unsigned {
-                    const unsigned even_pk = (unsigned)f32_to_bf16(own0) | ((unsigned)f32_to_bf16(oth0) << 16);
-                    const unsigned odd_pk = (unsigned)f32_to_bf16(oth1) | ((unsigned)f32_to_bf16(own1) << 16);
-                    return odd ? odd_pk : even_pk;
-                };
-                const unsigned p_r = pack(dar[x], dar[2 + x], o_r[x], o_r[2 + x]);
-                const unsigned p_z = pack(daz[x], daz[2 + x], o_z[x], o_z[2 + x]);
-                const unsigned p_q = pack(dq[x], dq[2 + x], o_q[x], o_q[2 + x]);
-                const int e = 2 * odd + x;
-                if (role && r0 + rloc + e < B) {
-                    unsigned* gp = reinterpret_cast<unsigned*>(xg + ((size_t)(s & 1) * RG + rloc + e) * K3 + (unit - odd));
-                    __hip_atomic_store(gp, p_r, ASR_RLX_AGENT);                   // k = unit       (r gate)
-                    __hip_atomic_store(gp + (H >> 1), p_z, ASR_RLX_AGENT);        // k = H + unit   (z gate)
-                    __hip_atomic_store(gp + H, p_q, ASR_RLX_AGENT);               // k = 2H + unit  (q)
-                }
-            }
-            // signal: every role wave drains its write-through stores, the last one to arrive adds to the pair's counter
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                const unsigned old = atomicAdd(s_arrive, 1u);              // LDS
-                if ((old & 1u) == 1u) __hip_atomic_fetch_add(counter, 1u, ASR_RLX_AGENT);
-            }
-        }
-    }
-    __syncthreads();
-    if (is_storer && !*s_abort) store_step(T - 1);
-    // bias gradients: rows 0..3 sit in lanes 0..15, rows 4..7 in lanes 16..31 of the same unit
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sb[q] += __shfl_xor(sb[q], 16, 64);
-    if (role && lane < 16 && db_ih && db_hh) {
-        float* bi = db_ih + (size_t)d * 3 * H + unit;
-        float* bh2 = db_hh + (size_t)d * 3 * H + unit;
-        atomicAdd(bi, sb[0]); atomicAdd(bi + H, sb[1]); atomicAdd(bi + 2 * H, sb[2]);
-        atomicAdd(bh2, sb[0]); atomicAdd(bh2 + H, sb[1]); atomicAdd(bh2 + 2 * H, sb[3]);
-    }
-#undef ASR_OP_LOAD
-#undef ASR_OP_PUT
-}
-
 // y = hf + hb (or a copy for one direction): f32 state -> bf16 layer output; rows beyond an utterance's length are zero
 __global__ void merge_dirs_kernel(const float* __restrict__ hseq, uint16_t* __restrict__ y, long long rows, int H,
                                   int ndir, const int* __restrict__ x_len, int B) {
@@ -3054,23 +2068,18 @@ using namespace asr;
 using namespace asr::gru;
 
 extern "C" size_t asr_gru_sync_bytes(int B, int H, int ndir) {
-    const size_t G = (size_t)(B + RG - 1) / RG;
-    const size_t exch = (size_t)ndir * G * 2 * RG * (3 * (size_t)H / 2) * 8;       // granule exchange area of the grouped kernels
     const int nrec_pad = (ndir * ((B + 3) / 4) + 7) & ~7;
-    const size_t ps = kShardBytes + ps_exchange_bytes(nrec_pad, H);                // sharded counters + the partial-sum ring (bwd_ps_kernel)
-    return 4096 + (exch > ps ? exch : ps);
+    const size_t ps = ps_exchange_bytes(nrec_pad, H);                  // the partial-sum ring (bwd_ps_kernel)
+    const size_t ring = (size_t)8 * PS_RING * 8 * H * 2;               // the forward kernel's hand-off ring
+    return 4096 + kShardBytes + (ps > ring ? ps : ring);               // control words, sharded counters, the larger exchange area
 }
 
+static bool valid_mode(int mode) { return mode == 0 || mode == 1 || mode == 2 || mode == 4 || (mode >= 7 && mode <= 10); }
 static int check_dims(int T, int B, int H, int ndir) {
     if (T <= 0 || B <= 0 || H <= 0 || (ndir != 1 && ndir != 2)) return ASR_ERR_BAD_ARG;
     if (H % 32) return ASR_ERR_UNSUPPORTED;       // MFMA K step and 16-unit workgroup slices
     return ASR_OK;
 }
-
-// persistent form applies when one pass covers the batch (B <= 32), the grid is surely co-resident (<= 128 workgroups)
-// and the offsets fit the 32-bit buffer descriptors
-// grouped form: 8 workgroups x 64 units, groups of 8 utterances; at most 4 groups x 2 directions x 8 = 64 workgroups
-static bool can_group(int B, int H) { return H % 128 == 0 && H <= 512 && B <= 4 * RG; }
 
 // control words [0, 4092) and the area behind them are zeroed by every call; the abort word (int 1023) is NOT: it is
 // sticky, so that a caller reusing one sync_ws sees a failed launch later (and every later launch gives up at once)
@@ -3156,10 +2165,10 @@ static bool can_persist(int T, int B, int H, int ndir, int mode, const void* syn
 }
 
 // first-poll delay of the forward hand-off in s_sleep(1) units (~70 cycles each), see kFirstPollDelay: measured per H (the number of
-// producers of a recurrence, H / 16, shifts the moment the last store lands); ASR_GRU_POLL_DELAY overrides
+// producers of a recurrence, H / 16, shifts the moment the last store lands); ASR_DEBUG gru_poll_delay overrides
 static int fwd_poll_delay(int H, bool ring) {
     static int env = -2;
-    if (env == -2) { const char* e = getenv("ASR_GRU_POLL_DELAY"); env = e ? atoi(e) : -1; }
+    if (env == -2) env = debug_flag("gru_poll_delay", -1);
     if (env >= 0) return env > 255 ? 255 : env;
     // T=1000, B=32, us per step at 0 / best.  Ring form (whole-line stores into L2-resident slots): H=512 1.30 / 1.23 (5-6),
     // H=384 1.20 / 1.18 (3), H=256 1.03 / 1.00 (3), H=128 1.20 flat.  Sequence form (32-B pieces of fresh lines): H=512 1.49 / 1.34 (11),
@@ -3168,17 +2177,13 @@ static int fwd_poll_delay(int H, bool ring) {
     return H >= 512 ? kFirstPollDelay : (H >= 256 ? 3 : 6);
 }
 
-// which forward kernel family serves a call: 0 one launch per step, 1 wide, 2 16-unit x 8-row (the default at B <= 32),
-// 3 grouped, 4 plain persistent
+// which forward kernel family serves a call: 0 one launch per time step, 1 wide (32 units x 4-row recurrences), 2 the 16-unit x 8-row
+// kernel (the default at 16 < B <= 32, and of every slab of a larger batch)
 static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
-    const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
-    if (!persist) return 0;
-    const int Gio = (B + 7) / 8;
+    if (!can_persist(T, B, H, ndir, mode, sync_ws)) return 0;
     const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
-    if ((mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) return 1;
-    if (mode != 3 && H % 16 == 0 && ndir * Gio <= 16) return 2;
-    if (can_group(B, H)) return 3;
-    return 4;
+    if ((mode == 2 || wide_half) && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) return 1;
+    return 2;
 }
 
 // the default pair -- forward with the L2-resident ring hand-off, backward with the partial-sum exchange -- can keep the saved gates
@@ -3186,7 +2191,7 @@ static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_
 static bool fwd_ring_form(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
     if (fwd_family(T, B, H, ndir, mode, sync_ws) != 2) return false;
     static int ring_env = -1;
-    if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }
+    if (ring_env < 0) ring_env = debug_flag("fwd_ring", 1);
     const int Gio = (B + 7) / 8, ksw = (H / 32 + 3) / 4;
     return (mode == 0 || mode == 8) && ndir * Gio <= 8 && ksw >= 2 && ring_env != 0;
 }
@@ -3208,7 +2213,7 @@ static int slab_rows(int T, int B, int H, int ndir, int mode, const void* sync_w
     // the 16-unit x 8-row forward kernel (its ring form, or -- K split too shallow for it, H < 256 -- its flag form, which fills no
     // sentinels into the whole sequence) and the partial-sum backward kernel: both take (boff, Bn)
     if (fwd_family(T, kSlab, H, ndir, mode, sync_ws) != 2 || !bwd_ps_form(T, kSlab, H, ndir, mode, sync_ws)) return 0;
-    if (!fwd_ring_form(T, kSlab, H, ndir, mode, sync_ws) && (H / 32 + 3) / 4 >= 2) return 0;       // (ASR_FWD_RING=0: sequence polling)
+    if (!fwd_ring_form(T, kSlab, H, ndir, mode, sync_ws) && (H / 32 + 3) / 4 >= 2) return 0;       // (ASR_DEBUG fwd_ring=0: sequence polling)
     return kSlab;
 }
 
@@ -3234,11 +2239,11 @@ static int fwd_io_launch(hipStream_t st, void* gi_any, int gi_bf16, const void* 
     const int ksw = (H / 32 + 3) / 4;
     const int io_rows = 8, io_lds = kPersistLds;
     const int Gio = (Bn + io_rows - 1) / io_rows;
-    const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
+    const bool local = (mode == 0 || mode == 4 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
     // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
     const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
     static int ring_env = -1;
-    if (ring_env < 0) { const char* e = getenv("ASR_FWD_RING"); ring_env = e ? atoi(e) : 1; }      // (0: the payload is polled in the bf16 sequence itself)
+    if (ring_env < 0) ring_env = debug_flag("fwd_ring", 1);      // (0: the payload is polled in the bf16 sequence itself)
     const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
     if (gates_f16 && !use_ring) return ASR_ERR_UNSUPPORTED;
     if (!use_ring && (forge & 8) && (boff != 0 || Bn != B)) return ASR_ERR_UNSUPPORTED;      // (slabs: not the form that fills / polls the whole sequence)
@@ -3281,6 +2286,7 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
+    if (!valid_mode(mode)) return ASR_ERR_BAD_ARG;
     if (mode == 9 || mode == 10) mode = 0;      // (those select backward kernels)
     const int slab = slab_rows(T, B, H, ndir, mode, sync_ws);
     if (gates_f16 && !fwd_ring_form(T, slab ? slab : B, H, ndir, mode, sync_ws)) return ASR_ERR_UNSUPPORTED;       // (ask asr_gru_gates_f16_ok)
@@ -3298,18 +2304,15 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     if (ksw > 8) return ASR_ERR_UNSUPPORTED;      // H <= 1024
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
-    const bool grouped = persist && can_group(B, H);
-    const int Gio = (B + 7) / 8;
-    // wide form also for B <= 16 in the default modes: a half batch (asr/pipeline.py) then makes 8 recurrences of 16
-    // workgroups, so that the launch of the other half batch finds a free CU for every workgroup of its own
-    const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
+    const int family = fwd_family(T, B, H, ndir, mode, sync_ws);
+    // wide form also for 4 < B <= 16 in the default modes (the step of a 4-row recurrence fetches half the hand-off bytes)
     if (slab) {         // consecutive slabs of <= 32 rows through the default kernel (see slab_rows); the launches share sync_ws in stream order
         for (int boff = 0; boff < B; boff += slab) {
             const int rc2 = fwd_io_launch(st, gi_any, gi_bf16, whh_bf16, bhh, hseq, hseq_bf16, gates, sync_ws, T, B, H, ndir, mode, gates_f16, boff,
                                           B - boff < slab ? B - boff : slab);
             if (rc2 != ASR_OK) return rc2;
         }
-    } else if (persist && (mode == 2 || wide_half) && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) {
+    } else if (family == 1) {
         // wide form (32 units x 4-row recurrences).  Measured at T=1000, B=32, H=512: with the XCD-local hand-off it ties
         // the 16-unit x 8-row kernel (2.11 vs 2.12 us: the smaller payload is paid back in the 8-wave reduction), with the
         // placement-free hand-off it wins (2.47 vs 2.72 us) -- so it serves mode 2 only; the backward pass is wide in both.
@@ -3334,37 +2337,9 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     } while (0)
         if (ks8 <= 1) ASR_FWDW(1); else if (ks8 <= 2) ASR_FWDW(2); else ASR_FWDW(4);
 #undef ASR_FWDW
-    } else if (persist && mode != 3 && H % 16 == 0 && ndir * Gio <= 16) {
+    } else if (family == 2) {
         const int rc2 = fwd_io_launch(st, gi_any, gi_bf16, whh_bf16, bhh, hseq, hseq_bf16, gates, sync_ws, T, B, H, ndir, mode, gates_f16, 0, B);
         if (rc2 != ASR_OK) return rc2;
-    } else if (grouped) {
-        const int G = (B + RG - 1) / RG;
-        if (!clear_sync(sync_ws, (size_t)ndir * G * 2 * RG * (H / 2) * 8, st)) return ASR_ERR_LAUNCH;
-        const dim3 ggrid(H / UW, G, ndir), gblock(640);
-#define ASR_FWDG(K)                                                                                                       \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL(fwd_group_kernel<K>, ggrid, gblock, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,   \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, (u64*)((char*)sync_ws + 4096), T, B, H, ndir);  \
-    } while (0)
-        switch (H / 128) {
-            case 1: ASR_FWDG(1); break;
-            case 2: ASR_FWDG(2); break;
-            case 3: ASR_FWDG(3); break;
-            case 4: ASR_FWDG(4); break;
-            default: return ASR_ERR_UNSUPPORTED;
-        }
-#undef ASR_FWDG
-    } else if (persist) {
-        if (!clear_sync(sync_ws, 0, st)) return ASR_ERR_LAUNCH;
-#define ASR_FWDP(K)                                                                                                       \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL(fwd_persistent_kernel<K>, grid, block, kPersistLds, st, gi, (const uint16_t*)whh_bf16, bhh, hseq,      \
-                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir);                                      \
-    } while (0)
-        if (ksw <= 1) ASR_FWDP(1); else if (ksw <= 2) ASR_FWDP(2); else if (ksw <= 4) ASR_FWDP(4); else ASR_FWDP(8);
-#undef ASR_FWDP
     } else
     for (int s = 0; s < T; ++s) {
 #define ASR_FWD(K) hipLaunchKernelGGL(fwd_step_kernel<K>, grid, block, 0, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
@@ -3395,6 +2370,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
                            void* dy_ws, int gates_f16) {
     if (!dy_bf16 || !gates_any || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const float* gates = reinterpret_cast<const float*>(gates_any);
+    if (!valid_mode(mode)) return ASR_ERR_BAD_ARG;
     if (gates_f16 && !((bwd_ps_form(T, B, H, ndir, mode, sync_ws) || slab_rows(T, B, H, ndir, mode, sync_ws)) && db_ih && db_hh)) return ASR_ERR_UNSUPPORTED;
     const int rc = check_dims(T, B, H, ndir);
     if (rc != ASR_OK) return rc;
@@ -3413,31 +2389,6 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
     const int ksw = (3 * H / 32 + 3) / 4;
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws) && ksw <= 12;
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
-    // the grouped backward kernel still spills at H = 512 (168-VGPR cap of an 11-wave workgroup): measured 6.4 us per step
-    // against 5.6 us for the non-grouped counter kernel, so it is opt-in (mode 3) until it is restructured
-    const bool grouped = persist && can_group(B, H) && db_ih && db_hh && mode == 3;
-    if (grouped) {
-        const int G = (B + RG - 1) / RG;
-        if (!clear_sync(sync_ws, (size_t)ndir * G * 2 * RG * (3 * H / 2) * 8, st)) return ASR_ERR_LAUNCH;
-        const dim3 ggrid(H / UW, G, ndir), gblock(704);
-        constexpr int kBwdLds = 150 * 1024;
-#define ASR_BWDG(K)                                                                                                       \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)bwd_group_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds); \
-        hipLaunchKernelGGL(bwd_group_kernel<K>, ggrid, gblock, kBwdLds, st, (const uint16_t*)dy_bf16, gates, hseq,       \
-                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,              \
-                           (unsigned*)sync_ws, (u64*)((char*)sync_ws + 4096), T, B, H, ndir);                              \
-    } while (0)
-        switch (3 * H / 128) {
-            case 3: ASR_BWDG(3); break;
-            case 6: ASR_BWDG(6); break;
-            case 9: ASR_BWDG(9); break;
-            case 12: ASR_BWDG(12); break;
-            default: return ASR_ERR_UNSUPPORTED;
-        }
-#undef ASR_BWDG
-        return ASR_OK;
-    }
     // partial-sum exchange (bwd_ps_kernel): the default where it applies (modes 0 / 8; 9 asks for it, 10 forges a split
     // placement so that its placement-free stores are exercised); measured 1.78 -> 1.59 us per step at T=1000, B=32, H=512
     const int slab = (db_ih && db_hh) ? slab_rows(T, B, H, ndir, mode, sync_ws) : 0;       // (see slab_rows: batches beyond 32 rows)
@@ -3473,8 +2424,8 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
         }
         return ASR_OK;
     }
-    // wide form (32 units x 4-row recurrences): mode 5 keeps the 16-unit x 8-row kernels for comparison
-    if (persist && mode != 3 && mode != 5 && db_ih && db_hh && H % 32 == 0 && H >= 128 && ndir * ((B + 3) / 4) <= 16) {
+    // wide form (32 units x 4-row recurrences): every other persistent case
+    if (persist && db_ih && db_hh && H >= 64 && ndir * ((B + 3) / 4) <= 16) {
         const int Gw = (B + 3) / 4, nrec = ndir * Gw, nrec_pad = (nrec + 7) & ~7;
         const int ks8 = (3 * H / 32 + 7) / 8;
         if (ks8 <= 6) {
@@ -3503,47 +2454,8 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
             return ASR_OK;
         }
     }
-    if (persist && mode != 3 && db_ih && db_hh && H % 16 == 0) {
-        // batch rows split into independent recurrences of 8 rows (half of one 16-row MFMA tile)
-        // measured at T=1000, H=512, B=32: 32 rows 6.3 us/step, 16 rows 4.6, 8 rows 4.2
-        const int rows = 8;
-        const int G = (B + rows - 1) / rows;
-        if (ndir * G <= 16) {
-            if (!clear_sync(sync_ws, kShardBytes, st)) return ASR_ERR_LAUNCH;
-            const bool local = (mode == 0 || mode == 4 || mode == 5 || mode == 7) && ndir * G <= 8;   // try the XCD-local hand-off
-            const int forge = mode == 7;
-            const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, G, ndir), iblock(384);
-#define ASR_BWDIO(K)                                                                                                      \
-    do {                                                                                                                  \
-        if (local) {                                                                                                      \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, true>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
-                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
-                               (unsigned*)sync_ws, T, B, H, ndir, rows, forge);                                                   \
-        } else {                                                                                                          \
-            (void)hipFuncSetAttribute((const void*)bwd_persistent_io_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-            hipLaunchKernelGGL((bwd_persistent_io_kernel<K, false>), igrid, iblock, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq, \
-                               (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, db_ih, db_hh,                \
-                               (unsigned*)sync_ws, T, B, H, ndir, rows, 0);                                                       \
-        }                                                                                                                 \
-    } while (0)
-            if (ksw <= 2) ASR_BWDIO(2); else if (ksw <= 6) ASR_BWDIO(6); else ASR_BWDIO(12);
-#undef ASR_BWDIO
-            ASR_LAUNCH_CHECK();
-            return ASR_OK;
-        }
-    }
-    if (persist) {
-        if (!clear_sync(sync_ws, 0, st)) return ASR_ERR_LAUNCH;
-#define ASR_BWDP(K)                                                                                                       \
-    do {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)bwd_persistent_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \
-        hipLaunchKernelGGL(bwd_persistent_kernel<K>, grid, block, kPersistLds, st, (const uint16_t*)dy_bf16, gates, hseq,         \
-                           (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, (unsigned*)sync_ws, T, B, H, ndir); \
-    } while (0)
-        if (ksw <= 2) ASR_BWDP(2); else if (ksw <= 6) ASR_BWDP(6); else ASR_BWDP(12);
-#undef ASR_BWDP
-    } else
+    if (mode >= 2) return ASR_ERR_UNSUPPORTED;       // (no persistent kernel serves this shape; modes >= 2 do not fall back)
+    if (ksw > 12) return ASR_ERR_UNSUPPORTED;        // (the per-step kernel holds at most 12 K steps per wave: H <= 512)
     for (int s = 0; s < T; ++s) {
 #define ASR_BWD(K) hipLaunchKernelGGL(bwd_step_kernel<K>, grid, block, 0, st, (const uint16_t*)dy_bf16, gates, hseq, \
                                       (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s)
@@ -3551,7 +2463,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
 #undef ASR_BWD
     }
     ASR_LAUNCH_CHECK();
-    // bias gradients (the grouped kernel sums them in registers; here a column sum over all (t, b) rows)
+    // bias gradients (the persistent kernels sum them in registers; here a column sum over all (t, b) rows)
     if (db_ih) {
         const int rc2 = asr_colsum_acc(stream, dgi_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_ih);
         if (rc2 != ASR_OK) return rc2;

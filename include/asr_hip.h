@@ -294,15 +294,14 @@ int asr_batchnorm_bwd(void* stream, const void* x_bf16, const void* gy_bf16, con
  * the shape (H % 128 == 0, offsets below 2 GiB) -- utterances are independent, the results are those of one launch, the time is
  * ceil(B / 32) recurrences -- and otherwise with one launch per time step,
  * 1 = one launch per time step, 2 = persistent with the placement-free hand-off only (sc1 write-through + agent-scope
- * counter), 3 = the 32-unit grouped kernels, 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
+ * counter; the wide kernels: 32 units x 4-row recurrences), 4 = persistent, XCD-local hand-off where the workgroups of a recurrence
  * find themselves on one XCD (decided inside the launch, falls back to the mode-2 protocol otherwise) signalled through a
- * line of per-producer flags, 8 = the same with the payload as its own signal (what mode 0 selects: the call fills
- * hseq_bf16 / dgh_bf16 with 0xffff first and consumers load until no such word is left: no flags, no store drain, one
- * barrier per step), 5 = mode 4 with the 16-unit x 8-row backward kernel instead of the wide one (comparison),
- * 7 = mode 4 with a forged split placement (test hook for that fall-back).  Backward only: where H % 128 == 0 modes 0 / 8
- * run the partial-sum exchange kernel (a workgroup publishes the H partial sums of dh of its 32 units, 4 KB per step in
- * bf16, instead of every workgroup fetching the 3H gate gradients; dgh_bf16 is then written by a storer wave and needs no
- * sentinel fill); 9 = ask for that kernel, 10 = the same with a forged split placement (its write-through stores).
+ * line of per-producer flags, 8 = the same with the payload as its own signal (what mode 0 selects: consumers load until no
+ * sentinel word is left: no flags, no store drain, one barrier per step), 7 = mode 4 with a forged split placement (test hook for
+ * that fall-back).  Backward only: where H % 128 == 0 modes 0 / 8 run the partial-sum exchange kernel (a workgroup publishes the H
+ * partial sums of dh of its 32 units, 4 KB per step in bf16, instead of every workgroup fetching the 3H gate gradients; dgh_bf16 is
+ * then written by a storer wave and needs no sentinel fill); 9 = ask for that kernel, 10 = the same with a forged split placement
+ * (its write-through stores).  Other values: ASR_ERR_BAD_ARG (3, 5 and 6 named kernel forms that no shape selected; removed).
  * Modes >= 2 return ASR_ERR_UNSUPPORTED instead of falling back to mode 1.
  * After a synchronisation ((int*)sync_ws)[1023] != 0 reports a timed-out in-launch wait (results invalid).  That word
  * is sticky: the calls zero every other control word but never this one, so a caller that reuses one sync_ws (zeroed

@@ -468,3 +468,37 @@ def test_every_function_layer_of_the_reference_has_a_mirror():
     g = nn.GaussianNoise(0, 0.5)
     assert (g.mean, g.std) == (0, 0.5)
     assert callable(nn.LogSoftmax())
+
+
+def test_environment_is_reloaded_on_sigusr1(tmp_path):
+    """asr/training/environment.py:13-37 + its use in run/ctc/cnn/train.py:115-131: the script declares what can be steered, save()
+    writes it, an edit of the file + SIGUSR1 re-reads it (only declared attributes, nested option objects walked) and calls back"""
+    import io
+    import json
+    import signal
+    from asr.training import Environment, Iteration
+    from asr.data.augment import AugmentationOption
+    seen = []
+    keep = signal.getsignal(signal.SIGUSR1)
+    try:
+        env = Environment(str(tmp_path / "env.json"), lambda: seen.append((env.learning_rate, env.augmentation.add_noise)))
+        env.learning_rate, env.momentum, env.augmentation = 1e-3, 0.9, AugmentationOption(change_speech_rate=True)
+        env.save()
+        on_disk = json.load(open(str(tmp_path / "env.json")))
+        assert on_disk == {"learning_rate": 1e-3, "momentum": 0.9,
+                           "augmentation": {"add_noise": False, "change_speech_rate": True, "change_vocal_tract": False}}
+        on_disk["learning_rate"] = 5e-4
+        on_disk["augmentation"]["add_noise"] = True
+        on_disk["not_declared"] = 7                 # ignored: the file cannot add attributes
+        json.dump(on_disk, open(str(tmp_path / "env.json"), "w"))
+        os.kill(os.getpid(), signal.SIGUSR1)        # delivered to the main thread before the next byte code
+        assert seen == [(5e-4, True)] and env.momentum == 0.9 and not hasattr(env, "not_declared")
+        buf = io.StringIO()
+        env.dump(buf)
+        assert "learning_rate:\t0.0005" in buf.getvalue() and "add_noise:\tTrue" in buf.getvalue()
+        open(str(tmp_path / "env.json"), "w").write("{ not json")
+        with pytest.raises(AssertionError):
+            env.load()
+    finally:
+        signal.signal(signal.SIGUSR1, keep)
+    assert list(Iteration(3)) == [1, 2, 3]

@@ -405,11 +405,11 @@ def test_conv_bias_gradient_from_the_fused_maxout_pool_backward(device):
     assert grads[0][0].abs().max().item() > 0
 
 
-# 1: one launch per time step, 2: persistent, placement-free hand-off, 3: 32-unit grouped kernels,
+# 1: one launch per time step, 2: persistent, placement-free hand-off,
 # 4: persistent with the XCD-local hand-off where placement allows, signalled by flags; 8: the same with the payload as its
 # own signal (= automatic); 7: 4 with a forged split placement
 # 9: backward with the partial-sum exchange (bwd_ps_kernel; H % 128 == 0, else the wide kernel serves); 10: 9 with a forged split placement
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7, 8, 9, 10])
+@pytest.mark.parametrize("mode", [1, 2, 4, 7, 8, 9, 10])
 @pytest.mark.parametrize("T,B,I,H,ndir", [(12, 4, 64, 64, 2), (9, 5, 96, 128, 1), (20, 32, 64, 512, 2), (7, 40, 32, 64, 2),
                                           (150, 32, 32, 256, 2), (40, 19, 48, 128, 2), (30, 7, 32, 384, 1)])
 def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
@@ -417,8 +417,6 @@ def test_gru_step_kernels(device, T, B, I, H, ndir, mode):
     from asr import _ops, _lib
     if mode >= 2 and B > 32:
         pytest.skip("an explicitly selected persistent form covers B <= 32 (mode 0 runs larger batches as slabs: the test below)")
-    if mode == 3 and H % 128:
-        pytest.skip("grouped kernels need H % 128 == 0")
     _ops.GRU_MODE[0] = mode
     try:
         _gru_case(device, T, B, I, H, ndir)
@@ -846,11 +844,11 @@ def test_persistent_recurrence_waits_out_busy_cus(device):
 
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_wide_nt_kernels_in_a_forced_process(mode):
-    """the 256 x 256 NT kernels (csrc/gemm.hip gemm_nt_wide_kernel) normally serve only large convolutions; ASR_NT_WIDE /
-    ASR_NT_WIDE_FORCE (read once per process) route the GEMM and implicit-convolution tests of this file through them"""
+    """the 256 x 256 NT kernels (csrc/gemm.hip gemm_nt_wide_kernel) normally serve only large convolutions; ASR_DEBUG nt_wide /
+    nt_wide_force (read once per process) route the GEMM and implicit-convolution tests of this file through them"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ASR_NT_WIDE=mode, ASR_NT_WIDE_FORCE="1")
+    env = dict(os.environ, ASR_DEBUG="nt_wide=%s,nt_wide_force=1" % mode)
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
                           "-k", "test_gemm_nt or test_implicit_conv or test_conv_as_im2col"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -875,11 +873,11 @@ def test_colsum_acc(device, rows, cols, dtype, ld):
 
 
 def test_tn256_kernel_in_a_forced_process():
-    """the 256 x 128 LDS-DMA TN kernel normally serves the convolution weight gradients with >= 256 output channels; ASR_TN256=2
+    """the 256 x 128 LDS-DMA TN kernel normally serves the convolution weight gradients with >= 256 output channels; ASR_DEBUG tn256=2
     (read once per process) routes the plain TN products of this file through it as well"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ASR_TN256="2")
+    env = dict(os.environ, ASR_DEBUG="tn256=2")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
                           "-k", "test_gemm_tn_acc or test_implicit_conv"], env=env, capture_output=True,
                          text=True, timeout=900)
@@ -887,11 +885,11 @@ def test_tn256_kernel_in_a_forced_process():
 
 
 def test_forward_recurrence_without_the_ring_in_a_forced_process():
-    """the forward hand-off normally goes through the L2-resident ring; ASR_FWD_RING=0 (read once per process) polls the payload in the
+    """the forward hand-off normally goes through the L2-resident ring; ASR_DEBUG fwd_ring=0 (read once per process) polls the payload in the
     bf16 state sequence instead (sentinel fill + pre-touch): the recurrence tests of this file must pass on that path as well"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ASR_FWD_RING="0")
+    env = dict(os.environ, ASR_DEBUG="fwd_ring=0")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
                           "-k", "test_gru_full_size_forms_agree or (test_gru_step_kernels and (20-32-64-512 or 40-19-48-128))"],
                          env=env, capture_output=True, text=True, timeout=1200)

@@ -256,86 +256,6 @@ def test_cast_many_ragged_shapes(device):
         assert torch.equal(d, want), (r, c, t)
 
 
-@pytest.mark.parametrize("B,T", [(6, 50), (5, 37)])
-def test_two_half_batches_give_the_same_step(device, B, T):
-    """asr.pipeline.HalfBatches: the batch run as two halves on two streams (persistent GRU kernels on disjoint halves of the
-    chip) produces the loss and the gradients of the plain step -- same per-utterance arithmetic, sums in another order"""
-    from asr import _ops
-    from asr.loss import connectionist_temporal_classification
-    from asr.pipeline import HalfBatches
-    V = 29
-    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=2, ragged=True)
-    x, labels, x_len, l_len = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
-
-    def grads(split):
-        cfg, model = _build(device, V=V, seed=3)
-        if not split:
-            loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
-            loss.backward()
-        else:
-            pipe = HalfBatches(device)
-            try:
-                loss = pipe.loss(lambda sl: connectionist_temporal_classification(model(x[sl]), labels[sl], 0, x_len[sl], l_len[sl]), B)
-                loss.backward()
-                pipe.join()
-            finally:
-                pipe.close()
-        from asr.functions import join_side_stream
-        join_side_stream()
-        torch.cuda.synchronize()
-        _ops.gru_check_sync()
-        return loss.item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()}
-
-    l0, g0 = grads(False)
-    l1, g1 = grads(True)
-    assert abs(l0 - l1) <= 1e-4 * abs(l0)
-    for name in g0:
-        scale = float(g0[name].abs().max()) + 1e-12
-        err = float((g0[name] - g1[name]).abs().max()) / scale
-        assert err < 2e-2, (name, err)          # bf16 activations: the split changes only the order of the float sums
-
-
-def test_staggered_half_batch_step_matches_plain_step(device):
-    """HalfBatches.step (each half forward + backward on its own stream, the second one delayed, then ONE optimiser
-    update) leaves the parameters where the plain step leaves them"""
-    from asr.loss import connectionist_temporal_classification
-    from asr.optimizers import get_optimizer, GradientClipping, WeightDecay
-    from asr.pipeline import HalfBatches
-    V, B, T = 29, 8, 60
-    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=3, Lmax=8, seed=4, ragged=True)
-    x, labels, x_len, l_len = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
-
-    def run(split):
-        cfg, model = _build(device, V=V, seed=6)
-        opt = get_optimizer("adam", 1e-3, 0.9)
-        model(x)
-        opt.setup(model)
-        opt.add_hook(GradientClipping(1.0))
-        opt.add_hook(WeightDecay(1e-5))
-        fn = lambda sl: connectionist_temporal_classification(model(x[sl]), labels[sl], 0, x_len[sl], l_len[sl])
-        losses = []
-        if split:
-            pipe = HalfBatches(device)
-            opt.set_pipeline(pipe)
-            for _ in range(3):
-                losses.append(pipe.step(opt, fn, B, stagger_us=200).item())
-        else:
-            for _ in range(3):
-                loss = fn(slice(0, B))
-                opt.update(lossfun=lambda: loss)
-                losses.append(loss.item())
-        torch.cuda.synchronize()
-        return losses, {n: p.detach().float().cpu().clone() for n, p in model.named_parameters()}
-
-    l0, p0 = run(False)
-    l1, p1 = run(True)
-    for a, b_ in zip(l0, l1):
-        assert abs(a - b_) <= 2e-3 * abs(a), (l0, l1)
-    for name in p0:
-        # three Adam steps of 1e-3 each: the parameters moved by ~3e-3; the two routes may differ by a fraction of a step
-        assert float((p0[name] - p1[name]).abs().max()) < 1.5e-3, name
-
-
 def test_step_is_dropped_on_the_device_when_a_recurrence_gave_up(device):
     """a persistent GRU launch that abandons an in-launch wait leaves finite garbage behind, which the
     isfinite(norm) guard lets through.  asr_step_control drops the step on the device when an abort word is raised: the

@@ -81,7 +81,7 @@ if backend == "gloo":
     _ops.GRU_MODE[0] = 1                        # (two processes' persistent launches would compete for the CUs of the shared device)
 torch.manual_seed(1234 + rank)                  # DIFFERENT seeds: only the broadcast can make the ranks agree
 V, B, T = 31, 8, 64
-if kind in ("ds2", "ds2+halves"):
+if kind == "ds2":
     from asr.model import ds2
     cfg = ds2.configure(); cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 16, 128, 32, 2
     model = ds2.Model(cfg).to_gpu(di)
@@ -109,17 +109,9 @@ xd, ld, xl, ll = x[mine].to(dev), labels[mine].to(dev), x_len[mine].to(dev), l_l
 opt._ensure_flat()
 p_start = opt.flat_parameters().detach().cpu().clone()
 losses, norms = [], []
-pipe = None
-if kind == "ds2+halves" and world > 1:          # the two-half-batch schedule (asr/pipeline.py) under the Communicator: two passes, two streams
-    from asr.pipeline import HalfBatches
-    pipe = HalfBatches(dev)
-    opt.set_pipeline(pipe)
 for _ in range(3):
-    if pipe is not None:
-        loss = pipe.step(opt, lambda sl: connectionist_temporal_classification(model(xd[sl]), ld[sl], 0, xl[sl], ll[sl]), xd.shape[0])
-    else:
-        loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
-        opt.update(lossfun=lambda: loss)
+    loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
+    opt.update(lossfun=lambda: loss)
     losses.append(loss.item())
     norms.append(float(opt._flat["sq"].item()) ** 0.5 / world)       # norm of the MEAN gradient
 torch.cuda.synchronize()
@@ -153,7 +145,7 @@ def _visible_gpus():
 
 
 @pytest.mark.parametrize("kind,optname,backend", [("ds2", "adam", "gloo"), ("ds2", "msgd", "gloo"), ("cnn+weightnorm", "msgd", "gloo"),
-                                                  ("ds2+halves", "msgd", "gloo"), ("ds2", "msgd", "nccl"), ("ds2", "adam", "nccl")])
+                                                  ("ds2", "msgd", "nccl"), ("ds2", "adam", "nccl")])
 def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname, backend):
     """backend nccl: the same comparison over RCCL with one GPU per rank and the persistent recurrence kernels -- needs two visible
     GPUs, skipped on the one-GPU test box (where RCCL is covered by the single-rank test above and the control flow by gloo)."""
@@ -184,8 +176,7 @@ def test_two_ranks_reproduce_one_rank_on_the_whole_batch(tmp_path, kind, optname
     # every slice went exactly once per step
     ks = [k for k, _ in two[0]["launches"]]
     assert sorted(ks) == list(range(len(ks)))
-    if kind == "ds2+halves":        # with two passes on two streams nothing is reduced before the last pass has queued everything
-        assert all(n == two[0]["launches"][0][1] for _, n in two[0]["launches"]), two[0]["launches"]
+
 
 
 # ---------------------------------------------------------------------------------------------- a rank's recurrence gives up

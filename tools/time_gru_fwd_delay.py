@@ -1,4 +1,4 @@
-"""first-poll delay sweep of the forward recurrence (ASR_GRU_POLL_DELAY is read once per process: one process per value)"""
+"""first-poll delay sweep of the forward recurrence (ASR_DEBUG gru_poll_delay is read once per process: one process per value)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -22,9 +22,9 @@ for rep in range(3):
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 10 / T * 1e3)
 _ops.gru_check_sync()
-print(json.dumps(dict(delay=os.environ.get("ASR_GRU_POLL_DELAY"), fwd_us_per_step=best)))
+print(json.dumps(dict(delay=os.environ.get("ASR_DEBUG"), fwd_us_per_step=best)))
 ''' % ROOT
 for d in sys.argv[1:] or ["2", "3", "4", "5", "6", "7", "8", "10"]:
-    env = dict(os.environ, ASR_GRU_POLL_DELAY=d)
+    env = dict(os.environ, ASR_DEBUG="gru_poll_delay=%s" % d)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     print(out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:])

@@ -28,4 +28,4 @@ for (T, B, H, ndir) in shapes:
     f = t(lambda: _ops.gru_fwd(gi, whh16, bhh, T, B, H, ndir)) / T * 1e3
     b = t(lambda: _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh)) / T * 1e3
     _ops.gru_check_sync()
-    print("[delay=%s] T=%d B=%d H=%d ndir=%d: fwd %.3f us/step, bwd %.3f us/step" % (os.environ.get("ASR_GRU_POLL_DELAY", "auto"), T, B, H, ndir, f, b))
+    print("[delay=%s] T=%d B=%d H=%d ndir=%d: fwd %.3f us/step, bwd %.3f us/step" % (os.environ.get("ASR_DEBUG", "auto"), T, B, H, ndir, f, b))

@@ -1,4 +1,4 @@
-"""NT GEMM / implicit convolution timings on the shapes of the two bench configurations (ASR_NT_WIDE selects the kernel)."""
+"""NT GEMM / implicit convolution timings on the shapes of the two bench configurations (ASR_DEBUG nt_wide selects the kernel)."""
 import sys, os, json, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd"))
@@ -11,7 +11,7 @@ def t(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-mode = os.environ.get("ASR_NT_WIDE", "default")
+mode = os.environ.get("ASR_DEBUG", "default")
 res = []
 for (M, N, K, od) in [(32000, 3072, 512, torch.float32), (32000, 3072, 384, torch.float32), (32000, 512, 3072, torch.bfloat16),
                       (32000, 3000, 320, torch.float32), (32000, 640, 512, torch.bfloat16), (8192, 8192, 8192, torch.bfloat16)]:

@@ -1,4 +1,4 @@
-"""The step's NT products under one kernel selection (ASR_NT_WIDE / ASR_NT_WIDE_FORCE / ASR_NT_PERSIST read once per process):
+"""The step's NT products under one kernel selection (ASR_DEBUG nt_wide / nt_wide_force / nt_persist, read once per process):
 python tools/time_nt_modes.py   -- prints ms and TFLOP/s per shape"""
 import sys, os, json, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n
 
 
-tag = "wide=%s force=%s persist=%s" % (os.environ.get("ASR_NT_WIDE", "-"), os.environ.get("ASR_NT_WIDE_FORCE", "-"), os.environ.get("ASR_NT_PERSIST", "-"))
+tag = "wide=%s force=%s persist=%s" % (os.environ.get("ASR_DEBUG", "-"), "", "")
 for (M, N, K, od) in [(32000, 3072, 512, torch.bfloat16), (32000, 512, 3072, torch.bfloat16), (32000, 3072, 384, torch.bfloat16),
                       (32000, 384, 3072, torch.bfloat16), (32000, 3000, 320, torch.float32), (32000, 320, 3000, torch.bfloat16),
                       (32000, 640, 512, torch.bfloat16), (32000, 512, 640, torch.bfloat16)]:

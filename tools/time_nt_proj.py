@@ -1,4 +1,4 @@
-"""Projection-shaped NT GEMMs of the step (ASR_NT_PERSIST=0 / 1 selects the kernel): python tools/time_nt_proj.py"""
+"""Projection-shaped NT GEMMs of the step (ASR_DEBUG nt_persist=0 / 1 selects the kernel): python tools/time_nt_proj.py"""
 import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd"))
@@ -11,7 +11,7 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-tag = os.environ.get("ASR_NT_PERSIST", "default")
+tag = os.environ.get("ASR_DEBUG", "default")
 for (M, N, K, od) in [(32000, 3072, 512, torch.bfloat16), (32000, 3072, 1024, torch.bfloat16), (32000, 3072, 384, torch.bfloat16),
                       (32000, 3000, 320, torch.float32), (32000, 3072, 512, torch.float32), (32000, 1024, 3072, torch.bfloat16),
                       (32000, 512, 3072, torch.bfloat16), (8192, 8192, 8192, torch.bfloat16)]:
