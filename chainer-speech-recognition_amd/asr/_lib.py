@@ -32,6 +32,7 @@ SIGNATURES = {
     "asr_version": (c_int, []),
     "asr_stream_delay": (c_int, [c_void_p, c_int]),
     "asr_occupy_cus": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "asr_stream_traffic": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_longlong]),
     "asr_ctc_workspace_bytes": (c_size_t, [c_int] * 5),
     "asr_ctc_forward": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t]),
     "asr_ctc_forward_lse": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 3 + [c_size_t, c_void_p]),

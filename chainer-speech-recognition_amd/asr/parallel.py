@@ -23,6 +23,13 @@ When a slice may go
   pass's) slices go the moment they are complete, beside the convolutions' backward pass; only the small slice at the front of
   the buffer (``make_plan``) is left for ``finish_backward``.  A backward pass without recurrences (the convolutional
   recipes) launches every slice the moment it is complete.
+* ``beside_recurrences=True`` drops that rule: slices go the moment they are complete and no recurrence waits for them.  What a
+  resident collective costs a recurrence was measured on one GPU with a stand-in (tools/gru_beside_collective.py, DESIGN.md section
+  13.5: 8 / 16 / 32 workgroups streaming memory with 16 KB of LDS each, resident for the whole launch): forward 1.23 -> 1.50 / 1.56 /
+  1.66 us per time step, backward 1.38 -> 1.57 / 1.60 / 1.74, no give-up, identical results; a stand-in whose LDS does not fit beside
+  a recurrence workgroup (backward: 132 of 160 KB) simply makes the recurrence wait until it has left.  A 1.2 ms recurrence fully
+  overlapped by collectives thus pays 0.2 - 0.4 ms -- about what the same collectives cost in the gaps -- so the rule stays the
+  default and the switch is for interconnects slow enough that the gaps do not hold a slice.
 """
 import os
 
@@ -31,7 +38,7 @@ import torch.distributed as dist
 
 
 class Communicator(object):
-    def __init__(self, backend=None, buckets=4, overlap=True):
+    def __init__(self, backend=None, buckets=4, overlap=True, beside_recurrences=False):
         if not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
@@ -42,6 +49,7 @@ class Communicator(object):
         self.size = dist.get_world_size()
         self.buckets = max(1, int(buckets))
         self.overlap = bool(overlap)
+        self.beside_recurrences = bool(beside_recurrences)
         self._stream = None
         self._pending = []
         self._plan = None
@@ -118,7 +126,7 @@ class Communicator(object):
         self._events = [[] for _ in self._plan]
         self._new_pass()
         self.launch_log = []
-        self._defer, self._met_recurrence = self._recurrent, False
+        self._defer, self._met_recurrence = self._recurrent and not self.beside_recurrences, False
         self._rec_count = 0
         # several passes: nothing is launched before finish_backward (the earlier passes' recurrences would otherwise meet the
         # collectives of a slice that is complete for THEIR pass only)
@@ -159,8 +167,11 @@ class Communicator(object):
 
     # recurrence boundaries (see the module docstring)
     def _before_recurrence(self):
-        self._defer = self._met_recurrence = True
+        self._met_recurrence = True
         self._rec_count += 1
+        if self.beside_recurrences:
+            return              # collectives in flight stay in flight; slices keep going the moment they are complete
+        self._defer = True
         self._join_pending()
 
     def _after_recurrence(self):

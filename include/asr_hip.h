@@ -18,11 +18,16 @@ extern "C" {
 #endif
 
 int asr_version(void);
-/* a one-wave kernel that idles for `microseconds` (<= 100000) on `stream`: used to stagger two concurrent half batches */
+/* a one-wave kernel that idles for `microseconds` (<= 100000) on `stream`: a timed gap (experiments) */
 int asr_stream_delay(void* stream, int microseconds);
 /* diagnostic: `blocks` workgroups holding `lds_bytes` of LDS each idle for `microseconds` (<= 200000) on `stream` -- makes CUs
  * temporarily unavailable to launches on other streams (tests of the persistent GRU kernels under partial residency) */
 int asr_occupy_cus(void* stream, int microseconds, int lds_bytes, int blocks);
+/* diagnostic: the stand-in for a resident collective -- `blocks` workgroups (256 threads, `lds_bytes` of LDS each) that stream
+ * buf[0, bytes / 2) into buf[bytes / 2, bytes) (read, add, write; buf 16-B aligned, float32) until `microseconds` (<= 200000) have
+ * passed.  The reference has no multi-GPU path ("NCCL call sites: zero"); this measures, on one GPU, what an
+ * RCCL ring kernel resident beside a persistent recurrence would cost it. */
+int asr_stream_traffic(void* stream, int microseconds, int lds_bytes, int blocks, void* buf, long long bytes);
 
 /* ---------------------------------------------------------------------------------------- CTC family
  * Replaces chainer.functions.connectionist_temporal_classification (call sites run/ctc/cnn/train.py:162,191,

@@ -842,6 +842,37 @@ def test_persistent_recurrence_waits_out_busy_cus(device):
     assert t0.elapsed_time(t1) > 25.0          # the hog really was in the way
 
 
+def test_persistent_recurrence_beside_a_resident_collective_stand_in(device):
+    """a collective kernel that is RESIDENT while a recurrence runs -- 16 workgroups that stream memory with 16 KB of LDS
+    each (asr_stream_traffic), i.e. small enough to sit beside a recurrence workgroup on its CU -- costs the recurrence time (measured
+    +14 .. +35 %, tools/gru_beside_collective.py) but neither an abort nor a different result: the hand-off protocol depends on no timing."""
+    from asr import _ops, _lib
+    T, B, H, ndir = 400, 32, 512, 2
+    g = torch.Generator().manual_seed(5)
+    gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device).to(_ops.gru_gi_dtype(T, B, H, ndir))
+    whh = (torch.randn(ndir, 3 * H, H, generator=g) / H ** 0.5).to(device)
+    whh16, whhT16 = whh.to(torch.bfloat16).contiguous(), whh.transpose(1, 2).contiguous().to(torch.bfloat16)
+    bhh = (torch.randn(ndir * 3 * H, generator=g) * 0.1).to(device)
+    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    scratch = torch.zeros(16 * 1024 * 1024, device=device)
+    side = torch.cuda.Stream()
+
+    def run(beside):
+        torch.cuda.synchronize()
+        if beside:
+            _lib.check(_lib.lib().asr_stream_traffic(side.cuda_stream, 20000, 16 * 1024, 16, scratch.data_ptr(), scratch.numel() * 4), "asr_stream_traffic")
+            _lib.lib().asr_stream_delay(_lib.stream(), 300)
+        y, hseq, hseq16, gates = _ops.gru_fwd(gi.clone(), whh16, bhh, T, B, H, ndir)
+        dbi, dbh = torch.zeros(ndir * 3 * H, device=device), torch.zeros(ndir * 3 * H, device=device)
+        dgi, dgh = _ops.gru_bwd(dy, gates, hseq, whhT16, T, B, H, ndir, dbi, dbh)
+        torch.cuda.synchronize()
+        _ops.gru_check_sync()
+        return [t.clone() for t in (y, hseq, _ops.gru_gates_standard(gates, H), dgi, dgh)]
+    ref, got = run(False), run(True)
+    for a, b_ in zip(ref, got):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_wide_nt_kernels_in_a_forced_process(mode):
     """the 256 x 256 NT kernels (csrc/gemm.hip gemm_nt_wide_kernel) normally serve only large convolutions; ASR_DEBUG nt_wide /

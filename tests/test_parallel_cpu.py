@@ -143,14 +143,14 @@ def _ds2_parameters():
     return out
 
 
-def _plan_worker(rank, world, port, q, buckets):
+def _plan_worker(rank, world, port, q, buckets, beside=False):
     """replays the order in which asr/functions.py queues kernels and announces gradients during the backward pass of the
     BASELINE model -- including _GRU.backward's bias-gradients-first / w_ih-before-w_hh order and the recurrence hooks --
     and checks at every all-reduce launch that every writer of the slice has been queued"""
     _env(rank, world, port)
     from asr import link, _ops
     from asr.parallel import Communicator
-    comm = Communicator("gloo", buckets=buckets)
+    comm = Communicator("gloo", buckets=buckets, beside_recurrences=beside)
     names = _ds2_parameters()
     opt = _FakeOpt([n for _, n in names], rank)
     index = {name: i for i, (name, _) in enumerate(names)}
@@ -222,6 +222,21 @@ def test_baseline_plan_never_reduces_a_slice_before_its_writers(buckets):
         assert second[-1][1] == n_params
         first = launches[:nslices]                  # first step: nothing known yet, the first GRU layer's slice waits for the end
         assert first[-2][1] == n_params
+
+
+def test_slices_may_go_beside_recurrences_on_request():
+    """Communicator(beside_recurrences=True) (the measured alternative of DESIGN.md section 13.5): no launch waits for a recurrence boundary
+    -- already in the FIRST step every slice but the front one is on its way before the convolutions' gradients are written --, the
+    order is still the same on every rank and no slice goes before its writers."""
+    res = _run(_plan_worker, 2, (4, True))
+    for rank, violations, launches, nslices, ok in res:
+        assert violations == [] and ok
+        assert sorted(k for k, _, _ in launches[-nslices:]) == list(range(nslices))
+    assert res[0][2] == res[1][2]
+    _, _, launches, nslices, _ = res[0]
+    n_params = len(_ds2_parameters())
+    first = launches[:nslices]
+    assert all(written <= n_params - 4 for k, written, _ in first[:-1]), first
 
 
 def test_plan_keeps_the_last_slice_small():
