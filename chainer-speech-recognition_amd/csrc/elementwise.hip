@@ -645,7 +645,7 @@ __global__ void maxout2_pool_fwd_kernel(const uint16_t* __restrict__ x, uint16_t
 // 256 % (C / 8) == 0: then a thread meets the same eight channel pairs in every round of its grid-stride loop.
 __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                         uint16_t* __restrict__ dx, float* __restrict__ db, long long R, int Hin, int Hout, int C, int k) {
-    __shared__ float red[256 * 16];
+    __shared__ float red[16 * (256 + 32)];
     const int c8n = C >> 3;
     const long long n = R * Hout * c8n;
     float bsum[16];
@@ -698,16 +698,18 @@ __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const ui
         }
     }
     if (db) {       // threads tid, tid + c8n, ... hold the same channels: one atomic per channel and workgroup
-        // image [e][thread]: a wave writes 64 consecutive floats per e and the folding threads of one e read consecutive ones
-        // (the [thread][16] image was a 16-way bank conflict on every access: 0.88 of this kernel's LDS cycles, profiles/r03_pmc_sq.csv)
+        // image [e][thread], pitch 256 + c8n floats: a wave writes 64 consecutive floats per e; the folding threads (e, c8) of a wave read
+        // banks e c8n + c8 (mod 32): at most two per bank.  (The [thread][16] image was a 16-way bank conflict on every access: 0.88 of
+        // this kernel's LDS cycles, profiles/r03_pmc_sq.csv; pitch 256 still put the eight e of a wave on the same banks: 0.60.)
+        const int pitch = 256 + (c8n < 32 ? c8n : 32);      // (c8n >= 32: a wave's folding threads span at most two e)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[e * 256 + threadIdx.x] = bsum[e];
+        for (int e = 0; e < 16; ++e) red[e * pitch + threadIdx.x] = bsum[e];
         __syncthreads();
         const int t = threadIdx.x;
         if (t < c8n * 16) {
             const int e = t / c8n, c8 = t - e * c8n;
             float s = 0.f;
-            for (int u = c8; u < 256; u += c8n) s += red[e * 256 + u];
+            for (int u = c8; u < 256; u += c8n) s += red[e * pitch + u];
             atomicAdd(db + c8 * 16 + e, s);
         }
     }
