@@ -621,7 +621,7 @@ def time_cnn_config(args, nconv, dev, steps=10):
 def sq_profile():
     """per-kernel SQ counter summary of a `bench.py` step (rocprofv3 --pmc passes condensed by tools/pmc_sq.py into profiles/): a
     process cannot read its own PMC counters, so the line quotes the committed pass of this same command"""
-    for name in ("r03_pmc_sq.json",):
+    for name in ("r04_pmc_sq.json", "r03_pmc_sq.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
@@ -891,7 +891,7 @@ def main():
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
         traffic, traffic_src = None, None
-        pmc_path = next((os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic_v9.json")
+        pmc_path = next((os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v9.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         if pmc_path is not None:
             ks = json.load(open(pmc_path))["kernels"]

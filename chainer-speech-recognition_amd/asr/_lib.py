@@ -129,6 +129,12 @@ SIGNATURES = {
     "asr_unpool_h_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int, c_int]),
     "asr_unpool_h_bwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_int, c_int]),
     "asr_gaussian_noise": (c_int, [c_void_p] * 3 + [c_longlong, c_float, ctypes.c_uint]),
+    "asr_maxpool_h_indexes": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int]),
+    "asr_upsample_h_fwd": (c_int, [c_void_p] * 4 + [c_longlong] + [c_int] * 4),
+    "asr_upsample_h_bwd": (c_int, [c_void_p] * 4 + [c_longlong] + [c_int] * 4),
+    "asr_spp_bins": (c_int, [c_int]),
+    "asr_spp_fwd": (c_int, [c_void_p] * 4 + [c_int] * 5),
+    "asr_spp_bwd": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "asr_sgd_ctl": (c_int, [c_void_p] * 4 + [c_longlong, c_int] + [c_float] * 3 + [c_void_p]),
 }
 

@@ -852,6 +852,52 @@ def unpool_h_bwd(dy, H, k):
     return dx
 
 
+def maxpool_h_indexes(x, k):
+    """x (T, B, H, C) bf16 -> uint8 (T, B, Hout, C): row inside its window of the first maximum (what max_pooling_2d routes its gradient to)"""
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    T, B, H, C = x.shape
+    idx = torch.empty((T, B, pooled_height(H, k), C), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().asr_maxpool_h_indexes(stream(), ptr(x), ptr(idx), T * B, H, C, k), "asr_maxpool_h_indexes")
+    return idx
+
+
+def upsample_h_fwd(x, idx, k, Hout):
+    assert x.dtype == BF16 and x.is_contiguous() and idx.dtype == torch.uint8 and idx.is_contiguous() and idx.shape == x.shape
+    T, B, H, C = x.shape
+    y = torch.empty((T, B, Hout, C), dtype=BF16, device=x.device)
+    check(_lib.lib().asr_upsample_h_fwd(stream(), ptr(x), ptr(idx), ptr(y), T * B, H, Hout, C, k), "asr_upsample_h_fwd")
+    return y
+
+
+def upsample_h_bwd(dy, idx, k):
+    T, B, Hout, C = dy.shape
+    H = idx.shape[2]
+    dx = torch.empty((T, B, H, C), dtype=BF16, device=dy.device)
+    check(_lib.lib().asr_upsample_h_bwd(stream(), ptr(dy.contiguous()), ptr(idx), ptr(dx), T * B, H, Hout, C, k), "asr_upsample_h_bwd")
+    return dx
+
+
+def spp_fwd(x, pyramid_height, want_pos):
+    """x (T, B, H, C) bf16 -> y (B, bins, C) bf16 [, pos (B, bins, C) int32]"""
+    assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+    T, B, H, C = x.shape
+    bins = _lib.lib().asr_spp_bins(int(pyramid_height))
+    if bins <= 0:
+        raise ValueError("pyramid_height must be in 1..8")
+    y = torch.empty((B, bins, C), dtype=BF16, device=x.device)
+    pos = torch.empty((B, bins, C), dtype=torch.int32, device=x.device) if want_pos else None
+    check(_lib.lib().asr_spp_fwd(stream(), ptr(x), ptr(y), ptr(pos), T, B, H, C, int(pyramid_height)), "asr_spp_fwd")
+    return y, pos
+
+
+def spp_bwd(dy, pos, shape, pyramid_height):
+    T, B, H, C = shape
+    dx32 = torch.empty((T, B, H, C), dtype=F32, device=dy.device)
+    fill_(dx32, 0.0)
+    check(_lib.lib().asr_spp_bwd(stream(), ptr(dy.contiguous()), ptr(pos), ptr(dx32), T, B, H, C, int(pyramid_height)), "asr_spp_bwd")
+    return cast_bf16(dx32.reshape(T * B * H, C)).reshape(T, B, H, C)
+
+
 def gaussian_noise(x, std, seed):
     assert x.dtype == BF16
     x = x.contiguous()

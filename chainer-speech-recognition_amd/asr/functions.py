@@ -856,14 +856,75 @@ def unpooling_2d(x, ksize, stride=None, pad=0, outsize=None, cover_all=True):
     return logical4(_UnpoolH.apply(p, k, Hout))
 
 
+class _UpsampleH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, idx, k, Hout):
+        ctx.save_for_backward(idx)
+        ctx.k = k
+        return _ops.upsample_h_fwd(p, idx, k, Hout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        return _ops.upsample_h_bwd(gy.contiguous(), idx, ctx.k), None, None, None
+
+
+def max_pooling_2d_indexes(x, ksize):
+    """the `indexes` attribute of Chainer's MaxPooling2D function object for max_pooling_2d(x, (k, 1)): where inside its window every
+    maximum sits (first one on ties) -- what upsampling_2d takes.  Logical (B, C, Hout, T) uint8."""
+    kh, kw = (ksize, ksize) if isinstance(ksize, int) else ksize
+    if kw != 1:
+        raise NotImplementedError("max pooling on the HIP path: ksize (k, 1)")
+    idx = _ops.maxpool_h_indexes(phys4(x.detach()), int(kh))            # physical (T, B, Hout, C)
+    return idx.permute(1, 3, 2, 0)
+
+
 def upsampling_2d(x, indexes, ksize, stride=None, pad=0, outsize=None, cover_all=True):
-    raise NotImplementedError("upsampling_2d needs the argmax indexes of a Chainer MaxPooling2D function object "
-                              "(asr/nn/nn.py:135-146 passes `indexes` through); max pooling on the HIP path recomputes them in its backward pass")
+    """chainer.functions.upsampling_2d (asr/nn/nn.py:135-146) for ksize (k, 1), stride = ksize: x[b][c][h][t] goes to row h k + indexes of
+    the output, every other entry is zero; output height as unpooling_2d.  `indexes`: logical (B, C, H, T) integers in [0, k) -- see
+    max_pooling_2d_indexes."""
+    k = _height_pooling_args(ksize, stride, pad, "upsampling_2d")
+    p = phys4(x)
+    H = p.shape[2]
+    Hout = (k * (H - 1) + 1 if cover_all else k * H) if outsize is None else int(outsize[0] if isinstance(outsize, (tuple, list)) else outsize)
+    if not (k * (H - 1) < Hout <= k * H):
+        raise ValueError("outsize %d does not fit %d input rows with ksize %d" % (Hout, H, k))
+    if tuple(indexes.shape) != tuple(x.shape):
+        raise ValueError("indexes %s must have the shape of x %s" % (tuple(indexes.shape), tuple(x.shape)))
+    idx = indexes.permute(3, 0, 2, 1)
+    if idx.dtype != torch.uint8 or not idx.is_contiguous():
+        idx = idx.to(torch.uint8).contiguous()
+    return logical4(_UpsampleH.apply(p, idx, k, Hout))
 
 
-def spatial_pyramid_pooling_2d(x, pyramid_height, pooling_class):
-    raise NotImplementedError("spatial_pyramid_pooling_2d pools over (height, time) jointly and returns a fixed-size vector per utterance: "
-                              "outside the per-frame acoustic path (asr/nn/nn.py:115-121 is never instantiated by the reference)")
+class _SppMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, height):
+        y, pos = _ops.spp_fwd(p, height, ctx.needs_input_grad[0])
+        ctx.pos, ctx.shape, ctx.height = pos, tuple(p.shape), height
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _ops.spp_bwd(gy.contiguous(), ctx.pos, ctx.shape, ctx.height), None
+
+
+def spatial_pyramid_pooling_2d(x, pyramid_height, pooling_class=None):
+    """chainer.functions.spatial_pyramid_pooling_2d (asr/nn/nn.py:115-121): x (B, C, H, T) -> (B, C (4^height - 1) / 3, 1, 1), for every
+    level l < height the maxima over 2^l x 2^l bins of the (H, T) plane, [c][by][bx] per level, levels concatenated along axis 1.
+    Chainer accepts max pooling only; `pooling_class` may be None, "max", nn.MaxPooling2D or anything whose name contains MaxPooling."""
+    name = pooling_class if isinstance(pooling_class, str) else getattr(pooling_class, "__name__", type(pooling_class).__name__ if pooling_class is not None else "max")
+    if pooling_class is not None and "max" not in name.lower():
+        raise NotImplementedError("spatial_pyramid_pooling_2d: max pooling only (as in Chainer)")
+    p = phys4(x)
+    B, C = x.shape[0], x.shape[1]
+    y = _SppMax.apply(p, int(pyramid_height))              # (B, bins, C), bins level after level
+    parts, o = [], 0
+    for l in range(int(pyramid_height)):
+        n = 4 ** l
+        parts.append(y[:, o:o + n, :].permute(0, 2, 1).reshape(B, C * n))        # [c][by][bx]
+        o += n
+    return torch.cat(parts, dim=1).reshape(B, -1, 1, 1)
 
 
 class _GaussianNoise(torch.autograd.Function):

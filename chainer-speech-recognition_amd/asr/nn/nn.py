@@ -90,11 +90,11 @@ for _name, _fn, _sig, _doc in (
         ("AveragePooling2D", functions.average_pooling_2d, (("ksize", _REQUIRED), ("stride", None), ("pad", 0)), "asr/nn/nn.py:77-84"),
         ("AveragePoolingND", functions.average_pooling_nd, (("ksize", _REQUIRED), ("stride", None), ("pad", 0)), "asr/nn/nn.py:86-93"),
         ("SpatialPyramidPooling2D", functions.spatial_pyramid_pooling_2d, (("pyramid_height", _REQUIRED), ("pooling_class", _REQUIRED)),
-         "asr/nn/nn.py:115-121 (not on the HIP path: raises when called)"),
+         "asr/nn/nn.py:115-121 (max pooling, as Chainer)"),
         ("Unpooling2D", functions.unpooling_2d, (("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("outsize", None), ("cover_all", True)),
          "asr/nn/nn.py:123-133"),
         ("UpSampling2D", functions.upsampling_2d, (("indexes", _REQUIRED), ("ksize", _REQUIRED), ("stride", None), ("pad", 0), ("outsize", None),
-                                                   ("cover_all", True)), "asr/nn/nn.py:135-146 (not on the HIP path: raises when called)"),
+                                                   ("cover_all", True)), "asr/nn/nn.py:135-146 (indexes: functions.max_pooling_2d_indexes)"),
         # array manipulation (:148-207): views of the physical buffer
         ("BroadcastTo", functions.broadcast_to, (("shape", _REQUIRED),), None),
         ("ExpandDims", functions.expand_dims, (("axis", _REQUIRED),), None),

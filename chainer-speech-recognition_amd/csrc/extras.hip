@@ -141,6 +141,101 @@ __global__ void gaussian_noise_kernel(const uint16_t* __restrict__ x, uint16_t* 
 }
 
 }  // namespace extras
+// chainer.functions.upsampling_2d (asr/nn/nn.py:135-146): the inverse of a max pooling given the pooling's argmax positions
+// (`indexes` of a MaxPooling2D function object: the window-local position of every maximum; ksize (k, 1), stride = ksize here, so the
+// position is the row inside the window).  maxpool_h_indexes forms them (first maximum, as max_pooling_2d routes its gradient);
+// upsample: y[r][h k + j][c] = x[r][h][c] where j = idx[r][h][c], zero elsewhere; backward: dx[r][h][c] = dy[r][h k + idx][c].
+__global__ void maxpool_h_indexes_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ idx, long long R, int Hin, int Hout, int C, int k) {
+    const long long n = R * Hout * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ho = (int)((i / C) % Hout);
+        const long long r = i / ((long long)C * Hout);
+        float m = -INFINITY;
+        int best = 0;
+        for (int j = 0; j < k; ++j) {
+            const int h = ho * k + j;
+            if (h >= Hin) break;
+            const float v = bf16_to_f32(x[(r * Hin + h) * C + c]);
+            if (v > m) { m = v; best = j; }
+        }
+        idx[i] = (uint8_t)best;
+    }
+}
+__global__ void upsample_h_fwd_kernel(const uint16_t* __restrict__ x, const uint8_t* __restrict__ idx, uint16_t* __restrict__ y, long long R, int Hin,
+                                      int Hout, int C, int k) {
+    const long long n = R * Hout * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ho = (int)((i / C) % Hout);
+        const long long r = i / ((long long)C * Hout);
+        const long long src = (r * Hin + ho / k) * C + c;
+        y[i] = (int)idx[src] == ho % k ? x[src] : (uint16_t)0;
+    }
+}
+__global__ void upsample_h_bwd_kernel(const uint16_t* __restrict__ dy, const uint8_t* __restrict__ idx, uint16_t* __restrict__ dx, long long R,
+                                      int Hin, int Hout, int C, int k) {
+    const long long n = R * Hin * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int h = (int)((i / C) % Hin);
+        const long long r = i / ((long long)C * Hin);
+        const int ho = h * k + (int)idx[i];
+        dx[i] = ho < Hout ? dy[(r * Hout + ho) * C + c] : (uint16_t)0;
+    }
+}
+
+// chainer.functions.spatial_pyramid_pooling_2d (asr/nn/nn.py:115-121), max pooling: level l cuts the (H, T) plane of every (utterance,
+// channel) into 2^l x 2^l bins -- window (ceil(H / 2^l), ceil(T / 2^l)), stride = window, padded by ((2^l kh - H + 1) / 2, likewise in
+// time) with -inf, as Chainer's MaxPooling2D(ksize, pad, cover_all) does -- and keeps the maximum of every bin.  Output row b holds,
+// level after level, [c][by][bx] (the reference's reshape to (B, C 4^l, 1, 1) and concat along axis 1): here (B, sum_l 4^l, C) with the
+// channels innermost, which the wrapper permutes.  x is the physical (T, B, H, C) tensor.  One thread per (b, bin, c): channels run
+// across lanes, so every load of the window sweep is a coalesced row segment.  pos (optional) receives the flat (h T + t) position
+// of the first maximum in (h, t) row-major order -- Chainer's argmax over the flattened window -- for the backward scatter.
+struct SppBin { int level, by, bx, kh, kw, ph, pt; };
+__device__ __forceinline__ SppBin spp_bin(int bin, int H, int T) {
+    SppBin s;
+    int l = 0, base = 0;
+    while (bin >= base + (1 << (2 * l))) { base += 1 << (2 * l); ++l; }
+    const int nb = 1 << l, o = bin - base;
+    s.level = l; s.by = o / nb; s.bx = o - s.by * nb;
+    s.kh = (H + nb - 1) / nb; s.kw = (T + nb - 1) / nb;
+    s.ph = (nb * s.kh - H + 1) / 2; s.pt = (nb * s.kw - T + 1) / 2;
+    return s;
+}
+__global__ void spp_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int* __restrict__ pos, int T, int B, int H, int C, int bins) {
+    const long long n = (long long)B * bins * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int bin = (int)((i / C) % bins);
+        const int b = (int)(i / ((long long)C * bins));
+        const SppBin s = spp_bin(bin, H, T);
+        const int h0 = max(0, s.by * s.kh - s.ph), h1 = min(H, s.by * s.kh - s.ph + s.kh);
+        const int t0 = max(0, s.bx * s.kw - s.pt), t1 = min(T, s.bx * s.kw - s.pt + s.kw);
+        float m = -INFINITY;
+        int best = -1;
+        for (int h = h0; h < h1; ++h)
+            for (int t = t0; t < t1; ++t) {
+                const float v = bf16_to_f32(x[(((long long)t * B + b) * H + h) * C + c]);
+                if (v > m) { m = v; best = h * T + t; }
+            }
+        y[i] = f32_to_bf16(m);
+        if (pos) pos[i] = best;
+    }
+}
+// dx32 (T, B, H, C) float32, zeroed by the caller: several levels route their gradient to the same element
+__global__ void spp_bwd_kernel(const uint16_t* __restrict__ dy, const int* __restrict__ pos, float* __restrict__ dx32, int T, int B, int H, int C, int bins) {
+    const long long n = (long long)B * bins * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int p = pos[i];
+        if (p < 0) continue;
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long long)C * bins));
+        const int h = p / T, t = p - h * T;
+        atomicAdd(dx32 + (((long long)t * B + b) * H + h) * C + c, bf16_to_f32(dy[i]));
+    }
+}
+
 }  // namespace asr
 
 using namespace asr;
@@ -209,6 +304,51 @@ extern "C" int asr_unpool_h_bwd(void* stream, const void* dy, void* dx, long lon
 extern "C" int asr_gaussian_noise(void* stream, const void* x, void* y, long long n, float stdv, unsigned int seed) {
     if (!x || !y || n <= 0 || !(stdv >= 0.f)) return ASR_ERR_BAD_ARG;
     hipLaunchKernelGGL(gaussian_noise_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, n, stdv, seed);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_maxpool_h_indexes(void* stream, const void* x, void* idx_u8, long long R, int Hin, int C, int k) {
+    if (!x || !idx_u8 || R <= 0 || Hin <= 0 || C <= 0 || k <= 0 || k > 255) return ASR_ERR_BAD_ARG;
+    const int Hout = Hin <= k ? 1 : cdiv(Hin - k, k) + 1;       // cover_all, stride = k
+    hipLaunchKernelGGL(maxpool_h_indexes_kernel, dim3(grid_for(R * Hout * C)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint8_t*)idx_u8,
+                       R, Hin, Hout, C, k);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_upsample_h_fwd(void* stream, const void* x, const void* idx_u8, void* y, long long R, int Hin, int Hout, int C, int k) {
+    if (!x || !idx_u8 || !y || R <= 0 || Hin <= 0 || C <= 0 || k <= 0 || Hout <= 0 || Hout > Hin * k) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_h_fwd_kernel, dim3(grid_for(R * Hout * C)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (const uint8_t*)idx_u8, (uint16_t*)y, R, Hin, Hout, C, k);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_upsample_h_bwd(void* stream, const void* dy, const void* idx_u8, void* dx, long long R, int Hin, int Hout, int C, int k) {
+    if (!dy || !idx_u8 || !dx || R <= 0 || Hin <= 0 || C <= 0 || k <= 0 || Hout <= 0 || Hout > Hin * k) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(upsample_h_bwd_kernel, dim3(grid_for(R * Hin * C)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)dy,
+                       (const uint8_t*)idx_u8, (uint16_t*)dx, R, Hin, Hout, C, k);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_spp_bins(int pyramid_height) {
+    if (pyramid_height <= 0 || pyramid_height > 8) return -1;
+    int n = 0;
+    for (int l = 0; l < pyramid_height; ++l) n += 1 << (2 * l);
+    return n;
+}
+extern "C" int asr_spp_fwd(void* stream, const void* x, void* y, int* pos, int T, int B, int H, int C, int pyramid_height) {
+    const int bins = asr_spp_bins(pyramid_height);
+    if (!x || !y || T <= 0 || B <= 0 || H <= 0 || C <= 0 || bins <= 0 || (long long)H * T > 0x7fffffffLL) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(spp_fwd_kernel, dim3(grid_for((long long)B * bins * C)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y,
+                       pos, T, B, H, C, bins);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+extern "C" int asr_spp_bwd(void* stream, const void* dy, const int* pos, float* dx32, int T, int B, int H, int C, int pyramid_height) {
+    const int bins = asr_spp_bins(pyramid_height);
+    if (!dy || !pos || !dx32 || T <= 0 || B <= 0 || H <= 0 || C <= 0 || bins <= 0) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3(grid_for((long long)B * bins * C)), dim3(kThreads), 0, (hipStream_t)stream, (const uint16_t*)dy, pos, dx32,
+                       T, B, H, C, bins);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

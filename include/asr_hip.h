@@ -403,6 +403,21 @@ int asr_avgpool_h_bwd(void* stream, const void* dy, void* dx, long long R, int H
 int asr_unpool_h_fwd(void* stream, const void* x, void* y, long long R, int Hin, int Hout, int C, int k);
 int asr_unpool_h_bwd(void* stream, const void* dy, void* dx, long long R, int Hin, int Hout, int C, int k);
 int asr_gaussian_noise(void* stream, const void* x, void* y, long long n, float stdv, unsigned int seed);
+/* asr/nn/nn.py:135-146 UpSampling2D = chainer.functions.upsampling_2d: the inverse of a max pooling given its argmax positions
+ * (`indexes` of a MaxPooling2D function object; ksize (k, 1), stride = ksize: the row inside the window).  asr_maxpool_h_indexes forms
+ * them as uint8 (R, Hout, C) with Hout = the cover_all output height; upsample forward: y (R, Hout', C) with x[r][h][c] at row
+ * h k + idx and zeros elsewhere; backward: dx[r][h][c] = dy[r][h k + idx][c]. */
+int asr_maxpool_h_indexes(void* stream, const void* x, void* idx_u8, long long R, int Hin, int C, int k);
+int asr_upsample_h_fwd(void* stream, const void* x, const void* idx_u8, void* y, long long R, int Hin, int Hout, int C, int k);
+int asr_upsample_h_bwd(void* stream, const void* dy, const void* idx_u8, void* dx, long long R, int Hin, int Hout, int C, int k);
+/* asr/nn/nn.py:115-121 SpatialPyramidPooling2D = chainer.functions.spatial_pyramid_pooling_2d with max pooling: level l < pyramid_height
+ * pools the (H, T) plane of every (utterance, channel) over 2^l x 2^l bins (window ceil(size / 2^l), stride = window, -inf padding of
+ * (2^l k - size + 1) / 2).  x: the physical (T, B, H, C) bf16 tensor; y: (B, asr_spp_bins(pyramid_height), C) bf16, bins level after
+ * level, [by][bx] inside a level; pos (same shape, int32, may be NULL): flat h T + t position of each maximum (first one in (h, t)
+ * order) for asr_spp_bwd, which ADDS dy into dx32 (T, B, H, C) float32 (zeroed by the caller: levels overlap). */
+int asr_spp_bins(int pyramid_height);
+int asr_spp_fwd(void* stream, const void* x, void* y, int* pos, int T, int B, int H, int C, int pyramid_height);
+int asr_spp_bwd(void* stream, const void* dy, const int* pos, float* dx32, int T, int B, int H, int C, int pyramid_height);
 
 #ifdef __cplusplus
 }

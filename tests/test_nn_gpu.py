@@ -588,10 +588,8 @@ def test_crelu_softmax_pooling_layers(device):
         assert e[0] == 0.0 and e[1] < 4e-3, (cover_all, e)
     with pytest.raises(NotImplementedError):
         nn.Softmax(axis=2)(x.to(device))
-    with pytest.raises(NotImplementedError):
-        nn.UpSampling2D(None, (2, 1))(x.to(device))
-    with pytest.raises(NotImplementedError):
-        nn.SpatialPyramidPooling2D(2, None)(x.to(device))
+    with pytest.raises(NotImplementedError):          # (pooling over time is outside the height-pooling layers; UpSampling2D and
+        nn.UpSampling2D(None, (2, 2))(x.to(device))   # SpatialPyramidPooling2D themselves: test_upsampling_and_spatial_pyramid_pooling)
     # 3-d (B, D, T) and 2-d inputs take the same kernels
     x3 = _bf(torch.randn(3, 10, 8))
     y3 = nn.Softmax()(x3.to(device))
@@ -621,3 +619,73 @@ def test_gaussian_noise_layer(device):
         assert layer(xd) is xd
     finally:
         F.train_mode[0] = True
+
+
+def test_upsampling_and_spatial_pyramid_pooling(device):
+    """asr/nn/nn.py:135-146 UpSampling2D (chainer.functions.upsampling_2d: the inverse of a max pooling given its argmax `indexes`) and
+    :115-121 SpatialPyramidPooling2D (max pooling over 2^l x 2^l bins of the (H, T) plane per level) -- Chainer functions in the reference
+    (unpinned boundary): checked against their definitions in numpy / torch-CPU, forward and backward"""
+    import asr.nn as nn
+    from asr import functions as F
+    B, C, H, T, k = 2, 8, 7, 5, 3
+    x = _img(B, C, H, T, 3)
+    xd = x.to(device).to(BF16)
+    # indexes of max_pooling_2d(x, (k, 1)) (cover_all: Hout = 3) and the pooled values
+    idx = F.max_pooling_2d_indexes(xd, (k, 1))
+    pooled = F.max_pooling_2d(xd, (k, 1))
+    Hp = pooled.shape[2]
+    xp = torch.full((B, C, Hp * k, T), float("-inf"))
+    xp[:, :, :H] = x
+    win = xp.reshape(B, C, Hp, k, T)
+    assert torch.equal(idx.cpu().long(), win.argmax(dim=3))
+    # upsampling the pooled tensor with those indexes puts every maximum back where it came from, zeros elsewhere
+    layer = nn.UpSampling2D(idx, (k, 1), outsize=(H, T), cover_all=True)
+    pd = pooled.detach().clone().requires_grad_(True)
+    up = layer(pd)
+    assert tuple(up.shape) == (B, C, H, T)
+    want = torch.zeros(B, C, Hp * k, T)
+    want.scatter_(2, (torch.arange(Hp).reshape(1, 1, Hp, 1) * k + idx.cpu().long()), pooled.detach().float().cpu())
+    assert torch.equal(up.detach().float().cpu(), want[:, :, :H])
+    gy = _img(B, C, H, T, 4)
+    up.backward(gy.to(device).to(BF16))
+    gyp = torch.zeros(B, C, Hp * k, T)
+    gyp[:, :, :H] = gy
+    assert torch.equal(pd.grad.float().cpu(), gyp.gather(2, torch.arange(Hp).reshape(1, 1, Hp, 1) * k + idx.cpu().long()))
+    # spatial pyramid pooling, three levels, on a plane whose sizes are not multiples of the bin counts
+    B, C, H, T, height = 2, 8, 13, 37, 3
+    x = _img(B, C, H, T, 5)
+    xr = x.clone().requires_grad_(True)
+    outs = []
+    for l in range(height):
+        nb = 2 ** l
+        kh, kw = -(-H // nb), -(-T // nb)
+        ph, pw = (nb * kh - H + 1) // 2, (nb * kw - T + 1) // 2
+        xpad = torch.nn.functional.pad(xr, (pw, nb * kw - T - pw, ph, nb * kh - H - ph), value=float("-inf"))
+        outs.append(xpad.reshape(B, C, nb, kh, nb, kw).amax(dim=(3, 5)).reshape(B, C * nb * nb))
+    yr = torch.cat(outs, dim=1).reshape(B, -1, 1, 1)
+    xd = x.to(device).to(BF16).requires_grad_(True)
+    y = nn.SpatialPyramidPooling2D(height, nn.MaxPooling2D)(xd)
+    assert tuple(y.shape) == tuple(yr.shape) == (B, C * 21, 1, 1)
+    assert torch.equal(y.detach().float().cpu(), yr.detach())
+    g = _bf(torch.randn(yr.shape, generator=torch.Generator().manual_seed(8)))
+    y.backward(g.to(device).to(BF16))
+    # the gradient of a bin goes to its FIRST maximum in (h, t) order (Chainer's argmax over the flattened window; bf16 inputs tie often,
+    # and torch's amax would split the gradient between equal values)
+    want, o = torch.zeros(B, C, H, T), 0
+    gflat = g.reshape(B, -1)
+    for l in range(height):
+        nb = 2 ** l
+        kh, kw = -(-H // nb), -(-T // nb)
+        ph, pw = (nb * kh - H + 1) // 2, (nb * kw - T + 1) // 2
+        gl = gflat[:, o:o + C * nb * nb].reshape(B, C, nb, nb)
+        o += C * nb * nb
+        for by in range(nb):
+            for bx in range(nb):
+                h0, h1 = max(0, by * kh - ph), min(H, by * kh - ph + kh)
+                t0, t1 = max(0, bx * kw - pw), min(T, bx * kw - pw + kw)
+                w = x[:, :, h0:h1, t0:t1].reshape(B, C, -1)
+                a = w.argmax(dim=2)
+                hh, tt = h0 + a // (t1 - t0), t0 + a % (t1 - t0)
+                for b in range(B):
+                    want[b, torch.arange(C), hh[b], tt[b]] += gl[b, :, by, bx]
+    assert _rel(xd.grad.float().cpu(), want) < 6e-3              # (up to three levels add into one element: one bf16 rounding of the sum)
