@@ -2173,6 +2173,8 @@ static int fwd_poll_delay(int H, bool ring) {
     // T=1000, B=32, us per step at 0 / best.  Ring form (whole-line stores into L2-resident slots): H=512 1.30 / 1.23 (5-6),
     // H=384 1.20 / 1.18 (3), H=256 1.03 / 1.00 (3), H=128 1.20 flat.  Sequence form (32-B pieces of fresh lines): H=512 1.49 / 1.34 (11),
     // H=384 1.41 / 1.39 (2-4), H=256 1.156 / 1.137 (2-4), H=128 1.24 / 1.21 (6-12)
+    // (round 4, after the partial-product image changed, H = 512: 0 1.225, 3 1.203, 4 1.188, 5 1.185, 6 1.189, 7 1.203, 8 1.225, 9 1.255 us per
+    // step -- flat between 4 and 6: 6 stays)
     if (ring) return H >= 512 ? 6 : 3;
     return H >= 512 ? kFirstPollDelay : (H >= 256 ? 3 : 6);
 }
