@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--num-conv-layers", type=int, default=4,
                     help="--config cnn: 4 = the reference's default depth (164 GFLOP/utterance); > 4 = the wide 'VGG-deep' "
                          "branch, always 8 conv layers (822 GFLOP/utterance): run/ctc/cnn/model.py:153-157,177-187")
+    ap.add_argument("--cnn-extra", type=int, default=0, help="(used by the default run for its fp16 lines) time ONLY the configs[4] recipe with "
+                    "this many conv layers in this process -- with the library ASR_ACT selects -- and print its extra_configs entry as JSON")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-census", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs (Gram-CTC at configs[3] size, the two configs[4] CNN steps, "
@@ -582,12 +584,16 @@ def time_cnn_config(args, nconv, dev, steps=10):
     opt.setup(model)
     opt.add_hook(GradientClipping(1.0))
     opt.add_hook(WeightDecay(1e-5))
+    half = _ops.BF16 is torch.float16          # the IEEE-half library (ASR_ACT=f16): dynamic loss scaling, as the reference's fp16 runs need
+    if half:
+        opt.loss_scaling()
 
     def step():
         loss = connectionist_temporal_classification(model(x), labels, 0, x_len, l_len)
         opt.update(lossfun=lambda: loss)
         return loss
     spread, loss = settled_steps(step, steps)
+    attempted, applied, scale = opt.t, opt.applied_steps(), opt.loss_scale()
     dt = spread["ms_per_step"] * steps * 1e-3
     census = Census()
     census.wrap(_ops)
@@ -605,8 +611,11 @@ def time_cnn_config(args, nconv, dev, steps=10):
     flops = 3 * 2.0 * macs * T * B
     floors = sum(max(e["mfma_floor_ms"], e["hbm_floor_ms"]) * e["calls"] for e in shapes)
     times = sum(e["ms_per_call"] * e["calls"] for e in shapes)
-    res = {"workload": "BASELINE configs[4] on one GPU: zhang+residual, %s, ndim_h 128, ndim_dense 320, B=%d, T=%d, V=%d, bf16 (see dtype_note)"
-                       % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V),
+    res = {"workload": "BASELINE configs[4] on one GPU: zhang+residual, %s, ndim_h 128, ndim_dense 320, B=%d, T=%d, V=%d, %s"
+                       % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V,
+                          "IEEE half MFMA operands / activations (libasr_hip_f16.so), dynamic loss scaling" if half else "bf16 (see dtype_note)"),
+           "dtype": "fp16" if half else "bf16", "steps_attempted": attempted, "steps_applied": applied, "loss_scale": scale[0],
+           "loss_scale_overflows": scale[1],
            "ms_per_step": dt / steps * 1e3, "utterances_per_s": B * steps / dt, "steps": steps, "step_spread": spread,
            "final_loss": float(loss.item()),
            "gflop_per_utterance": 3 * 2.0 * macs * T / 1e9,
@@ -616,6 +625,21 @@ def time_cnn_config(args, nconv, dev, steps=10):
     del model, opt
     torch.cuda.empty_cache()
     return res
+
+
+def cnn_extra_in_a_child(args, nconv):
+    import subprocess
+    env = dict(os.environ, ASR_ACT="f16")
+    env.pop("ASR_HIP_LIB", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cnn-extra", str(nconv), "--frames", str(args.frames)]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "child exited %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-400:])}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "child timed out"}
 
 
 def sq_profile():
@@ -743,6 +767,9 @@ def main():
     from asr.optimizers import Adam, GradientClipping, WeightDecay
     from asr.data.synthetic import synthetic_batch
     _lib.lib()      # fail loudly if the HIP library is missing
+    if args.cnn_extra:
+        print(json.dumps(time_cnn_config(args, args.cnn_extra, dev)))
+        return
 
     comm = None
     if world > 1 or os.environ.get("ASR_BENCH_FORCE_COMM") == "1":      # the latter: exercise the RCCL path on one GPU
@@ -803,8 +830,9 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "dtype_note": "bf16 MFMA operands / activations, float32 accumulation, master weights, optimiser state, statistics, logits and "
-                         "CTC; bf16 also stands in for the fp16 of BASELINE configs[4] (same MFMA rate on gfx950, no loss scaling needed: "
-                         "DESIGN.md section 11.1) -- no fp16 path exists",
+                         "CTC.  The fp16 of BASELINE configs[4] is the IEEE-half build of the same kernels (libasr_hip_f16.so, ASR_ACT=f16, "
+                         "with chainer's loss_scaling on the device): extra_configs.cnn_*_fp16, measured in child processes; the "
+                         "recurrences (configs[1], this line) are bfloat16-only (DESIGN.md 13.9)",
            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
            "config": {"workload": ("BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
                                    "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V)) if args.config == "ds2" else
@@ -975,6 +1003,10 @@ def main():
         torch.cuda.empty_cache()
         extra["cnn_4conv"] = time_cnn_config(args, 4, dev)
         extra["cnn_wide8"] = time_cnn_config(args, 8, dev)
+        # configs[4] quotes "fp16 MFMA": the same two steps on the IEEE-half library, which is a per-process choice (ASR_ACT) -- child
+        # processes, started the ordinary way (never an exec from this GPU-initialised one)
+        for nconv, key in ((4, "cnn_4conv_fp16"), (8, "cnn_wide8_fp16")):
+            extra[key] = cnn_extra_in_a_child(args, nconv)
         out["extra_configs"] = extra
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, T, V, dev)

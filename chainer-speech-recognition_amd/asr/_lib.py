@@ -9,10 +9,20 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ASR_HIP_LIB: another build of the same library (what-if builds of the timing tools); the default is the in-tree one
-LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libasr_hip.so")
+# ASR_HIP_LIB: another build of the same library (what-if builds of the timing tools); ASR_ACT=f16 (or float16 / half): the in-tree
+# IEEE-half build libasr_hip_f16.so (BASELINE configs[4]'s "fp16 MFMA": csrc/common.hpp); the default is the in-tree bfloat16 build.
+# Read once, when the first asr module is imported: one process, one activation format.
+_ACT = os.environ.get("ASR_ACT", "").lower()
+LIB_PATH = os.environ.get("ASR_HIP_LIB") or os.path.join(os.path.dirname(_HERE),
+                                                        "libasr_hip_f16.so" if _ACT in ("f16", "fp16", "float16", "half") else "libasr_hip.so")
 
 _lib = None
+
+
+def act_dtype():
+    """torch dtype of the 16-bit activation format of the loaded library (asr_act_dtype): bfloat16, or float16 for libasr_hip_f16.so.
+    The modules bind it once at import under the historical name BF16."""
+    return torch.float16 if lib().asr_act_dtype() else torch.bfloat16
 
 
 def debug_flag(key, default):
@@ -30,6 +40,7 @@ c_longlong = ctypes.c_longlong
 # name -> (restype, argtypes).  Mirrors include/asr_hip.h one to one; tests/test_abi.py checks both ways.
 SIGNATURES = {
     "asr_version": (c_int, []),
+    "asr_act_dtype": (c_int, []),
     "asr_stream_delay": (c_int, [c_void_p, c_int]),
     "asr_occupy_cus": (c_int, [c_void_p, c_int, c_int, c_int]),
     "asr_stream_traffic": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_longlong]),
@@ -119,6 +130,7 @@ SIGNATURES = {
     "asr_sqnorm_partials_count": (c_int, [c_longlong]),
     "asr_gather_abort": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "asr_step_control": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2 + [c_int]),
+    "asr_step_control_scaled": (c_int, [c_void_p, c_void_p, c_longlong] + [c_void_p] * 3 + [c_float] * 5 + [c_void_p] * 2 + [c_int, c_void_p]),
     "asr_adam_ctl": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 4 + [c_void_p]),
     "asr_crelu_fwd": (c_int, [c_void_p] * 3 + [c_longlong, c_int]),
     "asr_crelu_bwd": (c_int, [c_void_p] * 4 + [c_longlong, c_int]),

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream
 
-BF16 = torch.bfloat16
+BF16 = _lib.act_dtype()      # the 16-bit activation format of the loaded library: bfloat16 (default build) or float16 (ASR_ACT=f16)
 F32 = torch.float32
 
 
@@ -545,13 +545,15 @@ def clear_abort_words(dev):
             w.zero_()
 
 
-def step_control(g, partials, clip, grad_scale, alpha, beta1, beta2, applied, ctl, any_abort=None, reserved_index=-1):
-    """any_abort: the word gather_abort returned for this step (None: gathered here); reserved_index: see asr_hip.h"""
+def step_control(g, partials, clip, grad_scale, alpha, beta1, beta2, applied, ctl, any_abort=None, reserved_index=-1, loss_scale=None):
+    """any_abort: the word gather_abort returned for this step (None: gathered here); reserved_index, loss_scale (device float[4] or
+    None): see asr_hip.h"""
     if any_abort is None:
         any_abort = gather_abort(g.device)
-    rc = _lib.lib().asr_step_control(stream(), ptr(g), g.numel(), ptr(partials), ptr(any_abort), None, float(clip), float(grad_scale),
-                                     float(alpha), float(beta1), float(beta2), ptr(applied), ptr(ctl), int(reserved_index))
-    check(rc, "asr_step_control")
+    rc = _lib.lib().asr_step_control_scaled(stream(), ptr(g), g.numel(), ptr(partials), ptr(any_abort), None, float(clip),
+                                            float(grad_scale), float(alpha), float(beta1), float(beta2), ptr(applied), ptr(ctl),
+                                            int(reserved_index), None if loss_scale is None else ptr(loss_scale))
+    check(rc, "asr_step_control_scaled")
 
 
 def sqnorm_partials_count(n):

@@ -20,7 +20,7 @@ from . import _ops
 from ._lib import debug_flag as _lib_debug
 from .link import grad_buffer, grads_queued
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32 = _ops.BF16, torch.float32       # BF16: the library's 16-bit activation format (bfloat16, or float16 with ASR_ACT=f16)
 
 
 # ---------------------------------------------------------------------------------------------- side stream
@@ -1077,7 +1077,7 @@ def batch_normalization(x, gamma, beta, avg_mean, avg_var, eps=2e-5, decay=0.9):
 # ---------------------------------------------------------------------------------------------- GRU
 def _cast_transposed_per_direction(w):
     """(ndir, 3H, H) f32 -> (ndir, H, 3H) bf16, written in place (no torch.stack copy)."""
-    out = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+    out = torch.empty((w.shape[0], w.shape[2], w.shape[1]), dtype=BF16, device=w.device)
     for d in range(w.shape[0]):
         _ops.cast_bf16(w[d], transpose=True, out=out[d])
     return out

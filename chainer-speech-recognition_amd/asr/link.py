@@ -9,8 +9,10 @@ import math
 
 import torch
 
+from . import _lib
+
 F32 = torch.float32
-BF16 = torch.bfloat16
+BF16 = _lib.act_dtype()      # the 16-bit activation format of the loaded library: bfloat16 (default build) or float16 (ASR_ACT=f16)
 
 # bumped by the optimisers after every in-place parameter update done behind torch's back (HIP kernels)
 _WEIGHT_EPOCH = [0]

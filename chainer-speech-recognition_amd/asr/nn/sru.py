@@ -9,7 +9,7 @@ import torch
 from .. import functions, _ops
 from ..link import Link, Parameter, get_initializer, grad_buffer, grads_queued
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32 = _ops.BF16, torch.float32
 
 
 class SRUFunction(torch.autograd.Function):

@@ -44,6 +44,8 @@ class Optimizer(object):
         self._gave_up = [None, None, 0]     # pinned host copy of ctl[6] (give-up drops so far), event of that copy, update it was queued behind
         self._gave_up_reported = 0.0
         self._incident_until = -1           # last update attributed to the incident reported last
+        self._loss_scaling = None           # (interval, initial scale) once loss_scaling() was called
+        self._ls = None                     # device float[4]: asr_step_control_scaled's loss_scale
 
     # -- Chainer surface ---------------------------------------------------------------------------
     def setup(self, link):
@@ -64,6 +66,29 @@ class Optimizer(object):
             # forward pass would still run on the rank-local weights
             self._broadcast_state()
 
+    def loss_scaling(self, interval=1000, scale=None):
+        """chainer.Optimizer.loss_scaling: seed the backward pass with a loss scale S and take it out again in the update, so that
+        small activation gradients survive a 16-bit format with a 5-bit exponent (the IEEE-half library, ASR_ACT=f16; harmless with
+        bfloat16).  scale=None: dynamic -- S starts at 4096, is halved whenever a gradient overflows (that step is dropped, as every
+        step with a non-finite gradient is) and doubled after `interval` applied steps in a row; a number: static.  S lives on the
+        device and is changed there (asr_step_control_scaled): no host synchronisation, identical on every data-parallel rank."""
+        self._loss_scaling = (int(interval) if scale is None else 0, 4096.0 if scale is None else float(scale))
+        self._ls = None
+
+    def loss_scale(self):
+        """(S, overflows so far) -- synchronises: tests / logging only"""
+        if self._ls is None:
+            return (1.0 if self._loss_scaling is None else self._loss_scaling[1]), 0
+        v = self._ls.cpu()
+        return float(v[0]), int(v[3])
+
+    def _loss_scale_buffer(self, dev):
+        if self._loss_scaling is None:
+            return None
+        if self._ls is None or self._ls.device != dev:
+            self._ls = torch.tensor([self._loss_scaling[1], 0.0, float(self._loss_scaling[0]), 0.0], dtype=F32, device=dev)
+        return self._ls
+
     def update(self, lossfun=None, *args, **kwds):
         if lossfun is not None:
             loss = lossfun(*args, **kwds)
@@ -71,7 +96,11 @@ class Optimizer(object):
             if self.communicator is not None:
                 self.communicator.begin_backward(self)
             try:
-                loss.backward()
+                ls = self._loss_scale_buffer(loss.device)
+                if ls is None:
+                    loss.backward()
+                else:       # the seed is the device float itself: read when the loss head's backward kernel runs
+                    loss.backward(gradient=ls[0].reshape(loss.shape).to(loss.dtype))
             except BaseException:
                 if self.communicator is not None:
                     self.communicator.abort_backward()      # no listener / recurrence hooks left behind
@@ -99,7 +128,7 @@ class Optimizer(object):
         # launch that gave up a wait and left garbage behind) -- without a host synchronisation
         alpha, beta1, beta2 = self._control_constants()
         _ops.step_control(G, self._flat["partials"], clip, scale, alpha, beta1, beta2, self._flat["applied"], self._flat["ctl"],
-                          any_abort, 0)
+                          any_abort, 0, self._loss_scale_buffer(G.device))
         self._step(P, G, decay, self._flat["ctl"])
         bump_weight_epoch()
         refresh_compute_copies(self.target)     # every plain / transposed bf16 weight copy, one launch
@@ -200,7 +229,8 @@ class Optimizer(object):
     def _broadcast_state(self):
         """every rank takes rank 0's parameters, optimiser state and applied-step count"""
         self._needs_broadcast = False
-        for t in [self._flat["P"], self._flat["applied"]] + [b for b in self._state_buffers() if b is not None]:
+        ls = self._loss_scale_buffer(self._flat["P"].device)
+        for t in [self._flat["P"], self._flat["applied"]] + ([] if ls is None else [ls]) + [b for b in self._state_buffers() if b is not None]:
             self.communicator.broadcast(t)
         bump_weight_epoch()
 

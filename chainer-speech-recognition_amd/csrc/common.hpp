@@ -60,6 +60,41 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
+// ---- the 16-bit activation format
+// Every activation, MFMA operand and compute copy of a weight is a 16-bit value that the kernels touch only through the three
+// helpers below (packing two of them into a dword is format agnostic).  The default build stores bfloat16 -- hence the helpers'
+// names and the `bf16` in the names of the C ABI's arguments.  -DASR_ACT_F16 builds the SAME kernels with IEEE half storage and the
+// f16 MFMA (v_mfma_f32_16x16x32_f16, the bf16 form's rate): libasr_hip_f16.so, BASELINE configs[4]'s "fp16 MFMA" (the reference allows
+// float16 convolutions, asr/nn/convolution_2d.py:17-19).  Half has 11 significant bits instead of 8 and an exponent range of
+// 6e-8 .. 65504: the train step then needs loss scaling (asr/optimizers.py).  The recurrent kernels (gru.hip, sru.hip) and the feature
+// kernels manipulate bfloat16 bits directly in places and refuse to run in the half build (ASR_ERR_UNSUPPORTED): the convolutional
+// recipes -- configs[4] -- do not use them.
+#ifdef ASR_ACT_F16
+#define ASR_ACT_IS_F16 1
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {           // round to nearest even, overflow to infinity, NaN stays NaN
+    const _Float16 v = (_Float16)f;
+    uint16_t h;
+    __builtin_memcpy(&h, &v, 2);
+    return h;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    const f16x2_t r = __builtin_convertvector(v, f16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+// D = A (16 x 32) . B (32 x 16) + C on eight 16-bit operands per lane (passed as the 8 x short the kernels hold them in)
+#define ASR_MFMA_16x16x32(a, b, c)                                                                                  \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, (a)),   \
+                                           __builtin_bit_cast(__attribute__((ext_vector_type(8))) _Float16, (b)), (c), 0, 0, 0)
+#else
+#define ASR_ACT_IS_F16 0
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even f32 -> bf16 through the hardware conversion (keeps NaN a NaN)
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
@@ -75,6 +110,8 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
     return *reinterpret_cast<const uint32_t*>(&r);
 }
+#define ASR_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#endif
 
 // ONE debug table for every what-if switch of the library: ASR_DEBUG="key=value,key=value" (integers).  Kernel selections that differ
 // from the defaults exist for measurements and for the tests that pin the non-default kernels; nothing in a normal run sets them.

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const uint16_t* __restrict
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = ASR_MFMA_16x16x32(a[i].v, b[j].v, acc[i][j]);
         }
     };
     if (GLDS) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256_kernel(const uin
             Frag a;
             a.u = *reinterpret_cast<const uint4*>(Ab + aoff[i]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = ASR_MFMA_16x16x32(a.v, b[j].v, acc[i][j]);
         }
         wait_tiles_in_flight(min(S - 2, nk - 2 - kt));          // tiles kt + 2 .. may stay in flight, tile kt + 1 has landed
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, CONV ? 2 : 3) void gemm_nt256p_kernel(const ui
             for (int j = 0; j < NJ; ++j) {
                 if (j + 1 < NJ) b[(j + 1) & 1].u = *reinterpret_cast<const uint4*>(Bb + boff0 + (j + 1) * 1024);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j & 1].v, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i][j] = ASR_MFMA_16x16x32(a[i].v, b[j & 1].v, acc[i][j]);
             }
             __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);      // b0, a0..a3, b1
 #pragma unroll
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(128 * WN_) void gemm_nt_wide_kernel(const uint16_t*
                 Frag a;
                 a.u = *reinterpret_cast<const uint4*>(Ab + (aoff[i] ^ kx));
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = ASR_MFMA_16x16x32(a.v, b[j].v, acc[i][j]);
             }
         }
         wait_tiles_in_flight(min(S - 2, nk - 2 - kt));
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const uint16_t* __restr
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = ASR_MFMA_16x16x32(a[i].v, b[j].v, acc[i][j]);
         if (kt + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
     }
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_vec_kernel(const uint16_t* __r
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i].v, b[j].v, acc[i][j], 0, 0, 0);
+                acc[i][j] = ASR_MFMA_16x16x32(a[i].v, b[j].v, acc[i][j]);
     };
 
     const int nk = (kend - kbeg + TK - 1) / TK;
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn256_kernel(const uint16_t* __re
             a.h[0] = lds_tr16(reinterpret_cast<const uint16_t*>(Ab + aoff0[i]));
             a.h[1] = lds_tr16(reinterpret_cast<const uint16_t*>(Ab + aoff0[i] + A16));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b[j].v, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = ASR_MFMA_16x16x32(a.v, b[j].v, acc[i][j]);
         }
         wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -2284,6 +2284,7 @@ static int fwd_io_launch(hipStream_t st, void* gi_any, int gi_bf16, const void* 
 extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq,
                            void* hseq_bf16, void* gates_any, void* y_bf16, int T, int B, int H, int ndir, void* sync_ws,
                            int mode, const int* x_len, int gates_f16) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;      // (the recurrences handle bfloat16 bits directly: common.hpp)
     float* gates = reinterpret_cast<float*>(gates_any);
     if (!gi_any || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
     const int rc = check_dims(T, B, H, ndir);
@@ -2370,6 +2371,7 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
                            const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih,
                            float* db_hh, int T, int B, int H, int ndir, void* sync_ws, int mode, const int* x_len,
                            void* dy_ws, int gates_f16) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;      // (the recurrences handle bfloat16 bits directly: common.hpp)
     if (!dy_bf16 || !gates_any || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
     const float* gates = reinterpret_cast<const float*>(gates_any);
     if (!valid_mode(mode)) return ASR_ERR_BAD_ARG;

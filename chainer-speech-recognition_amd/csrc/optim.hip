@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
                                                            const int* __restrict__ abort0, const int* __restrict__ abort1,
                                                            float clip, float grad_scale, float alpha, float beta1, float beta2,
                                                            int* __restrict__ applied, float* __restrict__ ctl,
-                                                           const float* __restrict__ reserved) {
+                                                           const float* __restrict__ reserved, float* __restrict__ ls) {
     __shared__ float scratch[32];
     float s = 0.f;
     for (int i = threadIdx.x; i < npartials; i += blockDim.x) s += partials[i];
@@ -131,6 +131,24 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
     if (abort1 && abort1[0] != 0) gave_up = true;
     if (reserved && !isfinite(reserved[0])) gave_up = true;
     if (gave_up) drop = true;
+    // loss scaling (the IEEE-half build, configs[4]): the backward pass was seeded with ls[0], so the gradient factor carries 1 / ls[0];
+    // a non-finite norm that no recurrence explains is an overflow of a half activation gradient: the step is dropped (as above) and the
+    // scale halved; ls[2] applied steps in a row double it.  All of it here, on the device, identically on every data-parallel rank
+    // (the decision is taken on the REDUCED gradient) -- ls = {scale, applied steps since the last change, growth interval, overflows}
+    if (ls) {
+        grad_scale /= ls[0];
+        if (drop && !gave_up) {
+            ls[0] = fmaxf(ls[0] * 0.5f, 1.f);
+            ls[1] = 0.f;
+            ls[3] += 1.f;
+        } else if (!drop) {
+            ls[1] += 1.f;
+            if (ls[2] > 0.f && ls[1] >= ls[2]) {
+                ls[0] = fminf(ls[0] * 2.f, 16777216.f);
+                ls[1] = 0.f;
+            }
+        }
+    }
     float rate = grad_scale;
     if (!drop && clip > 0.f) {
         const float norm = sqrtf(sqnorm[0]) * fabsf(grad_scale);
@@ -245,17 +263,24 @@ extern "C" int asr_gather_abort(void* stream, const long long* word_ptrs, int n,
     return ASR_OK;
 }
 
-extern "C" int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
-                                float clip_threshold, float grad_scale, float alpha, float beta1, float beta2,
-                                int* applied_steps, float* ctl, int reserved_index) {
+extern "C" int asr_step_control_scaled(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
+                                       float clip_threshold, float grad_scale, float alpha, float beta1, float beta2,
+                                       int* applied_steps, float* ctl, int reserved_index, float* loss_scale) {
     if (!g || n <= 0 || !partials || !applied_steps || !ctl || reserved_index >= n) return ASR_ERR_BAD_ARG;
     const int blocks = grid_for(n);
     hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, partials);
     hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, blocks, abort0,
                        abort1, clip_threshold, grad_scale, alpha, beta1, beta2, applied_steps, ctl,
-                       reserved_index >= 0 ? g + reserved_index : (const float*)nullptr);
+                       reserved_index >= 0 ? g + reserved_index : (const float*)nullptr, loss_scale);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
+}
+
+extern "C" int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
+                                float clip_threshold, float grad_scale, float alpha, float beta1, float beta2,
+                                int* applied_steps, float* ctl, int reserved_index) {
+    return asr_step_control_scaled(stream, g, n, partials, abort0, abort1, clip_threshold, grad_scale, alpha, beta1, beta2,
+                                   applied_steps, ctl, reserved_index, nullptr);
 }
 
 extern "C" int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2,

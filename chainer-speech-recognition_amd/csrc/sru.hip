@@ -344,6 +344,7 @@ static bool aligned8(const void* p) { return (((uintptr_t)p) & 7) == 0; }
 extern "C" int asr_sru_fwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* c0,
                            const float* mask, void* H_bf16, float* C, float* cT, int T, int B, int D, int use_tanh, void* ws,
                            size_t ws_bytes) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;      // (bfloat16 bits handled directly: common.hpp)
     if (!x_bf16 || !U || !bias || !H_bf16 || !C || !cT || T <= 0 || B <= 0 || D <= 0) return ASR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int nc = sru_chunks(T, B, D);
@@ -370,6 +371,7 @@ extern "C" int asr_sru_fwd(void* stream, const void* x_bf16, const float* U, con
 extern "C" int asr_sru_bwd(void* stream, const void* x_bf16, const float* U, const float* bias, const float* C,
                            const float* c0, const float* mask, const void* gH_bf16, const float* gcT, void* gU_bf16,
                            void* gxh_bf16, float* gbias, float* gc0, int T, int B, int D, int use_tanh, void* ws, size_t ws_bytes) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;      // (bfloat16 bits handled directly: common.hpp)
     if (!x_bf16 || !U || !bias || !C || !gU_bf16 || !gxh_bf16 || !gbias || !gc0 || T <= 0 || B <= 0 || D <= 0)
         return ASR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -400,6 +402,7 @@ extern "C" int asr_sru_bwd(void* stream, const void* x_bf16, const float* U, con
 
 extern "C" int asr_sru_combine(void* stream, const void* a_bf16, const void* b_bf16, const float* mask, void* out_bf16,
                                long long n, int BD) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;      // (bfloat16 bits handled directly: common.hpp)
     if (!a_bf16 || !out_bf16 || n <= 0 || BD <= 0) return ASR_ERR_BAD_ARG;
     long long g = (n + 255) / 256;
     if (g > 4096) g = 4096;

@@ -1,6 +1,7 @@
 #include "common.hpp"
 #include "../../include/asr_hip.h"
 extern "C" int asr_version(void) { return 1; }
+extern "C" int asr_act_dtype(void) { return ASR_ACT_IS_F16; }
 
 // One wave that does nothing for `microseconds` (wall clock, 100 MHz): a timed gap on a stream (experiments).  Bounded (<= 100 ms).
 __global__ void stream_delay_kernel(unsigned long long ticks) {

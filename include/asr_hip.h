@@ -18,6 +18,12 @@ extern "C" {
 #endif
 
 int asr_version(void);
+/* the 16-bit format of every activation, MFMA operand and weight compute copy of THIS build: 0 = bfloat16 (libasr_hip.so, the default),
+ * 1 = IEEE half (libasr_hip_f16.so: the same kernels built with -DASR_ACT_F16 for BASELINE configs[4]'s "fp16 MFMA"; the reference
+ * allows float16 convolutions, asr/nn/convolution_2d.py:17-19).  Wherever this header says `bf16` it means that format.  The half build
+ * refuses the recurrent entry points (asr_gru_*, asr_sru_*: ASR_ERR_UNSUPPORTED); a train step in half needs loss scaling on the caller's
+ * side (the gradient factor of asr_step_control). */
+int asr_act_dtype(void);
 /* a one-wave kernel that idles for `microseconds` (<= 100000) on `stream`: a timed gap (experiments) */
 int asr_stream_delay(void* stream, int microseconds);
 /* diagnostic: `blocks` workgroups holding `lds_bytes` of LDS each idle for `microseconds` (<= 200000) on `stream` -- makes CUs
@@ -383,6 +389,16 @@ int asr_gather_abort(void* stream, const long long* word_ptrs, int n, int* any_w
 int asr_step_control(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
                      float clip_threshold, float grad_scale, float alpha, float beta1, float beta2, int* applied_steps,
                      float* ctl, int reserved_index);
+/* asr_step_control with loss scaling (chainer.Optimizer.loss_scaling(interval, scale); the IEEE-half build of BASELINE configs[4]):
+ * loss_scale = device float[4] {scale S, applied steps since S last changed, growth interval (0 = S is static), overflows so far}.
+ * The caller seeds the backward pass with S (the gradient handed to asr_ctc_backward's gy is the device float loss_scale[0] itself,
+ * read when that kernel runs); this call divides the gradient factor by S, and when the norm is not finite without a recurrence
+ * having given up -- an activation gradient overflowed the half range -- drops the step and halves S (never below 1); `interval`
+ * applied steps in a row double it (never above 2^24).  No host synchronisation; identical on every data-parallel rank.
+ * loss_scale == NULL: asr_step_control. */
+int asr_step_control_scaled(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
+                            float clip_threshold, float grad_scale, float alpha, float beta1, float beta2, int* applied_steps,
+                            float* ctl, int reserved_index, float* loss_scale);
 int asr_adam_ctl(void* stream, float* p, const float* g, float* m, float* v, long long n, float beta1, float beta2, float eps,
                  float weight_decay, const float* ctl);
 int asr_sgd_ctl(void* stream, float* p, const float* g, float* v, long long n, int kind, float lr, float momentum,

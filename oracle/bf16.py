@@ -19,13 +19,21 @@ torch's float32 ctc_loss here): ~1e-5, two orders below one bf16 ulp (3.9e-3 rel
 Reference arithmetic: asr/nn/nn.py (layers), asr/nn/layernorm.py:33-61, run/ctc/cnn/model.py:11-332, chainer's GRU / conv /
 CTC as restated in oracle/nn.py and oracle/model.py (unpinned boundary, see oracle/__init__.py).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 
+# the 16-bit format the device rounds to: bfloat16 (the default library) or IEEE half when the half build is under test (ASR_ACT=f16,
+# csrc/common.hpp) -- the same environment variable that selects the library
+ACT = torch.float16 if os.environ.get("ASR_ACT", "").lower() in ("f16", "fp16", "float16", "half") else torch.bfloat16
+
+
 def rnd(x):
-    """float32 -> nearest-even bfloat16 -> float32 (what v_cvt_pk_bf16_f32 / (__bf16)f does on the device)"""
-    return x.to(torch.bfloat16).to(torch.float32)
+    """float32 -> nearest-even 16-bit activation format -> float32 (what v_cvt_pk_bf16_f32 / (__bf16)f, or v_cvt_f16_f32 in the half
+    build, does on the device)"""
+    return x.to(ACT).to(torch.float32)
 
 
 class _RoundFB(torch.autograd.Function):

@@ -71,6 +71,19 @@ def test_every_declared_symbol_is_exported():
     assert handle.asr_version() >= 1
 
 
+def test_the_half_build_exports_the_same_symbols():
+    """libasr_hip_f16.so (ASR_ACT=f16: BASELINE configs[4]) is the same ABI; it says which 16-bit format it was compiled for"""
+    import ctypes
+    path = os.path.join(PKG, "libasr_hip_f16.so")
+    assert os.path.isfile(path), "run `make -C chainer-speech-recognition_amd`"
+    half = ctypes.CDLL(path)
+    for name in _header_functions():
+        assert hasattr(half, name), name
+    from asr import _lib
+    assert half.asr_act_dtype() == 1 and half.asr_version() == _lib.lib().asr_version()
+    assert _lib.lib().asr_act_dtype() == (1 if os.environ.get("ASR_ACT") else 0)
+
+
 def test_workspace_query_runs_on_host():
     from asr import _lib
     n = _lib.lib().asr_ctc_workspace_bytes(1000, 32, 3000, 120, 0)

@@ -16,12 +16,14 @@ import numpy as np
 import pytest
 import torch
 
+from asr._lib import act_dtype as _act_dtype      # bfloat16, or float16 when the half build is under test (ASR_ACT=f16)
+
 from oracle import bf16 as Q
 from oracle import model as omodel
 from oracle import nn as onn
 
 pytestmark = pytest.mark.gpu
-BF16 = torch.bfloat16
+BF16 = _act_dtype()
 
 # per-unit bars (relative L2), ~2 x what is measured on the device (printed by the test, run with -s).  Measured, B = 20 / 17, T = 150 / 120:
 #   convolutions, dense projections: forward 2.6e-5, input gradient 3.2e-5, parameter gradients 1e-6 (float32 summation order)

@@ -6,11 +6,13 @@ import numpy as np
 import pytest
 import torch
 
+from asr._lib import act_dtype as _act_dtype      # bfloat16, or float16 when the half build is under test (ASR_ACT=f16)
+
 from oracle import bf16 as Q
 from oracle import model as omodel
 
 pytestmark = pytest.mark.gpu
-BF16 = torch.bfloat16
+BF16 = _act_dtype()
 
 
 def _rel(a, b):

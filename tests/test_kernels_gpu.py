@@ -3,11 +3,13 @@ import numpy as np
 import pytest
 import torch
 
+from asr._lib import act_dtype as _act_dtype      # bfloat16, or float16 when the half build is under test (ASR_ACT=f16)
+
 from oracle import nn as onn
 
 pytestmark = pytest.mark.gpu
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32 = _act_dtype(), torch.float32
 
 
 def _bf(t):
@@ -337,12 +339,12 @@ def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
     g = torch.Generator().manual_seed(T * 100 + H)
     x = torch.randn(T, B, H, 2 * C, generator=g)
     x = (x * 2).round() / 2                     # many exact ties inside pairs and windows
-    xd = x.to(device).to(torch.bfloat16)
+    xd = x.to(device).to(BF16)
     assert _ops.maxout2_pool_ok(xd)
     y_ref = _ops.maxpool_h_fwd(_ops.maxout2_fwd(xd), k)
     y = _ops.maxout2_pool_fwd(xd, k)
     assert y.shape == y_ref.shape and torch.equal(y, y_ref)
-    gy = torch.randn(y.shape, generator=g).to(device).to(torch.bfloat16)
+    gy = torch.randn(y.shape, generator=g).to(device).to(BF16)
     mid = _ops.maxout2_fwd(xd)
     dx_ref = _ops.maxout2_bwd(xd, _ops.maxpool_h_bwd(mid, gy, k))
     dx = _ops.maxout2_pool_bwd(xd, gy, k)
@@ -364,7 +366,7 @@ def test_layer_stack_fuses_maxout_and_pooling(device):
     from asr import nn, functions as F
     from asr.nn.nn import _fusable_pool
     torch.manual_seed(2)
-    x = torch.randn(2, 32, 13, 9).to(device).to(torch.bfloat16)      # logical (B, 2C, H, T)
+    x = torch.randn(2, 32, 13, 9).to(device).to(BF16)      # logical (B, 2C, H, T)
     layers = [nn.Maxout(2), nn.Dropout(0), nn.MaxPooling2D(ksize=(3, 1))]
     assert _fusable_pool(layers, 0) == 2
     xa = x.clone().requires_grad_(True)
@@ -616,7 +618,7 @@ def test_gru_abort_word_is_sticky_and_reported(device):
     T, B, H, ndir = 6, 4, 64, 2
     g = torch.Generator().manual_seed(0)
     gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device)
-    whh = (torch.randn(ndir, 3 * H, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    whh = (torch.randn(ndir, 3 * H, H, generator=g) * 0.1).to(device).to(BF16)
     bhh = torch.zeros(ndir * 3 * H, device=device)
     _ops.gru_fwd(gi, whh, bhh, T, B, H, ndir)
     torch.cuda.synchronize()
@@ -646,10 +648,10 @@ def test_gru_full_size_forms_agree(device):
     g = torch.Generator().manual_seed(1)
     gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device)
     whh = (torch.randn(ndir, 3 * H, H, generator=g) / H ** 0.5).to(device)
-    whh16 = whh.to(torch.bfloat16).contiguous()
-    whhT16 = whh.transpose(1, 2).contiguous().to(torch.bfloat16)
+    whh16 = whh.to(BF16).contiguous()
+    whhT16 = whh.transpose(1, 2).contiguous().to(BF16)
     bhh = (torch.randn(ndir * 3 * H, generator=g) * 0.1).to(device)
-    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(BF16)
     res = {}
     try:
         for mode in (1, 2, 0, 4, 7, 10):
@@ -725,7 +727,7 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     pt = KW - 1
     Tout = T if causal else T + 2 * pt - KW + 1
     Hout = Hin + 2 * ph - KH + 1
-    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(torch.bfloat16)
+    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(BF16)
     W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.1).astype(np.float32)).to(device)
     bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
     w16 = _ops.conv_weight_pack(W)
@@ -734,13 +736,13 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     w16c = w16 if (KH * KW * Ci) % 32 == 0 else _ops.conv_weight_pack(W, Kp=(KH * KW * Ci + 31) // 32 * 32)      # K step of the kernels
     got = _ops.conv_nt(x, w16c, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
     assert _rel(got.cpu(), ref.cpu()) < 1e-5
-    got16 = _ops.conv_nt(x, w16c, bias, torch.bfloat16, KH, KW, ph, pt, +1, Tout, Hout)
+    got16 = _ops.conv_nt(x, w16c, bias, BF16, KH, KW, ph, pt, +1, Tout, Hout)
     assert _rel(got16.float().cpu(), ref.cpu()) < 1e-2
     # backward-data: dx = col2im(gy . W)
-    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(torch.bfloat16)
+    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(BF16)
     w16t = _ops.conv_weight_pack(W, transpose=True)
     dcol = _ops.gemm_nt(gy.reshape(-1, Co), w16t, None, torch.float32)
-    ref_dx = _ops.col2im(dcol.to(torch.bfloat16), T, B, Hin, Ci, KH, KW, ph, pt, Tout).float()
+    ref_dx = _ops.col2im(dcol.to(BF16), T, B, Hin, Ci, KH, KW, ph, pt, Tout).float()
     wb = _ops.conv_weight_pack_bwd(W)
     got_dx = _ops.conv_nt(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin).reshape(T, B, Hin, Ci)
     assert _rel(got_dx.cpu(), ref_dx.cpu()) < 2e-2      # the reference path rounds dcol to bf16 before the gather
@@ -781,12 +783,12 @@ def test_first_layer_weight_gradient_with_padded_channels(device):
     rs = np.random.RandomState(4)
     T, B, Hin, Ci, Co, KH, KW, ph = 21, 2, 9, 3, 32, 3, 5, 1
     pt, Tout, Hout = KW - 1, T, Hin + 2 * ph - KH + 1
-    x = torch.from_numpy(rs.randn(B, Ci, Hin, T).astype(np.float32)).to(torch.bfloat16).float()
-    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(torch.bfloat16).float()
+    x = torch.from_numpy(rs.randn(B, Ci, Hin, T).astype(np.float32)).to(BF16).float()
+    gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(BF16).float()
     xd = x.to(device)
     xpad = _ops.pack_input_pad(xd, (xd.stride(3), xd.stride(0), xd.stride(2), xd.stride(1)), T, B, Hin, Ci, 8)
     scratch = torch.zeros(Co, KH * KW * 8, device=device)
-    _ops.conv_tn_acc(gy.to(device).to(torch.bfloat16).reshape(-1, Co), xpad, scratch, KH, KW, ph, pt, Tout, Hout)
+    _ops.conv_tn_acc(gy.to(device).to(BF16).reshape(-1, Co), xpad, scratch, KH, KW, ph, pt, Tout, Hout)
     gW = torch.zeros(Co, Ci, KH, KW, device=device)
     _ops.conv_weight_grad_unpack(scratch, gW, 8)
     xp = torch.nn.functional.pad(x.double(), (pt, 0, ph, ph))                      # (B, Ci, Hin + 2 ph, T + pt)
@@ -799,7 +801,7 @@ def test_first_layer_weight_gradient_with_padded_channels(device):
     # one scratch copy per XCD (a single output tile under hundreds of K splits): the same gradient after the unpack's sum
     assert _ops.conv_tn_copies(Co, 8, KH, KW) == 8 and _ops.conv_tn_copies(512, 256, KH, KW) == 1
     scratch8 = torch.zeros(8, Co, KH * KW * 8, device=device)
-    _ops.conv_tn_acc(gy.to(device).to(torch.bfloat16).reshape(-1, Co), xpad, scratch8, KH, KW, ph, pt, Tout, Hout)
+    _ops.conv_tn_acc(gy.to(device).to(BF16).reshape(-1, Co), xpad, scratch8, KH, KW, ph, pt, Tout, Hout)
     gW8 = torch.ones(Co, Ci, KH, KW, device=device)
     _ops.conv_weight_grad_unpack(scratch8, gW8, 8)
     assert _rel((gW8 - 1.0).cpu().double(), ref) < 1e-5
@@ -814,9 +816,9 @@ def test_persistent_recurrence_waits_out_busy_cus(device):
     g = torch.Generator().manual_seed(3)
     gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device)
     whh = (torch.randn(ndir, 3 * H, H, generator=g) / H ** 0.5).to(device)
-    whh16, whhT16 = whh.to(torch.bfloat16).contiguous(), whh.transpose(1, 2).contiguous().to(torch.bfloat16)
+    whh16, whhT16 = whh.to(BF16).contiguous(), whh.transpose(1, 2).contiguous().to(BF16)
     bhh = (torch.randn(ndir * 3 * H, generator=g) * 0.1).to(device)
-    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(BF16)
 
     def run(hog):
         side = torch.cuda.Stream()
@@ -851,9 +853,9 @@ def test_persistent_recurrence_beside_a_resident_collective_stand_in(device):
     g = torch.Generator().manual_seed(5)
     gi = torch.randn(T * B, ndir * 3 * H, generator=g).to(device).to(_ops.gru_gi_dtype(T, B, H, ndir))
     whh = (torch.randn(ndir, 3 * H, H, generator=g) / H ** 0.5).to(device)
-    whh16, whhT16 = whh.to(torch.bfloat16).contiguous(), whh.transpose(1, 2).contiguous().to(torch.bfloat16)
+    whh16, whhT16 = whh.to(BF16).contiguous(), whh.transpose(1, 2).contiguous().to(BF16)
     bhh = (torch.randn(ndir * 3 * H, generator=g) * 0.1).to(device)
-    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(torch.bfloat16)
+    dy = (torch.randn(T * B, H, generator=g) * 0.1).to(device).to(BF16)
     scratch = torch.zeros(16 * 1024 * 1024, device=device)
     side = torch.cuda.Stream()
 

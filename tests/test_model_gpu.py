@@ -6,9 +6,22 @@ import numpy as np
 import pytest
 import torch
 
+from asr._lib import act_dtype as _act_dtype      # bfloat16, or float16 when the half build is under test (ASR_ACT=f16)
+
 from oracle import model as omodel
 
 pytestmark = pytest.mark.gpu
+BF16 = _act_dtype()
+# the IEEE-half build (ASR_ACT=f16, tests/test_f16_gpu.py) is only usable with a scaled backward seed (Optimizer.loss_scaling): the recipe
+# tests seed both sides' backward passes with it
+LOSS_SCALE = 1024.0 if BF16 is torch.float16 else 1.0
+
+
+def _seeded_backward(loss):
+    if LOSS_SCALE == 1.0:
+        loss.backward()
+    else:
+        loss.backward(gradient=torch.full_like(loss, LOSS_SCALE))
 
 
 def _cos(a, b):
@@ -71,7 +84,7 @@ def test_forward_backward_matches_oracle(device, B, T, bidir, V, H):
     assert fused == (V % 4 == 0)
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     logits = torch.stack(ys).detach().cpu()
-    gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2 if bidir else 1) == torch.bfloat16
+    gi_bf16 = _ops.gru_gi_dtype(T, B, H, 2 if bidir else 1) == BF16
     report = {}
     for matched in (True, False):
         ref = omodel.DS2Oracle(state, cfg.num_conv_layers, cfg.num_rnn_layers, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=fused,
@@ -189,12 +202,15 @@ def test_cnn_recipes_train_step(device, arch):
     opt.setup(model)
     opt.add_hook(GradientClipping(1.0))
     opt.add_hook(WeightDecay(1e-5))
+    if LOSS_SCALE != 1.0:
+        opt.loss_scaling()          # dynamic, chainer.Optimizer.loss_scaling
     losses = []
     for _ in range(4):
         loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
         opt.update(lossfun=lambda: loss)
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert opt.applied_steps() == 4 and opt.loss_scale()[1] == 0
 
 
 def test_weight_copies_refreshed_in_one_launch(device):
@@ -230,7 +246,7 @@ def test_weight_copies_refreshed_in_one_launch(device):
             w = param.detach()
             for so, do, r, c, t in jobs:
                 src = w.reshape(-1)[so:so + r * c].reshape(r, c)
-                want = (src.t() if t else src).contiguous().to(torch.bfloat16)
+                want = (src.t() if t else src).contiguous().to(BF16)
                 got = out.reshape(-1)[do:do + r * c].reshape(want.shape)
                 assert torch.equal(got, want), (key, r, c, t)
                 seen += 1
@@ -243,7 +259,7 @@ def test_cast_many_ragged_shapes(device):
     torch.manual_seed(3)
     shapes = [(1, 1, 0), (5, 7, 1), (64, 64, 1), (65, 130, 0), (130, 65, 1), (3, 257, 1), (200, 4, 1), (96, 1536, 0), (7, 12, 1)]
     srcs = [torch.randn(r, c, device=device) for r, c, _ in shapes]
-    dsts = [torch.full((c, r) if t else (r, c), 7.0, dtype=torch.bfloat16, device=device) for r, c, t in shapes]
+    dsts = [torch.full((c, r) if t else (r, c), 7.0, dtype=BF16, device=device) for r, c, t in shapes]
     rows, tile = [], 0
     for (r, c, t), s, d in zip(shapes, srcs, dsts):
         rows.append([s.data_ptr(), d.data_ptr(), r, c, t, tile])
@@ -252,7 +268,7 @@ def test_cast_many_ragged_shapes(device):
     _lib.check(_lib.lib().asr_cast_bf16_many(_lib.stream(), _lib.ptr(table), len(rows), tile), "asr_cast_bf16_many")
     torch.cuda.synchronize()
     for (r, c, t), s, d in zip(shapes, srcs, dsts):
-        want = (s.t() if t else s).contiguous().to(torch.bfloat16)
+        want = (s.t() if t else s).contiguous().to(BF16)
         assert torch.equal(d, want), (r, c, t)
 
 
@@ -421,7 +437,7 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         model(xd)                                   # lazily sized parameters; data-dependent weight-norm initialisation
     ys = model(xd)
     loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
-    loss.backward()
+    _seeded_backward(loss)
     from asr.functions import join_side_stream
     join_side_stream()
     torch.cuda.synchronize()
@@ -450,7 +466,7 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         assert out.shape == (B, V, 1, T)
         logits_ref = ocnn.logits_tbv(out)
         loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
-        loss_ref.backward()
+        (loss_ref * LOSS_SCALE).backward()       # both sides' gradients carry the seed: the relative errors do not
         errs = {}
         for name, p in model.named_parameters():
             g_ref = params[name].grad
@@ -574,7 +590,7 @@ def test_configs0_literal_shape(device, bidir):
     torch.cuda.synchronize()
     _ops.gru_check_sync()
     state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    gi_bf16 = _ops.gru_gi_dtype(T, B, 512, 2 if bidir else 1) == torch.bfloat16
+    gi_bf16 = _ops.gru_gi_dtype(T, B, 512, 2 if bidir else 1) == BF16
     for matched in (True, False):
         ref = omodel.DS2Oracle(state, cfg.num_conv_layers, 1, bidir, matched=matched, gi_bf16=gi_bf16, fused_logit_bias=False,
                                gates_f16=_ops.gru_gates_f16(T, B, 512, 2 if bidir else 1))
@@ -659,7 +675,7 @@ def test_cnn_recipes_layer_by_layer_against_the_matched_oracle(device, arch, nco
         model(xd)
     ys, rec = _trace_layers(model, xd)
     loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
-    loss.backward()
+    _seeded_backward(loss)         # teacher-forced below: the oracle's layers are handed the device's (scaled) gradients
     F.join_side_stream()
     torch.cuda.synchronize()
     prog = ocnn.program(arch, cfg)
@@ -683,7 +699,7 @@ def test_cnn_recipes_layer_by_layer_against_the_matched_oracle(device, arch, nco
         params = {pn: v.detach().cpu().clone().requires_grad_(True) for pn, v in model.named_parameters() if pn.rsplit(".", 1)[0] in names}
         xin = e["xin"].float().cpu()
         if k == 0:
-            xin = xin.to(torch.bfloat16).float()           # the first layer packs the loader's float32 minibatch to bf16
+            xin = xin.to(BF16).float()           # the first layer packs the loader's float32 minibatch to bf16
         xin.requires_grad_(k > 0)
         y = ocnn.run(prog, lo, hi, params, xin, matched=True, fused_logit_bias=False, weights=weights)
         got = e["xout"].float().cpu()
@@ -704,7 +720,7 @@ def test_cnn_recipes_layer_by_layer_against_the_matched_oracle(device, arch, nco
         col2im = [n for (op, n, _) in prog[lo:hi] if op in ("conv", "glu") and tuple(own(n).shape[2:]) == (3, 5) and (own(n).shape[0] * 15) % 32 != 0]
         if k > 0 and rec[k - 1]["gout"] is not None and float(rec[k - 1]["gout"].float().abs().max()) > 0.0:
             # (the device's tensor is bf16: where two branches meet -- a Residual's skip and its convolution -- the sum is rounded once more)
-            err = _rel(rec[k - 1]["gout"].float().cpu(), xin.grad.to(torch.bfloat16).float())
+            err = _rel(rec[k - 1]["gout"].float().cpu(), xin.grad.to(BF16).float())
             note("gx", err, tag)
             assert err < (LAYER_GX_COL2IM if col2im else LAYER_REL_L2), ("input gradient", tag, err)
         for pn, v in params.items():

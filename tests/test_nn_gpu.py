@@ -5,11 +5,13 @@ import numpy as np
 import pytest
 import torch
 
+from asr._lib import act_dtype as _act_dtype      # bfloat16, or float16 when the half build is under test (ASR_ACT=f16)
+
 from oracle import fft as offt
 from oracle import nn as onn
 
 pytestmark = pytest.mark.gpu
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32 = _act_dtype(), torch.float32
 
 
 def _bf(t):
@@ -247,7 +249,7 @@ def test_batch_normalization(device):
     rs = np.random.RandomState(3)
     B, C, H, T = 3, 24, 5, 17
     x = (rs.randn(B, C, H, T) * 1.5 + 0.7).astype(np.float32)
-    x = torch.from_numpy(x).to(torch.bfloat16).float()          # representable values
+    x = torch.from_numpy(x).to(BF16).float()          # representable values
     bn = nn.BatchNormalization(C)
     with torch.no_grad():
         bn.gamma.copy_(torch.from_numpy(rs.rand(C).astype(np.float32) + 0.5))
@@ -261,7 +263,7 @@ def test_batch_normalization(device):
     np.testing.assert_allclose(bn.avg_mean.cpu().numpy(), am, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(bn.avg_var.cpu().numpy(), av, rtol=1e-3, atol=1e-5)
     # gradients against torch autograd on the CPU
-    gy = torch.from_numpy(rs.randn(B, C, H, T).astype(np.float32)).to(torch.bfloat16).float()
+    gy = torch.from_numpy(rs.randn(B, C, H, T).astype(np.float32)).to(BF16).float()
     y.backward(gy.to(device).to(y.dtype))
     xr = x.clone().requires_grad_(True)
     gr, br = torch.tensor(g0, dtype=torch.float32, requires_grad=True), torch.tensor(b0, dtype=torch.float32, requires_grad=True)
@@ -282,7 +284,7 @@ def test_batch_normalization(device):
     np.testing.assert_allclose(yt.float().cpu().numpy(), want_t, rtol=2e-2, atol=2e-2)
     # 3-d input (B, C, T)
     bn3 = nn.BatchNormalization(8).to_gpu(0)
-    x3 = torch.from_numpy(rs.randn(4, 8, 11).astype(np.float32)).to(torch.bfloat16).float()
+    x3 = torch.from_numpy(rs.randn(4, 8, 11).astype(np.float32)).to(BF16).float()
     y3 = bn3(x3.to(device))
     w3, _, _ = onn.batch_normalization(x3.numpy().astype(np.float64), np.ones(8), np.zeros(8), np.zeros(8), np.ones(8))
     np.testing.assert_allclose(y3.float().detach().cpu().numpy(), w3, rtol=2e-2, atol=2e-2)
