@@ -393,8 +393,8 @@ int asr_step_control(void* stream, const float* g, long long n, float* partials,
  * loss_scale = device float[4] {scale S, applied steps since S last changed, growth interval (0 = S is static), overflows so far}.
  * The caller seeds the backward pass with S (the gradient handed to asr_ctc_backward's gy is the device float loss_scale[0] itself,
  * read when that kernel runs); this call divides the gradient factor by S, and when the norm is not finite without a recurrence
- * having given up -- an activation gradient overflowed the half range -- drops the step and halves S (never below 1); `interval`
- * applied steps in a row double it (never above 2^24).  No host synchronisation; identical on every data-parallel rank.
+ * having given up -- an activation gradient overflowed the half range -- drops the step and halves S (down to 2^-24: a model whose
+ * unscaled activation gradients leave the half range needs S < 1); `interval` applied steps in a row double it (up to 2^24).  No host synchronisation; identical on every data-parallel rank.
  * loss_scale == NULL: asr_step_control. */
 int asr_step_control_scaled(void* stream, const float* g, long long n, float* partials, const int* abort0, const int* abort1,
                             float clip_threshold, float grad_scale, float alpha, float beta1, float beta2, int* applied_steps,

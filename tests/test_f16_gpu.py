@@ -67,9 +67,11 @@ def test_half_build_only_library_and_refusals(device):
 
 @pytest.mark.skipif(not HALF, reason="runs in the child process of the test above (ASR_ACT=f16)")
 def test_half_build_only_loss_scaling_keeps_the_small_gradients(device):
-    """Gradients of the first layers of a recipe are ~1e-6 .. 1e-4 per element under a mean CTC loss: below the half format's normal
-    range (6.1e-5) they lose bits or vanish.  With the backward pass seeded by S the parameter gradients, divided by S again, agree with
-    the float32 oracle as well as the bfloat16 build's do; without the seed they do not -- the reason the scale exists."""
+    """Activation gradients below the half format's normal range (6.1e-5) lose bits, below 6e-8 they vanish.  The full-size step's are
+    ~1e-6 .. 1e-4 per element (mean CTC loss over 32 utterances x 1000 frames); this toy recipe's are ~0.05, so the test seeds its backward
+    pass with 2^-16 to put them where the full-size ones are, and with 2^-16 x 1024 for the scaled run: divided by the seed again, the
+    parameter gradients of the scaled run agree with the float32 oracle as well as half's 11 bits allow, the unscaled run's do not --
+    the reason Optimizer.loss_scaling exists."""
     from asr.loss import connectionist_temporal_classification
     from asr.functions import join_side_stream
     from oracle import cnn as ocnn
@@ -91,9 +93,9 @@ def test_half_build_only_loss_scaling_keeps_the_small_gradients(device):
             errs[n] = float((a - b).norm() / (b.norm() + 1e-30))
         return max(errs.values()), max(errs, key=errs.get)
 
-    scaled, unscaled = worst(1024.0), worst(1.0)
-    print("half build, worst parameter gradient against the float32 oracle: seed 1024 %.2e (%s), seed 1 %.2e (%s)" % (scaled + unscaled))
-    assert scaled[0] < 2e-2, scaled                 # half carries 3 more mantissa bits than bfloat16 (0.25 bar in test_model_gpu)
+    scaled, unscaled = worst(2.0 ** -6), worst(2.0 ** -16)
+    print("half build, worst parameter gradient against the float32 oracle: small gradients x 1024 %.2e (%s), as they are %.2e (%s)" % (scaled + unscaled))
+    assert scaled[0] < 0.15, scaled                 # (0.25: the bfloat16 build's bar against the float32 oracle in test_model_gpu)
     assert unscaled[0] > 2 * scaled[0], (scaled, unscaled)
 
 
@@ -125,7 +127,7 @@ def test_half_build_only_dynamic_loss_scale_backs_off_and_grows(device):
     s, overflows = opt.loss_scale()
     assert drops >= 1 and overflows >= drops and opt.applied_steps() >= 7
     assert opt.t == opt.applied_steps() + overflows                 # every attempted step is either applied or counted as an overflow
-    assert 1.0 <= s < 2.0 ** 24 and np.log2(s) == int(np.log2(s))
+    assert 0.0 < s < 2.0 ** 24 and np.log2(s) == int(np.log2(s))
     print("dynamic loss scale: %d overflow(s) from 2^24, settled at 2^%d after %d applied steps" % (overflows, int(np.log2(s)), opt.applied_steps()))
 
     # the applied update does not depend on S (up to the roundings S moves): a static 256 and a static 4096 give the same parameters

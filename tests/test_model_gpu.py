@@ -17,11 +17,12 @@ BF16 = _act_dtype()
 LOSS_SCALE = 1024.0 if BF16 is torch.float16 else 1.0
 
 
-def _seeded_backward(loss):
-    if LOSS_SCALE == 1.0:
+def _seeded_backward(loss, scale=None):
+    scale = LOSS_SCALE if scale is None else scale
+    if scale == 1.0:
         loss.backward()
     else:
-        loss.backward(gradient=torch.full_like(loss, LOSS_SCALE))
+        loss.backward(gradient=torch.full_like(loss, scale))
 
 
 def _cos(a, b):
@@ -55,6 +56,13 @@ MATCHED_LOSS_REL = 1e-3
 # 2 x what is measured.  The layer-by-layer tests below are the tight ones (5e-4 for every layer of every recipe, no accumulation).
 END_TO_END_BARS = {(False, False): (2e-3, MATCHED_GRAD_REL_L2, 0.0), (False, True): (2e-3, MATCHED_GRAD_REL_L2, 3 * MATCHED_GRAD_REL_L2),
                    (True, False): (5e-3, MATCHED_GRAD_WIDE8, 0.0), (True, True): (3.5e-2, 0.3, 0.35)}
+# The half build (ASR_ACT=f16; BARS measured there as well): logits agree BETTER (2e-4), but half's 8 x finer grid leaves 10 - 60 % of the
+# activations one ulp apart between the two implementations (bfloat16: 2 - 40 %), and among near-ties of a Maxout / max-pooling pair that
+# flips an arg-max now and then -- one gradient element routed to the other channel is 3e-3 .. 3e-2 of a small layer's gradient norm
+# (tools/debug_f16_chain.py shows the error entering AT a maxout backward: 1.1e-4 above it, 2.3e-3 below).  zhang+residual/4 measures
+# 6.9e-3 where the recipes without such an event measure 6e-4; the teacher-forced layer-by-layer test holds 5e-4 for every layer.
+if BF16 is torch.float16:
+    END_TO_END_BARS[(False, False)] = (2e-3, 1.5e-2, 0.0)
 # (True, True): the 8-convolution wide branch WITH weight normalisation and its data-dependent initialisation is ill-conditioned end to
 # end at random initialisation -- the rounding-matched oracle (logits 1.7e-2, gradients 0.15 - 0.17) tracks the device no better than
 # the plain float32 oracle does (3e-2 / 0.34) once it forms its own W (which agrees with the device's to 5e-7, checked above): a
@@ -205,12 +213,16 @@ def test_cnn_recipes_train_step(device, arch):
     if LOSS_SCALE != 1.0:
         opt.loss_scaling()          # dynamic, chainer.Optimizer.loss_scaling
     losses = []
-    for _ in range(4):
+    # half build: a recipe whose gradients times the initial scale of 4096 leave the half range drops those steps, halving the scale each
+    # time, until the backward pass fits (the un-normalised `glu` recipe at this toy size needs S < 1: its activation gradients reach 4e4)
+    for _ in range(4 if LOSS_SCALE == 1.0 else 28):
         loss = connectionist_temporal_classification(model(xd), ld, 0, xl, ll)
         opt.update(lossfun=lambda: loss)
         losses.append(loss.item())
+        if opt.applied_steps() == 4:
+            break
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
-    assert opt.applied_steps() == 4 and opt.loss_scale()[1] == 0
+    assert opt.applied_steps() == 4 and opt.applied_steps() + opt.loss_scale()[1] == len(losses)
 
 
 def test_weight_copies_refreshed_in_one_launch(device):
@@ -437,7 +449,10 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         model(xd)                                   # lazily sized parameters; data-dependent weight-norm initialisation
     ys = model(xd)
     loss = connectionist_temporal_classification(ys, labels.to(device), 0, x_len.to(device), l_len.to(device))
-    _seeded_backward(loss)
+    # half build: the un-normalised `glu` recipe at this toy size has activation gradients of 4e4 -- beyond the half range WITHOUT any
+    # scale (the dynamic loss scale settles below 1 for it: test_cnn_recipes_train_step); its seed is 2^-6
+    seed = LOSS_SCALE if not (LOSS_SCALE != 1.0 and arch == "glu" and not wn) else 2.0 ** -6
+    _seeded_backward(loss, seed)
     from asr.functions import join_side_stream
     join_side_stream()
     torch.cuda.synchronize()
@@ -466,7 +481,7 @@ def test_cnn_recipes_match_the_oracle_end_to_end(device, arch, nconv, wn):
         assert out.shape == (B, V, 1, T)
         logits_ref = ocnn.logits_tbv(out)
         loss_ref = omodel.ctc_mean_loss(logits_ref, labels, x_len, l_len)
-        (loss_ref * LOSS_SCALE).backward()       # both sides' gradients carry the seed: the relative errors do not
+        (loss_ref * seed).backward()       # both sides' gradients carry the seed: the relative errors do not
         errs = {}
         for name, p in model.named_parameters():
             g_ref = params[name].grad
