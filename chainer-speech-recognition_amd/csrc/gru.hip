@@ -1393,6 +1393,22 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         const int kk = ks * 32 + 8 * (lane >> 4);
         ring_frag_off[i2] = (unsigned)(((kk >> 4) * 128 + row * 16 + (kk & 15)) * 2);
     }
+#ifdef ASR_EXP_REDUNDANT
+    // what-if: every compute wave also fetches (and waits for) the other ASR_EXP_REDUNDANT waves' K slices -- the L2 -> CU volume of a form
+    // in which each wave needs the whole state row
+    Frag xtra[3][NA];
+    unsigned xoff[3][NA];
+#pragma unroll
+    for (int ww = 0; ww < 3; ++ww)
+#pragma unroll
+        for (int i2 = 0; i2 < KSW / 2; ++i2) {
+            const int r16 = lane & 15, row = r16 & 7, w2 = (w + ww + 1) & 3;
+            const int ks = ((i2 * 4 + w2) * 2) + (r16 >> 3);
+            const int kk = ks * 32 + 8 * (lane >> 4);
+            xoff[ww][i2] = (unsigned)(((kk >> 4) * 128 + row * 16 + (kk & 15)) * 2);
+            xtra[ww][i2].u = make_uint4(0, 0, 0, 0);
+        }
+#endif
     auto fetch_ring = [&](Frag (&f)[NA], int slot) {
 #pragma unroll
         for (int i2 = 0; i2 < KSW / 2; ++i2) {
@@ -1401,6 +1417,17 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 f[i2].u = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
+#ifdef ASR_EXP_REDUNDANT
+#pragma unroll
+        for (int ww = 0; ww < ASR_EXP_REDUNDANT; ++ww)
+#pragma unroll
+            for (int i2 = 0; i2 < KSW / 2; ++i2) {
+                if (frag_on[i2]) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ringrsrc, xoff[ww][i2] + (unsigned)slot * slot_bytes, 0, 16 /* sc1 */);
+                    xtra[ww][i2].u = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+            }
+#endif
     };
     const unsigned ring_store_off = (unsigned)(((j0 >> 4) * 128 + b * 16 + u) * 2);
     Frag ahead[NA], acur[NA];   // ahead: (gate waves) the next step's first attempt, issued right behind their own h store
@@ -1505,6 +1532,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
 #pragma unroll
                         for (int i2 = 0; i2 < KSW / 2; ++i2)
                             missing |= acur[i2].u.x == 0xffffffffu || acur[i2].u.y == 0xffffffffu || acur[i2].u.z == 0xffffffffu || acur[i2].u.w == 0xffffffffu;
+#ifdef ASR_EXP_REDUNDANT
+#pragma unroll
+                        for (int ww = 0; ww < ASR_EXP_REDUNDANT; ++ww)
+#pragma unroll
+                            for (int i2 = 0; i2 < KSW / 2; ++i2)
+                                missing |= xtra[ww][i2].u.x == 0xffffffffu || xtra[ww][i2].u.y == 0xffffffffu || xtra[ww][i2].u.z == 0xffffffffu || xtra[ww][i2].u.w == 0xffffffffu;
+#endif
                         if (__ballot(missing) == 0ull) break;
                         if ((++spins & 63u) == 0u) {
                             if (__hip_atomic_load(abort_word, ASR_RLX_AGENT) != 0u) { if (lane == 0) *s_abort = 1; break; }
