@@ -119,6 +119,8 @@ SIGNATURES = {
     "asr_gru_gates_f16_ok": (c_int, [c_int] * 5),
     "asr_gru_fwd": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int]),
     "asr_gru_bwd": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "asr_gru_fwd_state": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p]),
+    "asr_gru_bwd_state": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_void_p, c_void_p]),
     "asr_sru_ws_bytes": (c_size_t, [c_int] * 3),
     "asr_sru_fwd": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p, c_size_t]),
     "asr_sru_bwd": (c_int, [c_void_p] * 13 + [c_int] * 4 + [c_void_p, c_size_t]),

@@ -452,6 +452,37 @@ def gru_fwd(gi, whh16, bhh, T, B, H, ndir, x_len=None):
     return y, hseq, hseq16, gates
 
 
+def gru_fwd_state(gi, whh16, bhh, hx, T, B, H, ndir, x_len=None):
+    """the layer with an initial state hx (ndir, B, H) float32 (asr_gru_fwd_state: per-step kernels, float32 gi and gates)"""
+    dev = gi.device
+    assert gi.dtype == F32 and hx.dtype == F32 and hx.shape == (ndir, B, H) and hx.is_contiguous()
+    x_len = _len_i32(x_len, B, dev)
+    hseq = torch.empty((T * B, ndir * H), dtype=F32, device=dev)
+    hseq16 = torch.empty((T * B, ndir * H), dtype=BF16, device=dev)
+    gates = torch.empty((T * B, ndir, 4, H), dtype=F32, device=dev)
+    y = torch.empty((T * B, H), dtype=BF16, device=dev)
+    rc = _lib.lib().asr_gru_fwd_state(stream(), ptr(gi), ptr(whh16), ptr(bhh), ptr(hx), ptr(hseq), ptr(hseq16), ptr(gates), ptr(y),
+                                      T, B, H, ndir, ptr(x_len))
+    check(rc, "asr_gru_fwd_state")
+    return y, hseq, hseq16, gates
+
+
+def gru_bwd_state(dy, gates, hseq, hx, dhy, whhT16, T, B, H, ndir, db_ih=None, db_hh=None, x_len=None):
+    """-> dgi, dgh (bf16 rows) and dhx (ndir, B, H) float32; dhy: gradient of the final state or None"""
+    dev = dy.device
+    x_len = _len_i32(x_len, B, dev)
+    dy_ws = torch.empty((T * B, H), dtype=BF16, device=dev) if x_len is not None else None
+    dgi = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
+    dgh = torch.empty((T * B, ndir * 3 * H), dtype=BF16, device=dev)
+    carry = torch.empty((ndir, B, H), dtype=F32, device=dev)
+    dhx = torch.empty((ndir, B, H), dtype=F32, device=dev)
+    rc = _lib.lib().asr_gru_bwd_state(stream(), ptr(dy.contiguous()), ptr(gates), ptr(hseq), ptr(hx), None if dhy is None else ptr(dhy.contiguous()),
+                                      ptr(whhT16), ptr(dgi), ptr(dgh), ptr(carry), ptr(db_ih), ptr(db_hh), ptr(dhx), T, B, H, ndir,
+                                      ptr(x_len), ptr(dy_ws))
+    check(rc, "asr_gru_bwd_state")
+    return dgi, dgh, dhx
+
+
 LAST_SYNC = [None]
 
 

@@ -1122,12 +1122,58 @@ class _GRU(torch.autograd.Function):
         return gx, None, None, None, None, None, None, None, None, None, None
 
 
-def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir, x_length=None):
+class _GRUState(torch.autograd.Function):
+    """_GRU with a given initial state: x rows (T*B, I) bf16, hx (ndir, B, H) float32 -> y rows (T*B, H) bf16 (directions summed) and
+    the final state hy (ndir, B, H) float32 -- chainer.links.NStepGRU's hx / hy.  One launch per time step (asr_gru_fwd_state)."""
+
+    @staticmethod
+    def forward(ctx, x2, w_ih, w_hh, b_ih, b_hh, hx, copies, T, B, H, ndir, x_len):
+        wih16, wih16t, whh16, whh16t = copies
+        gi = _ops.gemm_nt(x2, wih16, b_ih.detach().reshape(-1), F32)
+        hx = hx.detach().to(F32).contiguous()
+        y, hseq, hseq16, gates = _ops.gru_fwd_state(gi, whh16, b_hh.detach().reshape(-1), hx, T, B, H, ndir, x_len)
+        h4 = hseq.reshape(T, B, ndir, H)
+        hy = torch.stack([h4[T - 1, :, 0]] + ([h4[0, :, 1]] if ndir == 2 else []), dim=0).contiguous()
+        ctx.save_for_backward(x2, hseq, hseq16, gates, wih16t, whh16t, hx)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.meta = (T, B, H, ndir, ctx.needs_input_grad[0], x_len)
+        return y, hy
+
+    @staticmethod
+    def backward(ctx, gy, ghy):
+        x2, hseq, hseq16, gates, wih16t, whh16t, hx = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh = ctx.params
+        T, B, H, ndir, need_dx, x_len = ctx.meta
+        if gy is None:
+            gy = torch.zeros((T * B, H), dtype=BF16, device=hseq.device)
+        dhy = None if ghy is None else ghy.to(F32).contiguous()
+        dgi, dgh, dhx = _ops.gru_bwd_state(gy.contiguous(), gates, hseq, hx, dhy, whh16t, T, B, H, ndir, grad_buffer(b_ih).reshape(-1),
+                                           grad_buffer(b_hh).reshape(-1), x_len)
+        gwih = grad_buffer(w_ih).reshape(ndir * 3 * H, -1)
+        gwhh = grad_buffer(w_hh).reshape(ndir, 3 * H, H)
+        hx16 = hx.to(BF16)
+        products = [(dgi, x2, gwih)]
+        for d in range(ndir):           # dW_hh[d] = sum_t dgh_t (x) h_{t-1}, h_{-1} = hx
+            a = dgh[:, d * 3 * H:(d + 1) * 3 * H]
+            h = hseq16[:, d * H:(d + 1) * H]
+            if T > 1:
+                products.append((a[B:], h[:-B], gwhh[d]) if d == 0 else (a[:-B], h[B:], gwhh[d]))
+            products.append((a[:B] if d == 0 else a[(T - 1) * B:], hx16[d], gwhh[d]))
+        for a, b, c in products:
+            _ops.gemm_tn_acc(a, b, c)
+        gx = _ops.gemm_nt(dgi, wih16t, None, BF16) if need_dx else None
+        grads_queued(w_ih, w_hh, b_ih, b_hh)
+        return gx, None, None, None, None, dhx, None, None, None, None, None, None
+
+
+def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir, x_length=None, hx=None):
     """x logical (B, I, T); parameters stacked over directions: w_ih (ndir, 3H, I), w_hh (ndir, 3H, H),
     b_ih / b_hh (ndir, 3H).  Returns logical (B, H, T), the directions summed.
     x_length (B) int32 device tensor or None: frames per utterance -- the recurrences then run every utterance over its own
     length as chainer.links.NStepBiGRU does (asr/nn/nn.py:3): the reverse direction of utterance b starts at x_length[b] - 1,
-    the output is zero beyond it and the padding receives / passes no gradient."""
+    the output is zero beyond it and the padding receives / passes no gradient.
+    hx (ndir, B, H) float32 or None: the initial state; given one, the result is (y, hy) with hy (ndir, B, H) the final state
+    (NStepGRU's hx / hy; this form runs one launch per time step: _GRUState)."""
     p = phys3(x)
     T, B, I = p.shape
     H = w_hh.shape[2]
@@ -1137,6 +1183,11 @@ def gru(x, w_ih, w_hh, b_ih, b_hh, link, ndir, x_length=None):
         link.compute_copy("whh16", w_hh, lambda w: _ops.cast_bf16(w.reshape(-1, w.shape[-1])).reshape(w.shape), "plain"),
         link.compute_copy("whh16t", w_hh, _cast_transposed_per_direction, "t_each"),
     )
+    if hx is not None:
+        if tuple(hx.shape) != (ndir, B, H):
+            raise ValueError("hx must have shape (ndir, B, H) = %s, got %s" % ((ndir, B, H), tuple(hx.shape)))
+        y, hy = _GRUState.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, hx, copies, T, B, H, ndir, x_length)
+        return logical3(y.reshape(T, B, H)), hy
     y = _GRU.apply(p.reshape(T * B, I), w_ih, w_hh, b_ih, b_hh, copies, T, B, H, ndir, x_length)
     return logical3(y.reshape(T, B, H))
 

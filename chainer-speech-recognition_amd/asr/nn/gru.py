@@ -27,12 +27,14 @@ class _GRUBase(Link):
         self.in_size = in_size
         self.w_ih.data = self._init((self.ndir, 3 * self.out_size, in_size)).to(self.w_ih.device)
 
-    def __call__(self, x, x_length=None):
+    def __call__(self, x, x_length=None, hx=None):
         """x (B, D, T) -> (B, H, T); bidirectional outputs are summed (Deep-Speech-2 style).  x_length (B) int32 on the device:
-        run every utterance over its own length (NStepBiGRU semantics on the padded block; functions.gru)."""
+        run every utterance over its own length (NStepBiGRU semantics on the padded block; functions.gru).
+        hx (ndir, B, H) float32: an initial state -- the call then returns (y, hy), hy (ndir, B, H) the final state, so that a long
+        sequence can be fed in pieces (the way the reference's SRU model carries its contexts, run/ctc/sru/model.py:105-122)."""
         if self.w_ih.numel() == 0:
             self._initialize_params(x.shape[1])
-        return functions.gru(x, self.w_ih, self.w_hh, self.b_ih, self.b_hh, self, self.ndir, x_length)
+        return functions.gru(x, self.w_ih, self.w_hh, self.b_ih, self.b_hh, self, self.ndir, x_length, hx)
 
 
 class GRU(_GRUBase):
@@ -51,7 +53,7 @@ class BiGRU(_GRUBase):
 
 class _NStep(Link):
     """chainer.links.NStepGRU / NStepBiGRU call semantics: ``hy, ys = rnn(hx, xs)`` with ``xs`` a list of (T_i, I) sequences
-    (any lengths), ``hx`` None (zero initial state; a given initial state is not supported by the recurrence kernels),
+    (any lengths), ``hx`` None (zero initial state) or (n_layers * ndir, B, H) (a given one runs the layer on the per-step kernels),
     ``ys`` a list of (T_i, ndir * H) outputs with the two directions CONCATENATED, ``hy`` (n_layers * ndir, B, H) the last
     states.  The reference never builds one, so this is API surface, not hot path: sequences are grouped by
     length, every group runs as one batch through per-direction GRU links (the backward direction on the time-reversed
@@ -65,10 +67,11 @@ class _NStep(Link):
                 setattr(self, "l%d_%d" % (i, d), _GRUBase(in_size if i == 0 else out_size * ndir, out_size, 1))
 
     def __call__(self, hx, xs):
-        if hx is not None:
-            raise NotImplementedError("an initial hidden state is not supported: pass hx=None (zeros)")
         if not isinstance(xs, (list, tuple)) or len(xs) == 0:
             raise TypeError("xs must be a list of (T_i, I) sequences")
+        if hx is not None and tuple(hx.shape) != (self.n_layers * self.ndir, len(xs), self.out_size):
+            raise ValueError("hx must have shape (n_layers * ndir, B, H) = %s, got %s"
+                             % ((self.n_layers * self.ndir, len(xs), self.out_size), tuple(hx.shape)))
         groups = {}
         for idx, x in enumerate(xs):
             groups.setdefault(int(x.shape[0]), []).append(idx)
@@ -80,10 +83,15 @@ class _NStep(Link):
                 outs = []
                 for d in range(self.ndir):
                     link = getattr(self, "l%d_%d" % (layer, d))
-                    y = link(h if d == 0 else torch.flip(h, dims=(2,)))
+                    hin = h if d == 0 else torch.flip(h, dims=(2,))
+                    if hx is None:
+                        y = link(hin)
+                    else:
+                        h0 = hx[layer * self.ndir + d][torch.as_tensor(members, device=hx.device)].unsqueeze(0)
+                        y, hlast = link(hin, hx=h0.to(torch.float32).contiguous())
                     y = y if d == 0 else torch.flip(y, dims=(2,))
                     outs.append(y)
-                    last = y[:, :, -1] if d == 0 else y[:, :, 0]
+                    last = (y[:, :, -1] if d == 0 else y[:, :, 0]).float() if hx is None else hlast[0]
                     for k, i in enumerate(members):
                         hy[layer * self.ndir + d][i] = last[k]
                 h = outs[0] if self.ndir == 1 else torch.cat(outs, dim=1)

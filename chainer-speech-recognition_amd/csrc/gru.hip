@@ -45,12 +45,14 @@ template <int KSW>
 __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__ gi, const uint16_t* __restrict__ whh,
                                                        const float* __restrict__ bhh, float* __restrict__ hseq,
                                                        uint16_t* __restrict__ hseq16, float* __restrict__ gates, int T,
-                                                       int B, int H, int ndir, int s) {
+                                                       int B, int H, int ndir, int s, const float* __restrict__ hx) {
+    // hx (ndir, B, H) float32 or NULL: the state in front of the first step (asr_gru_fwd_state); NULL = zeros, no product at s == 0
     __shared__ __attribute__((aligned(16))) float4 part[4 * MT * 3 * 64];
     const int d = blockIdx.y, j0 = blockIdx.x * 16;
     const int t = d == 0 ? s : T - 1 - s;
     const int tp = d == 0 ? t - 1 : t + 1;
-    const bool first = s == 0;
+    const bool from_hx = s == 0 && hx != nullptr;
+    const bool first = s == 0 && hx == nullptr;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nks = H >> 5;
     const size_t hs = (size_t)ndir * H;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
                 e_gi[q][g] = ok ? gir[g * H] : 0.f;
                 e_bh[q][g] = bhh[(d * 3 + g) * H + j0 + j];
             }
-            e_hp[q] = (ok && !first) ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : 0.f;
+            e_hp[q] = (ok && !first) ? (from_hx ? hx[((size_t)d * B + b) * H + j0 + j] : hseq[((size_t)tp * B + b) * hs + d * H + j0 + j]) : 0.f;
         }
         if (!first) {
             Frag a[KSW][MT], bb[KSW][3];
@@ -82,6 +84,14 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const float* __restrict__
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int row = b0 + m * 16 + (lane & 15);
+                    if (from_hx) {          // the given state, rounded to the 16-bit operand format as every later state is
+                        a[i][m].u = make_uint4(0, 0, 0, 0);
+                        if (kok && row < B) {
+                            const float4* src = reinterpret_cast<const float4*>(hx + ((size_t)d * B + row) * H + k);
+                            const float4 v0 = src[0], v1 = src[1];
+                            a[i][m].u = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w));
+                        }
+                    } else
                     a[i][m].u = (kok && row < B) ? *reinterpret_cast<const uint4*>(hseq16 + ((size_t)tp * B + row) * hs + d * H + k)
                                                  : make_uint4(0, 0, 0, 0);
                 }
@@ -150,7 +160,9 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
                                                        const float* __restrict__ hseq,
                                                        const uint16_t* __restrict__ whhT, uint16_t* __restrict__ dgi,
                                                        uint16_t* __restrict__ dgh, float* __restrict__ carry, int T,
-                                                       int B, int H, int ndir, int s) {
+                                                       int B, int H, int ndir, int s, const float* __restrict__ hx, int carry_init) {
+    // hx: the state in front of the first forward step (NULL = zeros); carry_init: `carry` arrives holding the gradient of the final
+    // state (dhy of asr_gru_bwd_state) instead of being undefined before the first step
     __shared__ __attribute__((aligned(16))) float4 part[4 * MT * 64];
     const int d = blockIdx.y, j0 = blockIdx.x * 16;
     const int t = d == 0 ? T - 1 - s : s;          // reverse of the forward order
@@ -171,11 +183,11 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
             const bool ok = b < B;
             const size_t rowi = (size_t)t * B + (ok ? b : 0);
             e_dy[q] = ok ? bf16_to_f32(dy[rowi * H + j0 + j]) : 0.f;
-            e_c[q] = (ok && !first) ? carry[((size_t)d * B + b) * H + j0 + j] : 0.f;
+            e_c[q] = (ok && (!first || carry_init)) ? carry[((size_t)d * B + b) * H + j0 + j] : 0.f;
             const float* gs = gates + (rowi * ndir + d) * 4 * H + j0 + j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) e_g[q][g] = ok ? gs[g * H] : 0.f;
-            e_hp[q] = (ok && has_prev) ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : 0.f;
+            e_hp[q] = !ok ? 0.f : has_prev ? hseq[((size_t)tp * B + b) * hs + d * H + j0 + j] : (hx ? hx[((size_t)d * B + b) * H + j0 + j] : 0.f);
         }
         if (!first) {
             f32x4 acc[MT];
@@ -218,9 +230,8 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const uint16_t* __restric
             const int m = bl >> 4, row = bl & 15;
             const int pl = (row >> 2) * 16 + j, pr = row & 3;
             const size_t rowi = (size_t)t * B + b;
-            float dh = e_dy[q];
+            float dh = e_dy[q] + e_c[q];
             if (!first) {
-                dh += e_c[q];
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) {
                     const float4 v = part[(ww * MT + m) * 64 + pl];
@@ -2026,6 +2037,27 @@ __global__ __launch_bounds__(640, 3) void fwd_wide_kernel(const float* __restric
 }
 
 // y = hf + hb (or a copy for one direction): f32 state -> bf16 layer output; rows beyond an utterance's length are zero
+// gradient of the initial state (asr_gru_bwd_state): dhx = dh_{first} z_{first} (what the sweep left in `carry`) + dgh_{first} W_hh
+__global__ __launch_bounds__(256) void dhx_kernel(const uint16_t* __restrict__ dgh, const uint16_t* __restrict__ whhT, const float* __restrict__ carry,
+                                                  float* __restrict__ dhx, int T, int B, int H, int ndir) {
+    const long long idx = blockIdx.x * 256ll + threadIdx.x, total = (long long)ndir * B * H;
+    if (idx >= total) return;
+    const int d = (int)(idx / ((long long)B * H)), b = (int)((idx / H) % B), j = (int)(idx % H);
+    const long long t0 = d == 0 ? 0 : T - 1;
+    const uint4* g = reinterpret_cast<const uint4*>(dgh + ((size_t)t0 * B + b) * ((size_t)ndir * 3 * H) + (size_t)d * 3 * H);
+    const uint4* w = reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + j) * (3 * (size_t)H));
+    float acc = carry[idx];
+    for (int k8 = 0; k8 < (3 * H) / 8; ++k8) {
+        const uint4 gv = g[k8], wv = w[k8];
+        const unsigned gs[4] = {gv.x, gv.y, gv.z, gv.w}, ws[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc += bf16_to_f32((uint16_t)(gs[e] & 0xffff)) * bf16_to_f32((uint16_t)(ws[e] & 0xffff)) +
+                   bf16_to_f32((uint16_t)(gs[e] >> 16)) * bf16_to_f32((uint16_t)(ws[e] >> 16));
+    }
+    dhx[idx] = acc;
+}
+
 __global__ void merge_dirs_kernel(const float* __restrict__ hseq, uint16_t* __restrict__ y, long long rows, int H,
                                   int ndir, const int* __restrict__ x_len, int B) {
     const long long n = rows * H;
@@ -2380,7 +2412,7 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     } else
     for (int s = 0; s < T; ++s) {
 #define ASR_FWD(K) hipLaunchKernelGGL(fwd_step_kernel<K>, grid, block, 0, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
-                                      (uint16_t*)hseq_bf16, gates, T, B, H, ndir, s)
+                                      (uint16_t*)hseq_bf16, gates, T, B, H, ndir, s, (const float*)nullptr)
         if (ksw <= 1) ASR_FWD(1); else if (ksw <= 2) ASR_FWD(2); else if (ksw <= 4) ASR_FWD(4); else ASR_FWD(8);
 #undef ASR_FWD
     }
@@ -2496,12 +2528,96 @@ extern "C" int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates_
     if (ksw > 12) return ASR_ERR_UNSUPPORTED;        // (the per-step kernel holds at most 12 K steps per wave: H <= 512)
     for (int s = 0; s < T; ++s) {
 #define ASR_BWD(K) hipLaunchKernelGGL(bwd_step_kernel<K>, grid, block, 0, st, (const uint16_t*)dy_bf16, gates, hseq, \
-                                      (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s)
+                                      (const uint16_t*)whhT_bf16, (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s, (const float*)nullptr, 0)
         if (ksw <= 2) ASR_BWD(2); else if (ksw <= 6) ASR_BWD(6); else ASR_BWD(12);
 #undef ASR_BWD
     }
     ASR_LAUNCH_CHECK();
     // bias gradients (the persistent kernels sum them in registers; here a column sum over all (t, b) rows)
+    if (db_ih) {
+        const int rc2 = asr_colsum_acc(stream, dgi_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_ih);
+        if (rc2 != ASR_OK) return rc2;
+    }
+    if (db_hh) {
+        const int rc2 = asr_colsum_acc(stream, dgh_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_hh);
+        if (rc2 != ASR_OK) return rc2;
+    }
+    return ASR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- a layer with a given initial state
+// chainer.links.NStepGRU / NStepBiGRU's hx and hy (asr/nn/nn.py:3 exports them; no recipe of the reference hands a state to a GRU --
+// its SRU model carries one, run/ctc/sru/model.py:105-122): the same arithmetic on the one-launch-per-time-step kernels, which take the
+// state in front of the first step from `hx` instead of zeros.  The final state is rows of hseq (direction 0: t = T - 1, direction 1:
+// t = 0; with x_len the frozen state of a shorter utterance), so there is no hy argument.
+extern "C" int asr_gru_fwd_state(void* stream, const float* gi, const void* whh_bf16, const float* bhh, const float* hx, float* hseq,
+                                 void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, const int* x_len) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;
+    if (!gi || !whh_bf16 || !bhh || !hseq || !hseq_bf16 || !gates) return ASR_ERR_BAD_ARG;
+    const int rc = check_dims(T, B, H, ndir);
+    if (rc != ASR_OK) return rc;
+    const int ksw = (H / 32 + 3) / 4;
+    if (ksw > 8 || (H % 8)) return ASR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (x_len) {
+        if ((long long)T * B > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(pin_update_gate_kernel<float>, dim3((unsigned)(T * B)), dim3(256), 0, st, (float*)gi, x_len, B, H, ndir);
+        ASR_LAUNCH_CHECK();
+    }
+    const dim3 grid(H / 16, ndir), block(256);
+    for (int s = 0; s < T; ++s) {
+#define ASR_FWD(K) hipLaunchKernelGGL(fwd_step_kernel<K>, grid, block, 0, st, gi, (const uint16_t*)whh_bf16, bhh, hseq, \
+                                      (uint16_t*)hseq_bf16, gates, T, B, H, ndir, s, hx)
+        if (ksw <= 1) ASR_FWD(1); else if (ksw <= 2) ASR_FWD(2); else if (ksw <= 4) ASR_FWD(4); else ASR_FWD(8);
+#undef ASR_FWD
+    }
+    ASR_LAUNCH_CHECK();
+    if (y_bf16) {
+        const bool vec = ((((uintptr_t)hseq) | ((uintptr_t)y_bf16)) & 15) == 0;
+        const long long n = (long long)T * B * (vec ? H / 8 : H);
+        long long g = (n + 255) / 256;
+        if (g > 4096) g = 4096;
+        if (vec) hipLaunchKernelGGL(merge_dirs_vec_kernel, dim3((unsigned)g), dim3(256), 0, st, hseq, (uint16_t*)y_bf16, (long long)T * B, H, ndir, x_len, B);
+        else hipLaunchKernelGGL(merge_dirs_kernel, dim3((unsigned)g), dim3(256), 0, st, hseq, (uint16_t*)y_bf16, (long long)T * B, H, ndir, x_len, B);
+        ASR_LAUNCH_CHECK();
+    }
+    return ASR_OK;
+}
+
+extern "C" int asr_gru_bwd_state(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const float* hx, const float* dhy,
+                                 const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh,
+                                 float* dhx, int T, int B, int H, int ndir, const int* x_len, void* dy_ws) {
+    if (ASR_ACT_IS_F16) return ASR_ERR_UNSUPPORTED;
+    if (!dy_bf16 || !gates || !hseq || !whhT_bf16 || !dgi_bf16 || !dgh_bf16 || !carry_ws) return ASR_ERR_BAD_ARG;
+    const int rc = check_dims(T, B, H, ndir);
+    if (rc != ASR_OK) return rc;
+    const int ksw = (3 * H / 32 + 3) / 4;
+    if (ksw > 12 || (H % 8)) return ASR_ERR_UNSUPPORTED;        // (the per-step kernel holds at most 12 K steps per wave: H <= 512)
+    hipStream_t st = (hipStream_t)stream;
+    if (x_len) {
+        if (!dy_ws) return ASR_ERR_BAD_ARG;
+        const long long n = (long long)T * B * (H / 8);
+        long long g = (n + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(mask_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, (const uint16_t*)dy_bf16, (uint16_t*)dy_ws, x_len, (long long)T * B, B, H / 8);
+        ASR_LAUNCH_CHECK();
+        dy_bf16 = dy_ws;
+    }
+    if (dhy && hipMemcpyAsync(carry_ws, dhy, (size_t)ndir * B * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return ASR_ERR_LAUNCH;
+    const dim3 grid(H / 16, ndir), block(256);
+    for (int s = 0; s < T; ++s) {
+#define ASR_BWD(K) hipLaunchKernelGGL(bwd_step_kernel<K>, grid, block, 0, st, (const uint16_t*)dy_bf16, gates, hseq, (const uint16_t*)whhT_bf16, \
+                                      (uint16_t*)dgi_bf16, (uint16_t*)dgh_bf16, carry_ws, T, B, H, ndir, s, hx, dhy ? 1 : 0)
+        if (ksw <= 2) ASR_BWD(2); else if (ksw <= 6) ASR_BWD(6); else ASR_BWD(12);
+#undef ASR_BWD
+    }
+    ASR_LAUNCH_CHECK();
+    if (dhx) {
+        const long long total = (long long)ndir * B * H;
+        hipLaunchKernelGGL(dhx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint16_t*)dgh_bf16, (const uint16_t*)whhT_bf16,
+                           (const float*)carry_ws, dhx, T, B, H, ndir);
+        ASR_LAUNCH_CHECK();
+    }
     if (db_ih) {
         const int rc2 = asr_colsum_acc(stream, dgi_bf16, 1, (long long)T * B, ndir * 3 * H, ndir * 3 * H, db_ih);
         if (rc2 != ASR_OK) return rc2;

@@ -340,6 +340,18 @@ int asr_gru_fwd(void* stream, void* gi, int gi_bf16, const void* whh_bf16, const
 int asr_gru_bwd(void* stream, const void* dy_bf16, const void* gates, const float* hseq, const void* whhT_bf16,
                 void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh, int T, int B, int H,
                 int ndir, void* sync_ws, int mode, const int* x_len, void* dy_ws, int gates_f16);
+/* The same layer with a GIVEN initial state (chainer.links.NStepGRU / NStepBiGRU: `hy, ys = rnn(hx, xs)`, exported by asr/nn/nn.py:3;
+ * the reference's SRU model carries a state across calls, run/ctc/sru/model.py:105-122, no GRU recipe does).  hx (ndir, B, H) float32 or
+ * NULL (= zeros); gi float32; gates float32 in the plain [T*B][ndir][4][H] layout.  They run on the one-launch-per-time-step kernels (the
+ * persistent kernels start from a zero state).  The final state hy is rows of hseq: direction 0 at t = T - 1, direction 1 at t = 0 (with
+ * x_len: the frozen state of a shorter utterance).  asr_gru_bwd_state: dhy (ndir, B, H) float32 or NULL = gradient arriving at hy; dhx
+ * (ndir, B, H) float32 or NULL receives the gradient of hx; the caller adds dgh_{first step}^T . hx to the W_hh gradient (the
+ * products over t >= 1 are those of asr_gru_bwd's caller). */
+int asr_gru_fwd_state(void* stream, const float* gi, const void* whh_bf16, const float* bhh, const float* hx, float* hseq,
+                      void* hseq_bf16, float* gates, void* y_bf16, int T, int B, int H, int ndir, const int* x_len);
+int asr_gru_bwd_state(void* stream, const void* dy_bf16, const float* gates, const float* hseq, const float* hx, const float* dhy,
+                      const void* whhT_bf16, void* dgi_bf16, void* dgh_bf16, float* carry_ws, float* db_ih, float* db_hh, float* dhx,
+                      int T, int B, int H, int ndir, const int* x_len, void* dy_ws);
 
 /* ---------------------------------------------------------------------------------------- SRU scan
  * Replaces the CUDA kernels `forward` / `backward` of asr/nn/sru.py:17-73,75-191 (SRUFunction.forward_gpu :327-367,

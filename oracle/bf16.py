@@ -196,6 +196,24 @@ def gru_f32(x, w_ih, w_hh, b_ih, b_hh, x_len=None):
     return y if ndir == 1 else y[..., :H] + y[..., H:]
 
 
+def gru_f32_state(x, w_ih, w_hh, b_ih, b_hh, h0, x_len=None):
+    """gru_f32 with an initial state h0 (ndir, B, H): -> (y (T, B, H) directions summed, hy (ndir, B, H)) -- NStepGRU's hx / hy"""
+    T, B, I = x.shape
+    ndir, H = w_hh.shape[0], w_hh.shape[2]
+    flat = []
+    for d in range(ndir):
+        flat += [w_ih[d], w_hh[d], b_ih[d], b_hh[d]]
+    if x_len is None:
+        res, hy = torch._VF.gru(x, h0, flat, True, 1, 0.0, False, ndir == 2, False)
+        return (res if ndir == 1 else res[..., :H] + res[..., H:]), hy
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, x_len.long().cpu(), enforce_sorted=False)
+    data, batch_sizes, sorted_idx, unsorted_idx = packed
+    res, hy = torch._VF.gru(data, batch_sizes, h0.index_select(1, sorted_idx), flat, True, 1, 0.0, False, ndir == 2)
+    out_packed = torch.nn.utils.rnn.PackedSequence(res, batch_sizes, sorted_idx, unsorted_idx)
+    y, _ = torch.nn.utils.rnn.pad_packed_sequence(out_packed, total_length=T)
+    return (y if ndir == 1 else y[..., :H] + y[..., H:]), hy.index_select(1, unsorted_idx)
+
+
 def gru(x, w_ih, w_hh, b_ih, b_hh, x_len=None, matched=False, gi_bf16=True, ps_units=None, gates_f16=False):
     if not matched:
         return gru_f32(x, w_ih, w_hh, b_ih, b_hh, x_len)

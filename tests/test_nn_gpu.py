@@ -395,8 +395,8 @@ def test_nstep_bigru_has_chainers_call_semantics(device):
     loss = sum(y.float().sum() for y in ys)
     loss.backward()
     assert rnn.l0_1.w_hh.grad is not None and torch.isfinite(rnn.l1_0.w_ih.grad).all()
-    with pytest.raises(NotImplementedError):
-        rnn(torch.zeros(L * 2, len(lens), H, device=device), [x.to(device) for x in xs])
+    with pytest.raises(ValueError):                 # (a given hx: tests/test_gru_state_gpu.py; a mis-shaped one is refused)
+        rnn(torch.zeros(L * 2 + 1, len(lens), H, device=device), [x.to(device) for x in xs])
 
 
 def test_projection_bias_gradient_with_a_second_consumer_of_the_logits(device):
