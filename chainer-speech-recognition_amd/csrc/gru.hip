@@ -278,13 +278,14 @@ constexpr unsigned kSpinLimit = 1u << 22;
 // their way to the L2 -- and the retry queues BEHIND it in the CU's memory pipeline: the hand-off then costs two round trips.  A
 // poll timed to pass the L2 just after the stores land usually succeeds at once.  Forward kernel, T=1000, B=32, H=512, us per step:
 // 0: 1.487, 3: 1.433, 6: 1.384, 10: 1.345, 11-12: 1.340, 14: 1.369, 18: 1.448, 26: 1.658 (three staggered polls in flight: 1.83).
-// The partial-sum backward kernel does not gain (0: 1.541, 6: 1.545, 10: 1.639): its first attempt already follows the re-arm stores
-// and the next step's LDS prologue.
+// The partial-sum backward kernel did not gain while its first attempt followed 64 16-lane store instructions of the workgroup (round 3:
+// 0: 1.541, 6: 1.545, 10: 1.639); with 16 full-wave stores (round 4) the poll goes out ~300 cycles earlier and wants the pause back:
+// 0: 1.331, 3: 1.287, 6: 1.262, 8: 1.251, 10: 1.252, 12: 1.297, 15: 1.379 us per step.
 #ifndef ASR_FIRST_POLL_DELAY
 #define ASR_FIRST_POLL_DELAY 11
 #endif
 #ifndef ASR_BWD_POLL_DELAY
-#define ASR_BWD_POLL_DELAY 0
+#define ASR_BWD_POLL_DELAY 8
 #endif
 #ifndef ASR_TOUCH
 #define ASR_TOUCH 1
@@ -373,6 +374,11 @@ __device__ __forceinline__ void poll_pause(int n) {
     else for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
 
+// the value of another lane through a DPP move (CTRL: 0x141 row_half_mirror = lane 7 - k of each eight, quad_perm 0x4E = k ^ 2, 0xB1 = k ^ 1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ unsigned lane_xor1_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
@@ -837,8 +843,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [8 lane groups][4 rows][2][16] f32, group pitch 144 floats: the eight store instructions of a gate wave (four groups of 16
     // lanes each) then meet a 2-way bank conflict, which a ds_write_b32 absorbs, instead of a 4-way one (pitch 128)
-    constexpr int RED_PITCH = 144;
-    float* red = reinterpret_cast<float*>(smem);
+    constexpr int RED_PITCH = 144;          // (the first 8 x 144 floats held the partial sums of the eight lane groups until round 4)
     // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB: rows 4 .. 15 exist and stay zero, so that every lane reads its
     // fragment unconditionally -- three ds_reads back to back and ONE wait (with 4-row images the reads sat behind exec-mask
     // branches, each followed by its own wait: two LDS round trips more on the chain of every compute wave)
@@ -926,14 +931,18 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                 bb[gg][n].u = *reinterpret_cast<const uint4*>(whhT + ((size_t)d * H + ncol0 + n * 16 + (lane & 15)) * (3 * H) + (size_t)gg * H + j0 +
                                                               8 * (lane >> 4));
     }
-    // gate phase on waves 2 and 3: thread (row (tid - 128) / 32, unit tid % 32)
-    const int b = ((tid - 128) >> 5) & 3, u0 = tid & 31;
+    // gate phase on waves 2 and 3.  Gate lane gl = tid - 128 belongs to the eight-lane group gl / 8 = unit pair `seg` and is thread
+    // (row gl % 4, unit 2 seg + (gl / 4) % 2): the eight lanes of a group fetch the 16 producers' pieces of THEIR unit pair (two each) and
+    // reduce-scatter them among themselves with DPP moves (see below) -- every lane ends up with the exchanged sum of its own (row, unit)
+    // without the LDS image and the workgroup barrier that stood between the poll and the gate math
+    const int b = (tid - 128) & 3, u0 = ((((tid - 128) >> 3) & 15) << 1) | (((tid - 128) >> 2) & 1);
     const bool gate_wave = tid >= 128 && tid < 256;
     const bool act = gate_wave && b < Bl;
     float carry = 0.f, sb[4] = {0.f, 0.f, 0.f, 0.f};
     if (tid == 0) {
         *s_abort = 0;
         s_abort[1] = 0;
+        s_abort[2] = 0;
         if (LOCAL) {
             const int v = decide_local(sync, rec, nwg, abort_word, (forge & 1) ? 2 + (slot & 1) : 0);
             if (v < 0) *s_abort = 1; else s_abort[1] = v;
@@ -951,15 +960,15 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 #define ASR_PS(i)
 #endif
 
-    // hand-off loads of the gate waves: 128 lanes x 2 pieces of 16 B = H/32 (<= 16.. 32) producers x 256 B.  Piece q = gl + 128 i:
-    // producer q / 16, columns j0 + 2 (q % 16), + 1 (x 4 rows).  (H = 1024: 32 producers -> 4 pieces per lane.)
+    // hand-off loads of the gate waves: 128 lanes x 2 pieces of 16 B = H/32 (<= 16.. 32) producers x 256 B.  Lane gl (group seg = gl / 8,
+    // k = gl % 8) fetches producers k, k + 8, ... : columns j0 + 2 seg, + 1 (x 4 rows).  (H = 1024: 32 producers -> 4 pieces per lane.)
     constexpr int NP = NT <= 4 ? 2 : 4;
     const int gl = tid - 128;                                   // 0 .. 127 on the gate waves
     unsigned poff[NP];
     bool pon[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int q = gl + 128 * i, pp = q >> 4, seg = q & 15;
+        const int pp = (gl & 7) + 8 * i, seg = (gl >> 3) & 15;
         pon[i] = gate_wave && pp < nwg;
         poff[i] = (unsigned)(((size_t)pp * H + j0 + 2 * seg) * 8);
     }
@@ -1021,6 +1030,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 #ifdef ASR_STAMP
                 ps_acc[7] += spins + 1;
 #endif
+                if (tid == 128) lds_poke(s_abort + 2, s);           // (the storer's cue)
                 // lane-local sum over this lane's producers, then [group = gl / 16][row][unit parity][seg] float32 in LDS
                 float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1034,32 +1044,21 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                         }
                     }
                 }
-                float* rw = red + (gl >> 4) * RED_PITCH + (gl & 15);
+                // acc8[j], j = 4 (unit parity) + row, is lane j's (of this eight-lane group) share held by this lane: reduce-scatter over the
+                // group in three DPP exchanges -- partner 7 - k (row_half_mirror) hands over the half it does not keep, then k ^ 2 and k ^ 1
+                // (quad_perm) -- 7 additions and 14 selects on the wave instead of 8 LDS writes, a workgroup barrier and 8 LDS reads
+                const bool lo4 = (gl & 4) == 0, lo2 = (gl & 2) == 0, lo1 = (gl & 1) == 0;
+                float k4[4], k2[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
+                for (int i = 0; i < 4; ++i) k4[i] = (lo4 ? acc8[i] : acc8[4 + i]) + dpp_mov_f32<0x141>(lo4 ? acc8[4 + i] : acc8[i]);
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) rw[rr * 32 + e * 16] = acc8[e * 4 + rr];
+                for (int i = 0; i < 2; ++i) k2[i] = (lo2 ? k4[i] : k4[2 + i]) + dpp_mov_f32<0x4E>(lo2 ? k4[2 + i] : k4[i]);
+                rcr = (lo1 ? k2[0] : k2[1]) + dpp_mov_f32<0xB1>(lo1 ? k2[1] : k2[0]);
             }
         }
         ASR_PS(2)
-        ASR_RAW_BARRIER();                  // (R) the partial sums of the eight lane groups are in LDS
         ASR_PS(3)
-        if ((s & 15) == 0 && lds_peek(s_abort)) break;
-        if (is_loader) {
-            issue(s + BIO_GD);              // the slot step s read above (before barrier R); waits until step s + 2 has landed
-            const int left = T - 1 - (s + 2);
-            // (in flight afterwards: the issues of the two youngest steps, 3 LDS-DMA instructions each -- 2 with half gates)
-            if (left >= BIO_GD - 2) { if (G16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-            else if (left == 1) { if (G16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (is_storer) {
-            if (s > 0) store_step(s - 1);
-        } else if (gate_wave) {
-            if (s > 0) {
-                const float* rr_ = red + b * 32 + (u0 & 1) * 16 + (u0 >> 1);
-#pragma unroll
-                for (int gq = 0; gq < 8; ++gq) rcr += rr_[gq * RED_PITCH];
-            }
+        if (gate_wave) {
             // (the factors that do not depend on dh were formed at the top of the step, under the hand-off's round trip)
             const float dh = dyc + rcr;
             const float dan = dh * f_an;
@@ -1077,50 +1076,84 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             }
         }
         ASR_PS(4)
-        ASR_RAW_BARRIER();                  // (A) the gate gradients of this step are in LDS
+        ASR_RAW_BARRIER();                  // (A) the gate gradients of this step are in LDS -- the step's only workgroup barrier
         ASR_PS(5)
+        if ((s & 15) == 0 && lds_peek(s_abort)) break;
+        if (is_loader) {
+            // the slot step s read (before barrier A) is refilled once the gate waves hold the exchanged sums of step s + 1 (the storer's cue
+            // below: an LDS-DMA in front of the payload stores and polls costs the chain ~0.05 us); then wait until step s + 2 has landed,
+            // which is read behind A(s + 1)
+            if (s + 1 < T) {
+                unsigned nap = 0;
+                while (lds_peek(s_abort + 2) < s + 1 && !lds_peek(s_abort) && ++nap < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+            }
+            issue(s + BIO_GD);
+            const int left = T - 1 - (s + 2);
+            // (in flight afterwards: the issues of the two youngest steps, 3 LDS-DMA instructions each -- 2 with half gates)
+            if (left >= BIO_GD - 2) { if (G16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else if (left == 1) { if (G16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (is_storer) {
+            // this step's gate gradients (staging slot s % 2: written again behind A(s + 2)) -- once the gate waves hold the exchanged sums
+            // of the NEXT step, i.e. when the payload / re-arm stores and the polls of the compute waves have left the CU's memory
+            // pipeline (where barrier R used to put these stores)
+            if (s + 1 < T) {
+                unsigned nap = 0;
+                while (lds_peek(s_abort + 2) < s + 1 && !lds_peek(s_abort) && ++nap < kSpinLimit) __builtin_amdgcn_s_sleep(1);
+            }
+            store_step(s);
+        }
         if (is_compute && s + 1 < T) {
             f32x4 acc[NT];
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) acc[nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
             Frag a[3];
-            const int aq = (lane >> 4) ^ ((0x78 >> ((((lane & 15) >> 2) & 3) * 2)) & 3);
+            // every 4-row group of the 16-row MFMA tile reads the SAME four live rows (an LDS broadcast read: rows lane % 4, chunk lane / 16),
+            // so every lane group q = lane / 16 holds a copy of every tile's result and stores tile q (+ 4, ...): ONE 64-lane store instruction
+            // per four tiles instead of four 16-lane ones, for the payload and for the re-arm.  The CU's memory pipeline took 64 store
+            // instructions per step from the eight compute waves; 16 now.  Same box, T=1000, B=32, H=512: 1.352 -> 1.255 us per step together
+            // with the DPP reduction of the gate waves and the first poll 8 x 64 cycles behind the stores (either change alone: 1.38 / 1.28).
+            const int aq = lane >> 4;
 #pragma unroll
-            for (int gg = 0; gg < 3; ++gg) a[gg].u = *reinterpret_cast<const uint4*>(aimg + (gg * 16 + (lane & 15)) * 32 + 8 * aq);
+            for (int gg = 0; gg < 3; ++gg) a[gg].u = *reinterpret_cast<const uint4*>(aimg + (gg * 16 + (lane & 3)) * 32 + 8 * aq);
 #pragma unroll
             for (int gg = 0; gg < 3; ++gg)
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[gg].v, bb[gg][nn].v, acc[nn], 0, 0, 0);
             const unsigned ring_off = (unsigned)(s & (PS_RING - 1)) * xslot_bytes, rearm_off = (unsigned)((s + 2) & (PS_RING - 1)) * xslot_bytes;
-            if (lane < 16) {
+            {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const int q = lane >> 4;
+                constexpr int NG = (NT + 3) / 4;
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) {
-                    unsigned lo = pack_bf16x2(acc[nn][0], acc[nn][1]);              // one v_cvt_pk_bf16_f32 per dword
-                    unsigned hi = pack_bf16x2(acc[nn][2], acc[nn][3]);
+                for (int g4 = 0; g4 < NG; ++g4) {
+                    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (g4 * 4 + j < NT) {
+                            const unsigned l = pack_bf16x2(acc[g4 * 4 + j][0], acc[g4 * 4 + j][1]), h2 = pack_bf16x2(acc[g4 * 4 + j][2], acc[g4 * 4 + j][3]);
+                            lo = q == j ? l : lo;
+                            hi = q == j ? h2 : hi;
+                        }
+                    }
                     if (lo == 0xffffffffu) lo = 0x7fc07fc0u;            // (NaN pairs of a diverged run) never the sentinel
                     if (hi == 0xffffffffu) hi = 0x7fc07fc0u;
-                    const unsigned o = soff + (unsigned)nn * 128u + ring_off;
-                    if (local) {
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, xrsrc, o, 0, 0);
-                    } else {
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), lo, ASR_RLX_AGENT);
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), hi, ASR_RLX_AGENT);
-                    }
-                }
-            }
-            // re-arm the slot of step s - 2 (every consumer finished with it before it could produce the P_{s-1} this workgroup
-            // has just consumed); the slots of steps s + 1, s + 3 are armed (launch fill / earlier re-arm)
-            if (lane < 16 && s >= 2) {
-#pragma unroll
-                for (int nn = 0; nn < NT; ++nn) {
-                    const unsigned o = soff + (unsigned)nn * 128u + rearm_off;
-                    if (local) {
-                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){0xffffffffu, 0xffffffffu}, xrsrc, o, 0, 0);
-                    } else {
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o), 0xffffffffu, ASR_RLX_AGENT);
-                        __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + 4u), 0xffffffffu, ASR_RLX_AGENT);
+                    // the slot of step s - 2 is re-armed behind it (every consumer finished with it before it could produce the P_{s-1} this
+                    // workgroup has just consumed); the slots of steps s + 1, s + 3 are armed (launch fill / earlier re-arm)
+                    const bool on = g4 * 4 + q < NT;
+                    const unsigned o = soff + (unsigned)(g4 * 4 + q) * 128u;
+                    if (on) {
+                        if (local) {
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, xrsrc, o + ring_off, 0, 0);
+                            if (s >= 2) __builtin_amdgcn_raw_buffer_store_b64((u32x2){0xffffffffu, 0xffffffffu}, xrsrc, o + rearm_off, 0, 0);
+                        } else {
+                            __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + ring_off), lo, ASR_RLX_AGENT);
+                            __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + ring_off + 4u), hi, ASR_RLX_AGENT);
+                            if (s >= 2) {
+                                __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + rearm_off), 0xffffffffu, ASR_RLX_AGENT);
+                                __hip_atomic_store(reinterpret_cast<unsigned*>(xbase + o + rearm_off + 4u), 0xffffffffu, ASR_RLX_AGENT);
+                            }
+                        }
                     }
                 }
             }
@@ -1134,7 +1167,6 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     }
     if (is_loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ASR_RAW_BARRIER();
-    if (is_storer && !*s_abort) store_step(T - 1);
     if (act && db_ih && db_hh) {
         float* bi = db_ih + (size_t)d * 3 * H + j0 + u0;
         float* bh2 = db_hh + (size_t)d * 3 * H + j0 + u0;
