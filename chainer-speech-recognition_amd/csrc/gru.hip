@@ -879,12 +879,16 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     const float* lgp = gates + (((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * ndir + d) * 4 * H + j0 + (lane & 7) * 4 +
                        (size_t)(lane >> 5) * H;
     // G16 (blocked layout [T*B][ndir][H / 16][4 gates][16 units] half): the 32 units of this workgroup are two adjacent blocks = 256
-    // contiguous bytes per row: lane = (row lane / 16, 16-B piece lane % 16)
-    const int lrow16 = lane >> 4;
+    // contiguous bytes per row: lane = (16-B piece lane / 4, row lane % 4), so that the LDS image (lane-linear) is [piece][row]: the four
+    // rows of a piece are 16 B apart and a gate wave -- whose lanes span all four rows since the DPP reduction -- reads 64 different
+    // halves out of 128 contiguous bytes per gate (in the [row][piece] image rows were 256 B apart: a 4-way bank conflict per read)
+    const int lrow16 = lane & 3;
     const uint16_t* lgp16 = reinterpret_cast<const uint16_t*>(gates) + ((((size_t)tfirst * B + b0 + (lrow16 < Bl ? lrow16 : 0)) * ndir + d) * (H >> 4) +
-                                                                        (j0 >> 4)) * 64 + (lane & 15) * 8;
-    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (lrow < Bl ? lrow : 0)) * (long long)hs +
-                       (size_t)d * H + j0 + (lane & 7) * 4;
+                                                                        (j0 >> 4)) * 64 + (lane >> 2) * 8;
+    // h_{t-1}: likewise [piece of 4 units][row] float32
+    const int hrow = lane & 3;
+    const float* lhp = hseq + ((long long)(d == 0 ? tfirst - 1 : tfirst + 1) * B + b0 + (hrow < Bl ? hrow : 0)) * (long long)hs +
+                       (size_t)d * H + j0 + ((lane & 31) >> 2) * 4;
     const uint16_t* lyp = dy + ((size_t)tfirst * B + b0 + (lane >= 32 && lane < 48 && lyrow < Bl ? lyrow : 0)) * H + j0 + (lane & 3) * 8;
     const char* l2p = lane < 32 ? reinterpret_cast<const char*>(lhp) : reinterpret_cast<const char*>(lyp);
     const long long lgs = tstep * (long long)B * ndir * 4 * H;
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)lgp, (lds_ptr_t)sl, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(lgp + 2 * (size_t)H), (lds_ptr_t)(sl + 1024), 16, 0, 0);
             }
-            if (lane < 32 ? (lrow < Bl && sq < T - 1) : (lane < 48 && lyrow < Bl))
+            if (lane < 32 ? (hrow < Bl && sq < T - 1) : (lane < 48 && lyrow < Bl))
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)l2p, (lds_ptr_t)(sl + 2048), 16, 0, 0);
         }
         lgp += lgs; lgp16 += lgs; l2p += l2s;
@@ -993,13 +997,13 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
             const char* sl = opring + (s % BIO_GD) * BIO_SLOT;
             const float* of = reinterpret_cast<const float*>(sl) + b * 32 + u0;
             if (G16) {
-                // slot image [4 rows][2 blocks][4 gates][16 units] half
-                const _Float16* oh = reinterpret_cast<const _Float16*>(sl) + b * 128 + (u0 >> 4) * 64 + (u0 & 15);
-                r = (float)oh[0]; z = (float)oh[16]; n = (float)oh[32]; qq = (float)oh[48];
+                // slot image [16 pieces: (block, gate, unit half)][4 rows][8 units] half
+                const _Float16* oh = reinterpret_cast<const _Float16*>(sl) + ((((u0 >> 4) * 8 + ((u0 & 15) >> 3)) * 4 + b) << 3) + (u0 & 7);
+                r = (float)oh[0]; z = (float)oh[64]; n = (float)oh[128]; qq = (float)oh[192];
             } else {
                 r = of[0]; z = of[128]; n = of[256]; qq = of[384];
             }
-            hp = s < T - 1 ? of[512] : 0.f;
+            hp = s < T - 1 ? reinterpret_cast<const float*>(sl)[512 + (((u0 >> 2) * 4 + b) << 2) + (u0 & 3)] : 0.f;
             dyy = bf16_to_f32(reinterpret_cast<const uint16_t*>(sl + 5 * 512)[b * 32 + u0]);
             dyc = dyy + carry;                          // dh = dy + z dh' + (the exchanged sum)
             f_an = (1.0f - z) * (1.0f - n * n);         // dan = dh (1 - z)(1 - n^2)
