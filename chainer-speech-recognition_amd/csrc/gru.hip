@@ -1232,7 +1232,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
     // three, one and none): the hand-off loads of the compute waves return behind it.
     const float* gi = reinterpret_cast<const float*>(gi_);
     const uint16_t* gi16 = reinterpret_cast<const uint16_t*>(gi_);
-    const int b_ = ((tid - 128) >> 4) & 7, u_ = tid & 15;          // the gate thread's (row, unit)
+    // the gate thread's (row, unit): lane l of gate wave g (= 0, 1) is row 4 g + (l / 2) % 4, unit 2 (l / 8) + l % 2 -- units u, u + 1 stay
+    // lanes l, l ^ 1 (the payload pair), and the partial-sum reads of a 32-lane group (dword 4 u + row % 4) cover 32 consecutive dwords:
+    // with (row l / 16, unit l % 16) units u and u + 8 met in one bank, a 2-way conflict on each of the step's twelve ds_read_b32
+    const int b_ = (((tid - 128) >> 6) << 2) | (((tid - 128) >> 1) & 3), u_ = ((((tid - 128) >> 3) & 7) << 1) | (tid & 1);
     // GI16: lane = (gate lane / 16, row (lane % 16) / 2, units 8 (lane % 2) ..), lanes 0..47
     const int lrow = GI16 ? (lane & 15) >> 1 : (lane & 31) >> 2;
     const float* lgp = gi + ((size_t)tfirst * B + b0 + (lrow < Bl ? lrow : 0)) * (3 * hs) + (size_t)d * 3 * H + j0 + (lane & 3) * 4 +
@@ -1283,12 +1286,13 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
                 } else if (pp < 96) {
                     // blocked layout [T*B][ndir][H / 16][4 gates][16 units]: this workgroup's r | z | n | q of a row are ONE 128-B line
                     // (in the [4][H] layout they were four 32-B pieces of four lines, each completed by three other workgroups).
-                    // The gate waves leave them in LDS as that line already (put_state: IEEE half, [8 rows][4 gates][16 units]): a
+                    // The gate waves leave them in LDS as that line already (put_state: IEEE half, [8 rows][4 gates][16 units], row pitch 144 B): a
                     // piece is one conflict-free 16-B read -- the float32 [gate][row][unit] image cost two 4-way conflicted reads and
                     // four conversions per piece on this wave.
                     const int q = pp - 32, row = q >> 3;
                     if (row < Bl) {
-                        const f32x4_asm v = lds_read16_raw(reinterpret_cast<const char*>(src + 128) + q * 16);
+                        // (rows of the staging image are 144 B apart: see put_state)
+                        const f32x4_asm v = lds_read16_raw(reinterpret_cast<const char*>(src + 128) + row * 144 + (q & 7) * 16);
                         *reinterpret_cast<f32x4_asm*>(gates16 + ((((size_t)tq * B + b0 + row) * ndir + d) * (H >> 4) + (j0 >> 4)) * 64 + (q & 7) * 8) = v;
                     }
                 }
@@ -1325,7 +1329,10 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         float* od = oring + (size_t)parity * 5 * 8 * 16;
         od[bb_ * 16 + uu_] = h;
         if (G16) {
-            _Float16* oh = reinterpret_cast<_Float16*>(od + 128) + bb_ * 64 + uu_;
+            // the memory line [row][4 gates][16 units] with a row pitch of 144 instead of 128 B: the 4 rows x 8 units a 32-lane group stores
+            // per gate then hit 16 different banks (at 128 B all four rows met in one bank: 4-way on each of the four stores); the storer's
+            // pieces stay 16 contiguous bytes
+            _Float16* oh = reinterpret_cast<_Float16*>(od + 128) + bb_ * 72 + uu_;
             oh[0] = (_Float16)r; oh[16] = (_Float16)z; oh[32] = (_Float16)n; oh[48] = (_Float16)q;
         } else {
             float* og = od + 128 + bb_ * 16 + uu_;
@@ -1350,7 +1357,7 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
         }
     }
     // gate phase on waves 2 and 3 (no I/O wave on their SIMDs): thread (row (tid - 128) / 16, unit tid % 16)
-    const int b = ((tid - 128) >> 4) & 7, u = tid & 15;
+    const int b = b_ & 7, u = u_;
     const bool act = tid >= 128 && tid < 256 && b < Bl;
     constexpr int kPoller = 128;
     float bh[3] = {0.f, 0.f, 0.f};
