@@ -2292,8 +2292,10 @@ static int fwd_poll_delay(int H, bool ring) {
 // kernel (the default at 16 < B <= 32, and of every slab of a larger batch)
 static int fwd_family(int T, int B, int H, int ndir, int mode, const void* sync_ws) {
     if (!can_persist(T, B, H, ndir, mode, sync_ws)) return 0;
-    const bool wide_half = (mode == 0 || mode == 8) && B <= 16 && B > 4;
-    if ((mode == 2 || wide_half) && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) return 1;
+    // (until round 4 the wide form also served 4 < B <= 16 in the default modes -- "a 4-row recurrence fetches half the hand-off bytes" --
+    // but the 8-row kernel has since gained the ring hand-off, bf16 input projections and half gates: T=1000, H=512, us per step,
+    // wide / 8-row: B=16 1.64 / 1.18, B=12 1.58 / 1.17, B=8 1.46 / 1.16, B=5 1.42 / 1.16.  The wide form is the placement-free mode 2's.)
+    if (mode == 2 && H >= 128 && ndir * ((B + 3) / 4) <= 16 && (H / 32 + 7) / 8 <= 4) return 1;
     return 2;
 }
 
@@ -2417,7 +2419,7 @@ extern "C" int asr_gru_fwd(void* stream, void* gi_any, int gi_bf16, const void* 
     const bool persist = can_persist(T, B, H, ndir, mode, sync_ws);
     if (mode >= 2 && !persist) return ASR_ERR_UNSUPPORTED;
     const int family = fwd_family(T, B, H, ndir, mode, sync_ws);
-    // wide form also for 4 < B <= 16 in the default modes (the step of a 4-row recurrence fetches half the hand-off bytes)
+    // (the wide form serves the placement-free mode 2; see fwd_family)
     if (slab) {         // consecutive slabs of <= 32 rows through the default kernel (see slab_rows); the launches share sync_ws in stream order
         for (int boff = 0; boff < B; boff += slab) {
             const int rc2 = fwd_io_launch(st, gi_any, gi_bf16, whh_bf16, bhh, hseq, hseq_bf16, gates, sync_ws, T, B, H, ndir, mode, gates_f16, boff,
