@@ -818,13 +818,16 @@ __global__ __launch_bounds__(640, 3) void bwd_wide_kernel(const uint16_t* __rest
 // moves to the producer: a workgroup multiplies the 96 gate gradients it has just computed (its 32 units, gates r, z, q) by
 // its 96 ROWS of W_hh and publishes the H partial sums  P[p][h'][row] = sum_{g in p's 96} dgh[row][g] W_hh[g][h']  in bf16
 // (4 rows x H x 2 B = 4 KB written); a consumer fetches the 32 columns it owns from all H / 32 producers (256 B each: 4 KB
-// at H = 512) and adds them up (float32).  Same number of MFMAs, a third of the hand-off bytes, one more workgroup barrier:
-//   gate waves (2, 3):  poll-load P_{s-1} (sentinel 0xffff, as in bwd_wide_kernel) -> float32 in LDS -> barrier R ->
-//                       16-way sum -> gate math -> (ar, az, aq) as the MFMA A image in LDS + (ar, az, an, aq) for the storer
-//   all 8 compute waves: barrier A -> 3 K steps (gates) x H/128 column tiles of MFMA -> bf16 -> P_s (plain stores when the
-//                       recurrence sits on one XCD, write-through otherwise; polled with sc1 loads either way)
-//   loader / storer waves as in bwd_wide_kernel; the storer now also writes dgh (no longer the exchange medium, so it needs no
-//   sentinel fill: 196 MB of memset per launch less).
+// at H = 512) and adds them up (float32).  Same number of MFMAs, a third of the hand-off bytes:
+//   gate waves (2, 3):  poll-load P_{s-1} (sentinel 0xffff, as in bwd_wide_kernel): lane k of an eight-lane group the pieces of producers
+//                       k, k + 8 for the group's unit pair -> lane-local sums -> reduce-scatter over the group with three DPP exchanges
+//                       (round 4; until then: float32 in LDS, a barrier, a 16-way sum) -> gate math -> (ar, az, aq) as the MFMA A
+//                       image in LDS + (ar, az, an, aq) for the storer
+//   all 8 compute waves: barrier A (the step's only one) -> 3 K steps (gates) x H/128 column tiles of MFMA, the four live rows read
+//                       into every 4-row group of the tile -> bf16 -> P_s and the re-arm as ONE 64-lane store each (plain stores when
+//                       the recurrence sits on one XCD, write-through otherwise; polled with sc1 loads either way)
+//   loader / storer waves as in bwd_wide_kernel, cued by an LDS word the gate wave raises when its poll has succeeded; the storer
+//   also writes dgh (no longer the exchange medium, so it needs no sentinel fill: 196 MB of memset per launch less).
 // The exchange buffer is a ring of four steps (a producer re-arms the slot of step s - 2 with the sentinel once its loads of
 // step s - 1 have succeeded: every consumer has then finished with step s - 2), 4 x H/32 x H x 8 B per recurrence inside sync_ws.
 constexpr int PS_RING = 4;
@@ -841,12 +844,9 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
                                                         int forge, int boff, int Bn) {
     // (boff, Bn): the slab of batch rows this launch serves (see fwd_persistent_io_kernel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [8 lane groups][4 rows][2][16] f32, group pitch 144 floats: the eight store instructions of a gate wave (four groups of 16
-    // lanes each) then meet a 2-way bank conflict, which a ds_write_b32 absorbs, instead of a 4-way one (pitch 128)
     constexpr int RED_PITCH = 144;          // (the first 8 x 144 floats held the partial sums of the eight lane groups until round 4)
-    // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB: rows 4 .. 15 exist and stay zero, so that every lane reads its
-    // fragment unconditionally -- three ds_reads back to back and ONE wait (with 4-row images the reads sat behind exec-mask
-    // branches, each followed by its own wait: two LDS round trips more on the chain of every compute wave)
+    // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB, of which rows 0 .. 3 are written: every lane reads row lane % 4 (an LDS
+    // broadcast), unconditionally -- three ds_reads back to back and ONE wait
     // The fragment read of lane (row r = lane % 16, chunk q = lane / 16) takes chunk q ^ g4(r) of its row, g4 = {0, 2, 3, 1}[r / 4]: the
     // sixteen lanes of a ds_read_b128 group then cover all 64 banks (rows are 64 B apart: unswizzled, rows r and r + 4 k met in the same
     // banks).  g4 = 0 on the live rows 0 .. 3, so the writers store unswizzled, and the rows beyond are zero in every chunk.
