@@ -847,9 +847,7 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
     constexpr int RED_PITCH = 144;          // (the first 8 x 144 floats held the partial sums of the eight lane groups until round 4)
     // MFMA A image [3 gates][16 rows][32 units] bf16 = 3 KB, of which rows 0 .. 3 are written: every lane reads row lane % 4 (an LDS
     // broadcast), unconditionally -- three ds_reads back to back and ONE wait
-    // The fragment read of lane (row r = lane % 16, chunk q = lane / 16) takes chunk q ^ g4(r) of its row, g4 = {0, 2, 3, 1}[r / 4]: the
-    // sixteen lanes of a ds_read_b128 group then cover all 64 banks (rows are 64 B apart: unswizzled, rows r and r + 4 k met in the same
-    // banks).  g4 = 0 on the live rows 0 .. 3, so the writers store unswizzled, and the rows beyond are zero in every chunk.
+    // (chunk lane / 16 of its row; rows are 64 B apart, so the four rows x four chunks of a ds_read_b128 lane group cover all 64 banks)
     uint16_t* aimg = reinterpret_cast<uint16_t*>(smem + 8 * RED_PITCH * 4);
     char* opring = smem + 8 * RED_PITCH * 4 + 3072;                                     // [BIO_GD][BIO_SLOT] (as bwd_wide_kernel)
     unsigned* oring = reinterpret_cast<unsigned*>(opring + BIO_GD * BIO_SLOT);         // [2][4: ar az an aq][4 rows][16 pairs]
