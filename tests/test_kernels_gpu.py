@@ -710,6 +710,48 @@ def test_non_finite_step_is_skipped(device):
         assert torch.equal(p, p0) and bool((vel == 0).all())
 
 
+def test_step_control_with_a_loss_scale_on_the_device(device):
+    """asr_step_control_scaled (chainer.Optimizer.loss_scaling): the gradient factor carries 1 / S, a non-finite norm that no recurrence
+    explains halves S and drops the step, `interval` applied steps in a row double it, a static scale (interval 0) never moves, a step
+    dropped because a recurrence gave up leaves S alone -- all on the device, read back here"""
+    from asr import _ops
+    n = 1000
+    g = torch.Generator().manual_seed(3)
+    grad = torch.randn(n, generator=g).to(device)
+    partials = torch.empty(_ops.sqnorm_partials_count(n), device=device)
+    applied = torch.zeros(1, dtype=torch.int32, device=device)
+    ctl = torch.zeros(8, device=device)
+    no_abort = torch.zeros(1, dtype=torch.int32, device=device)
+    ls = torch.tensor([1024.0, 0.0, 3.0, 0.0], device=device)          # S, applied since the last change, interval, overflows
+    norm = float(grad.norm())
+
+    def step(gr, abort=no_abort, scale=ls):
+        _ops.step_control(gr, partials, 1.0, 0.5, 1e-3, 0.9, 0.999, applied, ctl, abort, -1, scale)
+        return ctl.cpu().tolist(), (None if scale is None else scale.cpu().tolist()), int(applied.cpu()[0])
+
+    c, s, a = step(grad * 1024.0)                                       # a scaled gradient: factor = 0.5 / 1024, clipped by the UNSCALED norm
+    assert c[0] == 0.0 and a == 1 and s == [1024.0, 1.0, 3.0, 0.0]
+    want = 0.5 / 1024.0 * min(1.0, 1.0 / (norm * 0.5))
+    assert abs(c[1] - want) < 1e-6 * want, (c[1], want)
+    c, s, a = step(grad * 1024.0); c, s, a = step(grad * 1024.0)        # three applied steps in a row: S doubles
+    assert a == 3 and s == [2048.0, 0.0, 3.0, 0.0]
+    bad = grad.clone(); bad[5] = float("inf")
+    c, s, a = step(bad)                                                 # overflow: dropped, S halved, counted
+    assert c[0] == 1.0 and c[5] == 0.0 and a == 3 and s == [1024.0, 0.0, 3.0, 1.0]
+    raised = torch.ones(1, dtype=torch.int32, device=device)
+    c, s, a = step(grad, abort=raised)                                  # a given-up recurrence: dropped, S untouched
+    assert c[0] == 1.0 and c[5] == 1.0 and a == 3 and s == [1024.0, 0.0, 3.0, 1.0]
+    static = torch.tensor([256.0, 0.0, 0.0, 0.0], device=device)
+    for _ in range(5):
+        c, s, a = step(grad * 256.0, scale=static)
+    assert s[0] == 256.0 and a == 8
+    tiny = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device)            # S may go below 1 (gradients beyond the half range WITHOUT a scale)
+    c, s, a = step(bad, scale=tiny)
+    assert s[0] == 0.5 and s[3] == 1.0
+    c, s, a = step(grad, scale=None)                                    # no scale: asr_step_control
+    assert abs(c[1] - 0.5 * min(1.0, 1.0 / (norm * 0.5))) < 1e-6 and a == 9
+
+
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
                                                           (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
                                                           # > 128 output (or, for backward-data, input) channels: 256 x 256 tiles
