@@ -19,7 +19,8 @@ for _ in range(2):
 torch.cuda.synchronize()
 s = _ops.LAST_SYNC[0].cpu().view(torch.uint8)
 st = s[4096:4096 + 2 * 10 * 8 * 8].view(torch.int64).reshape(2, 10, 8)
-names = ["top..lds-in", "poll", "sum->R", "barrier R", "R..A work", "barrier A", "mfma+store+fetch", "attempts"]
+# (round 4: the gate waves reduce with DPP moves, barrier R is gone -- phase 3 is empty; I/O waves: phase 6 includes their wait for the cue)
+names = ["top..lds-in", "poll", "lane sums + DPP reduce", "(was barrier R)", "gate math + A image", "barrier A", "mfma+store+pause+fetch", "attempts"]
 for wg in (0, 1):
     for w in (0, 2, 3, 8, 9):
         print("wg", wg, "wave", w, " ".join("%s=%.3f" % (n, st[wg, w, i].item() / 100.0 / T) for i, n in enumerate(names[:7])),
