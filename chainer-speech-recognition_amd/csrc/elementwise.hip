@@ -494,7 +494,7 @@ __global__ void conv_weight_grad_unpack_kernel(const float* __restrict__ scratch
         const long long o = (long long)co * Kp + (kh * KW + kw) * Cs + ci;
         float v = scratch[o];
         for (int c = 1; c < copies; ++c) v += scratch[o + (long long)c * Co * Kp];           // (per-XCD copies: asr_conv_tn_acc_copies)
-        atomicAdd(gW + i, v);      // (two half batches may add at once)
+        gW[i] += v;                // (one writer per element: a float atomic here ran at the memory side, 45 us for 123 k elements)
     }
 }
 
