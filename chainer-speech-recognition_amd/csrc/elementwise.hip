@@ -973,9 +973,11 @@ extern "C" int asr_maxout2_pool_bwd_db(void* stream, const void* x, const void* 
     if (db && (kThreads != 256 || (256 % (C >> 3)) != 0)) return ASR_ERR_UNSUPPORTED;
     const int Hout = (Hin + k - 1) / k;
     int grid = grid_for(R * Hout * (C >> 3));
-    // one atomic per channel and workgroup, ~12 ns each on one address: 2048 workgroups (eight per CU, all resident) keep that tail at
-    // ~25 us; 768 starved the streaming part (three workgroups per CU: 289 us for the 311 MB of the first block instead of 166)
-    if (db && grid > 2048) grid = 2048;
+    // one float atomic per channel and workgroup, all of them on the same 2 C addresses at the end of the launch: that tail, not the
+    // streaming, sets the size of the grid.  T=1000, B=32, first block (H=38, 311 MB in and out) / second block (H=11) of the BASELINE model,
+    // us with the bias sums (without: 127 / 32): 4096 workgroups 248 / 213, 2048 190 / 121, 1024 166 / 78, 768 154 / 66, 512 157 / 58,
+    // 384 190 / 58, 256 245 / 65 (round 3 measured 768 as starving the streaming part, with the 16-way conflicted reduction image)
+    if (db && grid > 512) grid = 512;
     hipLaunchKernelGGL(maxout2_pool_bwd_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)x, (const uint16_t*)dy, (uint16_t*)dx, db, R, Hin, Hout, C, k);
     ASR_LAUNCH_CHECK();
