@@ -545,6 +545,7 @@ def settled_steps(step, steps, max_warmup=12):
         step()
         warm += 1
         quiet = quiet + 1 if allocs() == a0 else 0
+    quiesce_host_gc()
     torch.cuda.synchronize()
     a0 = allocs()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -705,11 +706,23 @@ def spawn_ranks(args):
 REGION = {"device_allocations": None}       # hipMalloc calls of the caching allocator inside the last timed region (healthy: 0)
 
 
+def quiesce_host_gc():
+    """A full (generation-2) collection of this process takes ~35 ms (170 k tracked objects: tools/gc_probe.py) and CPython starts one
+    when enough long-lived objects have piled up -- building a model does that.  Landing in the first steps of a timed region, where the
+    host is not yet ahead of the device, it showed as one 50 - 90 ms step in a 100-step trace and in two bench lines of round 4.  Run it
+    now, outside the region, and move the survivors to the permanent generation so that later collections only look at what the steps
+    create (host hygiene of the measurement; the collector stays enabled)."""
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def timed_region(step, steps, warmup, comm, sync, dev=None):
     """the contract's timed region: W untimed steps, barrier + synchronize, K steps, synchronize + barrier, MAX over ranks"""
     import torch.distributed as dist
     for _ in range(warmup):
         step()
+    quiesce_host_gc()
     sync()
     if comm is not None:
         comm.barrier()
