@@ -67,6 +67,8 @@ SIGNATURES = {
     "asr_edit_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "asr_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 4),
     "asr_conv_nt": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
+    "asr_conv_direct_ok": (c_int, [c_int] * 11),
+    "asr_conv_direct_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
     "asr_pack_input_pad": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 5 + [c_void_p]),
     "asr_conv_weight_pack_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),

@@ -1727,6 +1727,9 @@ extern "C" int asr_conv_tn_acc(void* stream_, const void* g, int ldg, const void
     return asr_conv_tn_acc_copies(stream_, g, ldg, x, C, ldc, 1, Co, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, Tr, Hr);
 }
 
+extern "C" int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW, int Tr, int Hr, int N, int K, int out_bf16);
+extern "C" int asr_conv_direct_nt(void* stream, const void* x, const void* W, int ldw, void* out, const float* bias, int Ts, int B, int Hs,
+                                  int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
 extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias,
                            int Ts, int B, int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
     if (!x || !W || !out || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0 || N <= 0 ||
@@ -1735,6 +1738,16 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     const long long M = (long long)Tr * B * Hr;
     const int K = ldw;                  // row pitch of W = K of the GEMM: KH*KW*Cs, or more with empty (zero) taps behind
     if (ldw < KH * KW * Cs) return ASR_ERR_BAD_ARG;
+    // the kernel with the activation block resident in LDS (conv_direct.hip) where two of its workgroups fit a CU (<= 128 channels):
+    // T=1000, B=32, us, implicit GEMM / direct: 64 -> 64 channels 111 / 68, 128 -> 64 (a backward-data) 206 / 178, 128 -> 256 595 / 499,
+    // 128 -> 512 1090 / 953, 64 -> 128 138 / 135; with 256 input channels (one workgroup per CU) it loses, 996 / 1472
+    {
+        static int direct = -1;
+        if (direct < 0) direct = debug_flag("conv_direct", 1);
+        if (direct && out_bf16 && Cs <= 128 && asr_conv_direct_ok(Ts, B, Hs, Cs, KH, KW, Tr, Hr, N, ldw, 1) &&
+            !((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)out)) & 15) && !(bias && (((uintptr_t)bias) & 15)))
+            return asr_conv_direct_nt(stream_, x, W, ldw, out, bias, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, sgn, Tr, Hr, N);
+    }
     if ((Cs & 7) || (K % B2K) || (K % Cs) || M > 0x7fffffffLL || ((((uintptr_t)x) | ((uintptr_t)W)) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
     static bool attr = false;

@@ -179,6 +179,13 @@ int asr_conv_weight_pack(void* stream, const float* W, void* dst_bf16, int Co, i
  * asr_conv_weight_pack_bwd: dst[ci][(kh*KW + kw)*Co + co] = W[co][ci][kh][kw] as bf16. */
 int asr_conv_nt(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B,
                 int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+/* The same product with the activation block of a tile resident in LDS (csrc/conv_direct.hip): one workgroup = one utterance x 256 / Hr
+ * time steps x all Hr heights x 64 or 128 output columns; the (Tt + KW - 1) x (Hr + KH - 1) x Cs activations it can touch are loaded
+ * once instead of once per tap.  bf16 output, Cs in {32, 64, 128, 256}, ldw % 32 == 0; asr_conv_direct_ok says whether a shape is
+ * served (asr_conv_nt asks and dispatches by itself; ASR_DEBUG conv_direct=0 keeps the implicit-GEMM kernels). */
+int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW, int Tr, int Hr, int N, int K, int out_bf16);
+int asr_conv_direct_nt(void* stream, const void* x, const void* W, int ldw, void* out, const float* bias, int Ts, int B, int Hs, int Cs,
+                       int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
 /* any strided (T, B, H, C) f32 / bf16 tensor -> dense (T, B, H, Cpad) bf16, channels C..Cpad-1 zero: brings the loader's
  * (B, 3, 40, T) float32 minibatch into the layout of asr_conv_nt (first layer: C = 3 -> Cpad = 8) */
 int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,

@@ -801,6 +801,49 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     assert _rel(gW.cpu(), gW_ref.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
+                                                          (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
+                                                          (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),
+                                                          (12, 2, 6, 256, 64, 3, 5, 1, True), (120, 5, 38, 32, 64, 3, 5, 0, True),
+                                                          (41, 3, 11, 128, 64, 3, 5, 0, True), (77, 2, 1, 64, 72, 1, 1, 0, True)])
+def test_direct_conv_equals_the_implicit_gemm_conv(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
+    """asr_conv_direct_nt (activation block resident in LDS, csrc/conv_direct.hip) against the implicit-GEMM kernels of asr_conv_nt on the
+    same bf16 operands, forward (with bias) and backward-data: the same products summed in the same K order by the same MFMA -- equal up
+    to the bf16 rounding of the output (the float32 sums can differ in the last bit only where the MFMA's internal order does not)"""
+    from asr import _lib, _ops
+    rs = np.random.RandomState(T + Ci + Co)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(BF16)
+    W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.1).astype(np.float32)).to(device)
+    bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
+    K = KH * KW * Ci
+    w16 = _ops.conv_weight_pack(W, Kp=(K + 31) // 32 * 32)
+    assert _lib.lib().asr_conv_direct_ok(T, B, Hin, Ci, KH, KW, Tout, Hout, Co, w16.shape[1], 1) == 1
+    import os
+    ref = _conv_nt_implicit(x, w16, bias, KH, KW, ph, pt, +1, Tout, Hout)
+    got = _ops.conv_direct_nt(x, w16, bias, KH, KW, ph, pt, +1, Tout, Hout)
+    assert got.shape == ref.shape and _rel(got.float().cpu(), ref.float().cpu()) < 2e-3
+    assert float((got.float() - ref.float()).abs().max()) <= 2.0 ** -6 * float(ref.float().abs().max())        # at most one bf16 ulp anywhere
+    if Co in (32, 64, 128, 256):        # backward-data: the roles of the channels swap
+        gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(BF16)
+        wb = _ops.conv_weight_pack_bwd(W)
+        if _lib.lib().asr_conv_direct_ok(Tout, B, Hout, Co, KH, KW, T, Hin, Ci, wb.shape[1], 1) != 1:
+            assert Co == 256 and Hout >= 13         # (the block of 256 channels x 15 heights x 23 time steps does not fit the LDS)
+            return
+        ref_dx = _conv_nt_implicit(gy, wb, None, KH, KW, ph, pt, -1, T, Hin)
+        got_dx = _ops.conv_direct_nt(gy, wb, None, KH, KW, ph, pt, -1, T, Hin)
+        assert _rel(got_dx.float().cpu(), ref_dx.float().cpu()) < 2e-3
+        assert float((got_dx.float() - ref_dx.float()).abs().max()) <= 2.0 ** -6 * float(ref_dx.float().abs().max())
+
+
+def _conv_nt_implicit(x, W2, bias, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
+    """asr_conv_nt with the direct kernel switched off: the float32-output form never dispatches to it"""
+    from asr import _ops
+    return _ops.conv_nt(x, W2, bias, torch.float32, KH, KW, pad_h, pad_t, sgn, Tr, Hr).to(BF16)
+
+
 @pytest.mark.parametrize("B,C,H,T", [(3, 3, 40, 130), (2, 1, 13, 64), (2, 8, 9, 65), (32, 3, 40, 1000)])
 def test_pack_input_pad_layouts(device, B, C, H, T):
     """(T, B, H, 8) bf16 rows with zero channels behind C, from the loader's (B, C, H, T) float32 (time innermost: the LDS-tile kernel)
