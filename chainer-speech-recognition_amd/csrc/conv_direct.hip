@@ -44,11 +44,13 @@ constexpr int NSTG = 3;         // LDS stages of the weight ring (three more ste
 // MI = 2 -> tiles of 128 rows, two workgroups per CU (a workgroup alone on its CU -- MI = 4, 256 rows, ~100 KB of LDS -- has nothing to
 // cover its LDS latency and barrier with: 880 cycles per K step of 256 MFMA cycles).
 // LOG_NCH: log2(Cs / 8), the 16-B chunks of a position (Cs = 32, 64, 128, 256).
-template <int NJ, int LOG_NCH, int MI>
+// KS: 32-wide K steps per barrier (2 where the tile is 64 columns wide: 8 MFMAs per wave between two barriers were too few).
+template <int NJ, int LOG_NCH, int MI, int KS>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ out, const float* __restrict__ bias, Desc d, unsigned x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NCH = 1 << LOG_NCH, TNW = 16 * NJ, B_STAGE = TNW * 64, BP = NJ / 4;
+    constexpr int NCH = 1 << LOG_NCH, TNW = 16 * NJ, B_HALF = TNW * 64, B_STAGE = KS * B_HALF, BP = NJ / 4;
+    constexpr int R = KS == 2 ? 4 : 6;       // register sets of weight tiles in flight
     constexpr int POS_BYTES = NCH * 16;
     // 16-B chunk c of position p lives at slot c ^ swz(p): sixteen consecutive positions x one chunk index then cover all sixteen 16-B
     // bank groups of the LDS (a position is POS_BYTES = 64 .. 512 B: unswizzled, positions 256 / POS_BYTES apart met in the same banks)
@@ -76,25 +78,25 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
         const int col = tn * TNW + NJ * (rho & 15) + (rho >> 4);
         ob[i] = __umul24((unsigned)min(col, d.N - 1), (unsigned)(d.K * 2)) + lchunk;
     }
-    const int nk = d.K >> 5;
+    const int nk = (d.K >> 5) / KS;          // (K steps of 32 KS columns: the host chooses KS = 2 only where K / 32 is even)
     // weight tiles in flight (register sets): every workgroup of an XCD asks the same few KB of its L2 for the same tile at the same time
-    // and the answer takes ~1800 cycles, five K steps of this workgroup (with two steps of distance a K step took 880 cycles, not 300)
-    u32x4 breg[6][BP];
-    auto load_b = [&](u32x4 (&regs)[BP], int ks) {
+    // and the answer takes ~1800 cycles, several K steps of this workgroup (with two steps of distance a K step took 880 cycles, not 300)
+    u32x4 breg[R][KS * BP];
+    auto load_b = [&](u32x4 (&regs)[KS * BP], int ks) {
 #pragma unroll
-        for (int i = 0; i < BP; ++i)
-            regs[i] = ks < nk ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ob[i], ks * 64, 0) : (u32x4){0u, 0u, 0u, 0u};
-    };
-    auto write_b = [&](const u32x4 (&regs)[BP], int stage) {
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-        for (int i = 0; i < BP; ++i) *reinterpret_cast<u32x4*>(Bs + stage * B_STAGE + (i * 256 + tid) * 16) = regs[i];
+            for (int i = 0; i < BP; ++i)
+                regs[kk * BP + i] = ks < nk ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ob[i], (ks * KS + kk) * 64, 0) : (u32x4){0u, 0u, 0u, 0u};
     };
-    load_b(breg[0], 0);
-    load_b(breg[1], 1);
-    load_b(breg[2], 2);
-    load_b(breg[3], 3);
-    load_b(breg[4], 4);
-    load_b(breg[5], 5);
+    auto write_b = [&](const u32x4 (&regs)[KS * BP], int stage) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int i = 0; i < BP; ++i) *reinterpret_cast<u32x4*>(Bs + stage * B_STAGE + kk * B_HALF + (i * 256 + tid) * 16) = regs[kk * BP + i];
+    };
+#pragma unroll
+    for (int j = 0; j < R; ++j) load_b(breg[j], j);
     // ---- the activation block: chunk index idx = p NCH + slot lives at LDS byte idx 16; UF loads in flight per thread (with four, the
     // 88 KB block of a 128-channel tile took five dependent round trips to memory: 20 of a tile's 31 us)
     {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
     }
     write_b(breg[0], 0);
     write_b(breg[1], 1);
-    load_b(breg[0], 6);
+    load_b(breg[0], R);
 
     // ---- fragment addresses
     const int q = lane >> 4, r = lane & 15;
@@ -141,47 +143,58 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
 
     __syncthreads();
     int kh = 0, kw = 0, ci = 0;
-    // fragments of one K step: four rows tiles of the resident block at the tap's offset + the NJ column tiles of an LDS stage
-    Frag fa[2][MI], fb[2][NJ];
-    auto fetch = [&](Frag (&a)[MI], Frag (&bq)[NJ], int stage) {
-        // tap of the step -> offset inside the block; empty taps behind KH KW (zero weights) read tap 0
-        const int dt = d.sgn * (kw - d.pt) - d.dtmin, dh = d.sgn * (kh - d.ph) - d.dhmin;
-        const int dp = kh < d.KH ? dt * d.HB + dh : 0;
-        const int c0 = (ci >> 3) + q;
-        const char* Bb = Bs + stage * B_STAGE;
+    // fragments of one K step: per 32-wide sub-step the MI row tiles of the resident block at the tap's offset + the NJ column tiles of an LDS stage
+    Frag fa[2][KS * MI], fb[2][KS * NJ];
+    auto fetch = [&](Frag (&a)[KS * MI], Frag (&bq)[KS * NJ], int stage) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int p = pbase[i] + dp;
-            a[i].u = *reinterpret_cast<const uint4*>(Ab + p * POS_BYTES + ((c0 ^ swz(p)) << 4));
+        for (int kk = 0; kk < KS; ++kk) {
+            // tap of the sub-step -> offset inside the block; empty taps behind KH KW (zero weights) read tap 0
+            const int dt = d.sgn * (kw - d.pt) - d.dtmin, dh = d.sgn * (kh - d.ph) - d.dhmin;
+            const int dp = kh < d.KH ? dt * d.HB + dh : 0;
+            const int c0 = (ci >> 3) + q;
+            const char* Bb = Bs + stage * B_STAGE + kk * B_HALF;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int p = pbase[i] + dp;
+                a[kk * MI + i].u = *reinterpret_cast<const uint4*>(Ab + p * POS_BYTES + ((c0 ^ swz(p)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bq[kk * NJ + j].u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
+            ci += 32;
+            if (ci >= d.Cs) { ci = 0; if (++kw == d.KW) { kw = 0; ++kh; } }
         }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bq[j].u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
-        ci += 32;
-        if (ci >= d.Cs) { ci = 0; if (++kw == d.KW) { kw = 0; ++kh; } }
     };
     fetch(fa[0], fb[0], 0);
-    // K step ks (P6 = ks % 6): the weight tile of step ks + 7 is asked for; the MFMAs run on fragments fetched one step ago; the tile of step
-    // ks + 2 (asked for five steps ago) goes to LDS stage (ks + 2) % 3; the fragments of step ks + 1 -- its stage was written one step ago
-    // and published by that step's barrier -- are fetched BEFORE this step's barrier, so that their LDS latency and the barrier overlap the
-    // MFMAs still in the pipe.
-    auto kstep = [&](int ks, auto p6) {
-        constexpr int P6 = decltype(p6)::value, P3 = P6 % 3, P2 = P6 % 2;
-        load_b(breg[(P6 + 1) % 6], ks + 7);
+    // K step ks (P = ks % 12): the weight tile of step ks + R + 1 is asked for; the MFMAs run on fragments fetched one step ago; the tile of
+    // step ks + 2 (asked for R - 1 steps ago) goes to LDS stage (ks + 2) % 3; the fragments of step ks + 1 -- its stage was written one step
+    // ago and published by that step's barrier -- are fetched BEFORE this step's barrier, so that their LDS latency and the barrier
+    // overlap the MFMAs still in the pipe.
+    auto kstep = [&](int ks, auto pp) {
+        constexpr int P = decltype(pp)::value, P3 = P % 3, P2 = P % 2;
+        load_b(breg[(P + 1) % R], ks + R + 1);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-            for (int i = 0; i < MI; ++i) acc[i][j] = ASR_MFMA_16x16x32(fa[P2][i].v, fb[P2][j].v, acc[i][j]);
-        write_b(breg[(P6 + 2) % 6], (P3 + 2) % 3);
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[i][j] = ASR_MFMA_16x16x32(fa[P2][kk * MI + i].v, fb[P2][kk * NJ + j].v, acc[i][j]);
+        write_b(breg[(P + 2) % R], (P3 + 2) % 3);
         if (ks + 1 < nk) fetch(fa[P2 ^ 1], fb[P2 ^ 1], (P3 + 1) % 3);
         __syncthreads();
     };
-    for (int ks = 0; ks < nk; ks += 6) {
+    for (int ks = 0; ks < nk; ks += 12) {
         kstep(ks, std::integral_constant<int, 0>());
         if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>());
         if (ks + 2 < nk) kstep(ks + 2, std::integral_constant<int, 2>());
         if (ks + 3 < nk) kstep(ks + 3, std::integral_constant<int, 3>());
         if (ks + 4 < nk) kstep(ks + 4, std::integral_constant<int, 4>());
         if (ks + 5 < nk) kstep(ks + 5, std::integral_constant<int, 5>());
+        if (ks + 6 < nk) kstep(ks + 6, std::integral_constant<int, 6>());
+        if (ks + 7 < nk) kstep(ks + 7, std::integral_constant<int, 7>());
+        if (ks + 8 < nk) kstep(ks + 8, std::integral_constant<int, 8>());
+        if (ks + 9 < nk) kstep(ks + 9, std::integral_constant<int, 9>());
+        if (ks + 10 < nk) kstep(ks + 10, std::integral_constant<int, 10>());
+        if (ks + 11 < nk) kstep(ks + 11, std::integral_constant<int, 11>());
     }
     // ---- epilogue: acc[i][j][reg] = out[row wid 64 + 16 i + 4 q + reg][column tn TNW + NJ r + j]: NJ consecutive columns per lane and row
     const int col = tn * TNW + NJ * r;
@@ -231,7 +244,7 @@ extern "C" int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW,
     if ((unsigned long long)Ts * B * Hs * Cs * 2 >= 0xfffffff0ull || (unsigned long long)N * K * 2 >= (1ull << 31)) return 0;
     const int Tt = 128 / Hr;
     if (Tt < 1) return 0;
-    const size_t lds = (((size_t)(Tt + KW - 1) * (Hr + KH - 1) * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (N <= 64 ? 64 : 128) * 64;
+    const size_t lds = (((size_t)(Tt + KW - 1) * (Hr + KH - 1) * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (N <= 64 ? 2 * 64 : 128) * 64;
     return lds <= 150 * 1024 ? 1 : 0;
 }
 
@@ -251,26 +264,30 @@ extern "C" int asr_conv_direct_nt(void* stream_, const void* x, const void* W, i
     const bool narrow = N <= 64;
     d.tiles_n = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128);
     d.npos = d.TB * d.HB;
-    const size_t lds = (((size_t)d.npos * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (narrow ? 64 : 128) * 64;
+    // two 32-wide K steps per barrier for the 64-column tiles whose block (128 channels) allows two workgroups per CU anyway: 128 -> 64
+    // channels 178 -> 164 us; with 64 channels the 117 registers of the one-step form keep four workgroups on a CU and the 177 of the
+    // two-step form two (64 -> 64: 68 -> 87 us)
+    const bool ks2 = narrow && Cs >= 128 && ((ldw >> 5) % 2) == 0;
+    const size_t lds = (((size_t)d.npos * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (narrow ? (ks2 ? 2 : 1) * 64 : 128) * 64;
     const unsigned x_bytes = (unsigned)((unsigned long long)Ts * B * Hs * Cs * 2);
     const long long grid = (long long)d.tiles_t * B * d.tiles_n;
     if (grid > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
-#define ASR_CD(NJ_, L_)                                                                                                              \
+#define ASR_CD(NJ_, L_, KS_)                                                                                                         \
     do {                                                                                                                             \
         static bool attr_ = false;                                                                                                   \
         if (!attr_) {                                                                                                                \
-            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, 2, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_ = true;                                                                                                            \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, 2>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
+        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, 2, KS_>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
                            (uint16_t*)out, bias, d, x_bytes);                                                                        \
     } while (0)
-#define ASR_CDL(NJ_)                                                                                                                 \
+#define ASR_CDL(NJ_, KS_)                                                                                                            \
     do {                                                                                                                             \
-        if (Cs == 32) ASR_CD(NJ_, 2); else if (Cs == 64) ASR_CD(NJ_, 3); else if (Cs == 128) ASR_CD(NJ_, 4); else ASR_CD(NJ_, 5);     \
+        if (Cs == 32) ASR_CD(NJ_, 2, KS_); else if (Cs == 64) ASR_CD(NJ_, 3, KS_); else if (Cs == 128) ASR_CD(NJ_, 4, KS_); else ASR_CD(NJ_, 5, KS_); \
     } while (0)
-    if (narrow) ASR_CDL(4); else ASR_CDL(8);
+    if (narrow) { if (ks2) ASR_CDL(4, 2); else ASR_CDL(4, 1); } else ASR_CDL(8, 1);
 #undef ASR_CDL
 #undef ASR_CD
     ASR_LAUNCH_CHECK();
