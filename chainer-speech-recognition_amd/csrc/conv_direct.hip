@@ -35,6 +35,7 @@ struct Desc {
     int B, Hs, Cs, Ts, KH, KW, ph, pt, sgn, Hr, Tr;
     int Tt, TB, HB, dtmin, dhmin;       // tile: time steps per workgroup, block extents, smallest time / height offset of a tap
     int N, K, tiles_t, tiles_n, npos;
+    int Cb, npass;                      // channels of the resident block (<= 128) and passes over the channels (Cs / Cb)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +46,9 @@ constexpr int NSTG = 3;         // LDS stages of the weight ring (three more ste
 // cover its LDS latency and barrier with: 880 cycles per K step of 256 MFMA cycles).
 // LOG_NCH: log2(Cs / 8), the 16-B chunks of a position (Cs = 32, 64, 128, 256).
 // KS: 32-wide K steps per barrier (2 where the tile is 64 columns wide: 8 MFMAs per wave between two barriers were too few).
-template <int NJ, int LOG_NCH, int MI, int KS>
+// MULTI: more than 128 input channels, i.e. several passes over the channels with the accumulators kept (they then live through the block
+// loads: 169 instead of 117 registers for the 64-column form, two workgroups per CU instead of four -- so the one-pass kernels stay apart).
+template <int NJ, int LOG_NCH, int MI, int KS, bool MULTI>
 __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ out, const float* __restrict__ bias, Desc d, unsigned x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,7 +81,12 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
         const int col = tn * TNW + NJ * (rho & 15) + (rho >> 4);
         ob[i] = __umul24((unsigned)min(col, d.N - 1), (unsigned)(d.K * 2)) + lchunk;
     }
-    const int nk = (d.K >> 5) / KS;          // (K steps of 32 KS columns: the host chooses KS = 2 only where K / 32 is even)
+    // K steps of 32 KS columns per channel pass (the host chooses KS = 2 only where that is even).  With more than 128 input channels the
+    // block holds Cb = 128 of them and the tile is computed in Cs / Cb passes (block reloaded, accumulators kept): sub-step u of pass cp is
+    // tap u / (Cb / 32), channels cp Cb + 32 (u % (Cb / 32)) ..  -- column (tap Cs + that) of W
+    const int nk = (d.K / d.npass >> 5) / KS;
+    const int spt_log = LOG_NCH - 2;           // log2(Cb / 32)
+    int cp = 0;                                // the channel pass
     // weight tiles in flight (register sets): every workgroup of an XCD asks the same few KB of its L2 for the same tile at the same time
     // and the answer takes ~1800 cycles, several K steps of this workgroup (with two steps of distance a K step took 880 cycles, not 300)
     u32x4 breg[R][KS * BP];
@@ -87,7 +95,11 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
         for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int i = 0; i < BP; ++i)
-                regs[kk * BP + i] = ks < nk ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ob[i], (ks * KS + kk) * 64, 0) : (u32x4){0u, 0u, 0u, 0u};
+            {
+                const int u = ks * KS + kk;
+                const int kofs = ((u >> spt_log) * d.Cs + cp * d.Cb + ((u & ((1 << spt_log) - 1)) << 5)) * 2;
+                regs[kk * BP + i] = ks < nk ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ob[i], kofs, 0) : (u32x4){0u, 0u, 0u, 0u};
+            }
     };
     auto write_b = [&](const u32x4 (&regs)[KS * BP], int stage) {
 #pragma unroll
@@ -95,35 +107,6 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
 #pragma unroll
             for (int i = 0; i < BP; ++i) *reinterpret_cast<u32x4*>(Bs + stage * B_STAGE + kk * B_HALF + (i * 256 + tid) * 16) = regs[kk * BP + i];
     };
-#pragma unroll
-    for (int j = 0; j < R; ++j) load_b(breg[j], j);
-    // ---- the activation block: chunk index idx = p NCH + slot lives at LDS byte idx 16; UF loads in flight per thread (with four, the
-    // 88 KB block of a 128-channel tile took five dependent round trips to memory: 20 of a tile's 31 us)
-    {
-        constexpr int UF = 12;
-        const int nchunks = ablk_bytes >> 4;
-        for (int base = tid; base < nchunks; base += UF * 256) {
-            u32x4 v[UF];
-#pragma unroll
-            for (int u = 0; u < UF; ++u) {
-                const int idx = base + u * 256;
-                const int p = idx >> LOG_NCH, slot = idx & (NCH - 1);
-                const int c = slot ^ swz(p);
-                const int tb = p / d.HB, hb = p - tb * d.HB;
-                const int t = t0 + d.dtmin + tb, h = d.dhmin + hb;
-                const bool ok = idx < nchunks && p < d.npos && (unsigned)t < (unsigned)d.Ts && (unsigned)h < (unsigned)d.Hs;
-                const unsigned off = (unsigned)((((size_t)t * d.B + b) * d.Hs + h) * d.Cs + c * 8) * 2u;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? off : 0xfffffff0u, 0, 0);       // (beyond num_records: zeros)
-            }
-#pragma unroll
-            for (int u = 0; u < UF; ++u)
-                if (base + u * 256 < nchunks) *reinterpret_cast<u32x4*>(Ab + (size_t)(base + u * 256) * 16) = v[u];
-        }
-    }
-    write_b(breg[0], 0);
-    write_b(breg[1], 1);
-    load_b(breg[0], R);
-
     // ---- fragment addresses
     const int q = lane >> 4, r = lane & 15;
     int pbase[MI];              // block position of this lane's row of M tile i at the tap (dtmin, dhmin)
@@ -136,65 +119,100 @@ __global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const
     }
     const int boff0 = r * 64 + ((q ^ g4(r)) << 4);
     f32x4 acc[MI][NJ];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    if (MULTI) zero_acc();
 
-    __syncthreads();
-    int kh = 0, kw = 0, ci = 0;
-    // fragments of one K step: per 32-wide sub-step the MI row tiles of the resident block at the tap's offset + the NJ column tiles of an LDS stage
-    Frag fa[2][KS * MI], fb[2][KS * NJ];
-    auto fetch = [&](Frag (&a)[KS * MI], Frag (&bq)[KS * NJ], int stage) {
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            // tap of the sub-step -> offset inside the block; empty taps behind KH KW (zero weights) read tap 0
-            const int dt = d.sgn * (kw - d.pt) - d.dtmin, dh = d.sgn * (kh - d.ph) - d.dhmin;
-            const int dp = kh < d.KH ? dt * d.HB + dh : 0;
-            const int c0 = (ci >> 3) + q;
-            const char* Bb = Bs + stage * B_STAGE + kk * B_HALF;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int p = pbase[i] + dp;
-                a[kk * MI + i].u = *reinterpret_cast<const uint4*>(Ab + p * POS_BYTES + ((c0 ^ swz(p)) << 4));
+    for (cp = 0; cp < (MULTI ? d.npass : 1); ++cp) {
+    #pragma unroll
+        for (int j = 0; j < R; ++j) load_b(breg[j], j);
+        // ---- the activation block: chunk index idx = p NCH + slot lives at LDS byte idx 16; UF loads in flight per thread (with four, the
+        // 88 KB block of a 128-channel tile took five dependent round trips to memory: 20 of a tile's 31 us)
+        {
+            constexpr int UF = 12;
+            const int nchunks = ablk_bytes >> 4;
+            for (int base = tid; base < nchunks; base += UF * 256) {
+                u32x4 v[UF];
+    #pragma unroll
+                for (int u = 0; u < UF; ++u) {
+                    const int idx = base + u * 256;
+                    const int p = idx >> LOG_NCH, slot = idx & (NCH - 1);
+                    const int c = slot ^ swz(p);
+                    const int tb = p / d.HB, hb = p - tb * d.HB;
+                    const int t = t0 + d.dtmin + tb, h = d.dhmin + hb;
+                    const bool ok = idx < nchunks && p < d.npos && (unsigned)t < (unsigned)d.Ts && (unsigned)h < (unsigned)d.Hs;
+                    const unsigned off = (unsigned)((((size_t)t * d.B + b) * d.Hs + h) * d.Cs + cp * d.Cb + c * 8) * 2u;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? off : 0xfffffff0u, 0, 0);       // (beyond num_records: zeros)
+                }
+    #pragma unroll
+                for (int u = 0; u < UF; ++u)
+                    if (base + u * 256 < nchunks) *reinterpret_cast<u32x4*>(Ab + (size_t)(base + u * 256) * 16) = v[u];
             }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bq[kk * NJ + j].u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
-            ci += 32;
-            if (ci >= d.Cs) { ci = 0; if (++kw == d.KW) { kw = 0; ++kh; } }
         }
-    };
-    fetch(fa[0], fb[0], 0);
-    // K step ks (P = ks % 12): the weight tile of step ks + R + 1 is asked for; the MFMAs run on fragments fetched one step ago; the tile of
-    // step ks + 2 (asked for R - 1 steps ago) goes to LDS stage (ks + 2) % 3; the fragments of step ks + 1 -- its stage was written one step
-    // ago and published by that step's barrier -- are fetched BEFORE this step's barrier, so that their LDS latency and the barrier
-    // overlap the MFMAs still in the pipe.
-    auto kstep = [&](int ks, auto pp) {
-        constexpr int P = decltype(pp)::value, P3 = P % 3, P2 = P % 2;
-        load_b(breg[(P + 1) % R], ks + R + 1);
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) acc[i][j] = ASR_MFMA_16x16x32(fa[P2][kk * MI + i].v, fb[P2][kk * NJ + j].v, acc[i][j]);
-        write_b(breg[(P + 2) % R], (P3 + 2) % 3);
-        if (ks + 1 < nk) fetch(fa[P2 ^ 1], fb[P2 ^ 1], (P3 + 1) % 3);
+        write_b(breg[0], 0);
+        write_b(breg[1], 1);
+        load_b(breg[0], R);
+
+        if (!MULTI) zero_acc();
         __syncthreads();
-    };
-    for (int ks = 0; ks < nk; ks += 12) {
-        kstep(ks, std::integral_constant<int, 0>());
-        if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>());
-        if (ks + 2 < nk) kstep(ks + 2, std::integral_constant<int, 2>());
-        if (ks + 3 < nk) kstep(ks + 3, std::integral_constant<int, 3>());
-        if (ks + 4 < nk) kstep(ks + 4, std::integral_constant<int, 4>());
-        if (ks + 5 < nk) kstep(ks + 5, std::integral_constant<int, 5>());
-        if (ks + 6 < nk) kstep(ks + 6, std::integral_constant<int, 6>());
-        if (ks + 7 < nk) kstep(ks + 7, std::integral_constant<int, 7>());
-        if (ks + 8 < nk) kstep(ks + 8, std::integral_constant<int, 8>());
-        if (ks + 9 < nk) kstep(ks + 9, std::integral_constant<int, 9>());
-        if (ks + 10 < nk) kstep(ks + 10, std::integral_constant<int, 10>());
-        if (ks + 11 < nk) kstep(ks + 11, std::integral_constant<int, 11>());
+        int kh = 0, kw = 0, ci = 0;
+        // fragments of one K step: per 32-wide sub-step the MI row tiles of the resident block at the tap's offset + the NJ column tiles of an LDS stage
+        Frag fa[2][KS * MI], fb[2][KS * NJ];
+        auto fetch = [&](Frag (&a)[KS * MI], Frag (&bq)[KS * NJ], int stage) {
+    #pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                // tap of the sub-step -> offset inside the block; empty taps behind KH KW (zero weights) read tap 0
+                const int dt = d.sgn * (kw - d.pt) - d.dtmin, dh = d.sgn * (kh - d.ph) - d.dhmin;
+                const int dp = kh < d.KH ? dt * d.HB + dh : 0;
+                const int c0 = (ci >> 3) + q;
+                const char* Bb = Bs + stage * B_STAGE + kk * B_HALF;
+    #pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int p = pbase[i] + dp;
+                    a[kk * MI + i].u = *reinterpret_cast<const uint4*>(Ab + p * POS_BYTES + ((c0 ^ swz(p)) << 4));
+                }
+    #pragma unroll
+                for (int j = 0; j < NJ; ++j) bq[kk * NJ + j].u = *reinterpret_cast<const uint4*>(Bb + boff0 + j * 1024);
+                ci += 32;
+                if (ci >= d.Cb) { ci = 0; if (++kw == d.KW) { kw = 0; ++kh; } }
+            }
+        };
+        fetch(fa[0], fb[0], 0);
+        // K step ks (P = ks % 12): the weight tile of step ks + R + 1 is asked for; the MFMAs run on fragments fetched one step ago; the tile of
+        // step ks + 2 (asked for R - 1 steps ago) goes to LDS stage (ks + 2) % 3; the fragments of step ks + 1 -- its stage was written one step
+        // ago and published by that step's barrier -- are fetched BEFORE this step's barrier, so that their LDS latency and the barrier
+        // overlap the MFMAs still in the pipe.
+        auto kstep = [&](int ks, auto pp) {
+            constexpr int P = decltype(pp)::value, P3 = P % 3, P2 = P % 2;
+            load_b(breg[(P + 1) % R], ks + R + 1);
+    #pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+    #pragma unroll
+                for (int j = 0; j < NJ; ++j)
+    #pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[i][j] = ASR_MFMA_16x16x32(fa[P2][kk * MI + i].v, fb[P2][kk * NJ + j].v, acc[i][j]);
+            write_b(breg[(P + 2) % R], (P3 + 2) % 3);
+            if (ks + 1 < nk) fetch(fa[P2 ^ 1], fb[P2 ^ 1], (P3 + 1) % 3);
+            __syncthreads();
+        };
+        for (int ks = 0; ks < nk; ks += 12) {
+            kstep(ks, std::integral_constant<int, 0>());
+            if (ks + 1 < nk) kstep(ks + 1, std::integral_constant<int, 1>());
+            if (ks + 2 < nk) kstep(ks + 2, std::integral_constant<int, 2>());
+            if (ks + 3 < nk) kstep(ks + 3, std::integral_constant<int, 3>());
+            if (ks + 4 < nk) kstep(ks + 4, std::integral_constant<int, 4>());
+            if (ks + 5 < nk) kstep(ks + 5, std::integral_constant<int, 5>());
+            if (ks + 6 < nk) kstep(ks + 6, std::integral_constant<int, 6>());
+            if (ks + 7 < nk) kstep(ks + 7, std::integral_constant<int, 7>());
+            if (ks + 8 < nk) kstep(ks + 8, std::integral_constant<int, 8>());
+            if (ks + 9 < nk) kstep(ks + 9, std::integral_constant<int, 9>());
+            if (ks + 10 < nk) kstep(ks + 10, std::integral_constant<int, 10>());
+            if (ks + 11 < nk) kstep(ks + 11, std::integral_constant<int, 11>());
+        }
     }
     // ---- epilogue: acc[i][j][reg] = out[row wid 64 + 16 i + 4 q + reg][column tn TNW + NJ r + j]: NJ consecutive columns per lane and row
     const int col = tn * TNW + NJ * r;
@@ -239,12 +257,13 @@ using namespace asr::convd;
 
 // 1 when asr_conv_direct_nt serves the shape (asr_conv_nt asks before falling back to the implicit-GEMM kernels)
 extern "C" int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW, int Tr, int Hr, int N, int K, int out_bf16) {
-    if (!out_bf16 || (Cs != 32 && Cs != 64 && Cs != 128 && Cs != 256) || (N % 8) || (K % 32) || (K % Cs) || K < KH * KW * Cs) return 0;
+    if (!out_bf16 || (Cs != 32 && Cs != 64 && Cs != 128 && Cs != 256 && Cs != 512) || (N % 8) || (K % 32) || (K % Cs) || K < KH * KW * Cs) return 0;
     if (Hr > 128 || Hr <= 0 || KH > 8 || KW > 8 || Tr <= 0) return 0;
     if ((unsigned long long)Ts * B * Hs * Cs * 2 >= 0xfffffff0ull || (unsigned long long)N * K * 2 >= (1ull << 31)) return 0;
     const int Tt = 128 / Hr;
     if (Tt < 1) return 0;
-    const size_t lds = (((size_t)(Tt + KW - 1) * (Hr + KH - 1) * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (N <= 64 ? 2 * 64 : 128) * 64;
+    const int Cb = Cs < 128 ? Cs : 128;
+    const size_t lds = (((size_t)(Tt + KW - 1) * (Hr + KH - 1) * Cb * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (N <= 64 ? 2 * 64 : 128) * 64;
     return lds <= 150 * 1024 ? 1 : 0;
 }
 
@@ -264,28 +283,31 @@ extern "C" int asr_conv_direct_nt(void* stream_, const void* x, const void* W, i
     const bool narrow = N <= 64;
     d.tiles_n = (N + (narrow ? 63 : 127)) / (narrow ? 64 : 128);
     d.npos = d.TB * d.HB;
+    d.Cb = Cs < 128 ? Cs : 128;
+    d.npass = Cs / d.Cb;
     // two 32-wide K steps per barrier for the 64-column tiles whose block (128 channels) allows two workgroups per CU anyway: 128 -> 64
     // channels 178 -> 164 us; with 64 channels the 117 registers of the one-step form keep four workgroups on a CU and the 177 of the
     // two-step form two (64 -> 64: 68 -> 87 us)
-    const bool ks2 = narrow && Cs >= 128 && ((ldw >> 5) % 2) == 0;
-    const size_t lds = (((size_t)d.npos * Cs * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (narrow ? (ks2 ? 2 : 1) * 64 : 128) * 64;
+    const bool ks2 = narrow && Cs >= 128 && ((ldw / d.npass >> 5) % 2) == 0;
+    const size_t lds = (((size_t)d.npos * d.Cb * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (narrow ? (ks2 ? 2 : 1) * 64 : 128) * 64;
     const unsigned x_bytes = (unsigned)((unsigned long long)Ts * B * Hs * Cs * 2);
     const long long grid = (long long)d.tiles_t * B * d.tiles_n;
     if (grid > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
-#define ASR_CD(NJ_, L_, KS_)                                                                                                         \
+#define ASR_CD(NJ_, L_, KS_, MU_)                                                                                                         \
     do {                                                                                                                             \
         static bool attr_ = false;                                                                                                   \
         if (!attr_) {                                                                                                                \
-            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, 2, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, 2, KS_, MU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_ = true;                                                                                                            \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, 2, KS_>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
+        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, 2, KS_, MU_>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
                            (uint16_t*)out, bias, d, x_bytes);                                                                        \
     } while (0)
 #define ASR_CDL(NJ_, KS_)                                                                                                            \
     do {                                                                                                                             \
-        if (Cs == 32) ASR_CD(NJ_, 2, KS_); else if (Cs == 64) ASR_CD(NJ_, 3, KS_); else if (Cs == 128) ASR_CD(NJ_, 4, KS_); else ASR_CD(NJ_, 5, KS_); \
+        if (Cs == 32) ASR_CD(NJ_, 2, KS_, false); else if (Cs == 64) ASR_CD(NJ_, 3, KS_, false); else if (Cs == 128) ASR_CD(NJ_, 4, KS_, false); \
+        else ASR_CD(NJ_, 4, KS_, true);                                                                                                 \
     } while (0)
     if (narrow) { if (ks2) ASR_CDL(4, 2); else ASR_CDL(4, 1); } else ASR_CDL(8, 1);
 #undef ASR_CDL

@@ -1738,13 +1738,13 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     const long long M = (long long)Tr * B * Hr;
     const int K = ldw;                  // row pitch of W = K of the GEMM: KH*KW*Cs, or more with empty (zero) taps behind
     if (ldw < KH * KW * Cs) return ASR_ERR_BAD_ARG;
-    // the kernel with the activation block resident in LDS (conv_direct.hip) where two of its workgroups fit a CU (<= 128 channels):
-    // T=1000, B=32, us, implicit GEMM / direct: 64 -> 64 channels 111 / 68, 128 -> 64 (a backward-data) 206 / 178, 128 -> 256 595 / 499,
-    // 128 -> 512 1090 / 953, 64 -> 128 138 / 135; with 256 input channels (one workgroup per CU) it loses, 996 / 1472
+    // the kernel with the activation block resident in LDS (conv_direct.hip; at most 128 channels of it at a time, more in passes):
+    // T=1000, B=32, us, implicit GEMM / direct: 64 -> 64 channels 111 / 67, 128 -> 64 (a backward-data) 206 / 166, 128 -> 256 595 / 483,
+    // 128 -> 512 1085 / 938, 64 -> 128 138 / 134, 256 -> 128 544 / 462, 512 -> 128 1040 / 884, 256 -> 256 998 / 902
     {
         static int direct = -1;
         if (direct < 0) direct = debug_flag("conv_direct", 1);
-        if (direct && out_bf16 && Cs <= 128 && asr_conv_direct_ok(Ts, B, Hs, Cs, KH, KW, Tr, Hr, N, ldw, 1) &&
+        if (direct && out_bf16 && asr_conv_direct_ok(Ts, B, Hs, Cs, KH, KW, Tr, Hr, N, ldw, 1) &&
             !((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)out)) & 15) && !(bias && (((uintptr_t)bias) & 15)))
             return asr_conv_direct_nt(stream_, x, W, ldw, out, bias, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, sgn, Tr, Hr, N);
     }
