@@ -421,7 +421,15 @@ class _Conv2D(torch.autograd.Function):
         def input_grad():
             if not need_dx:
                 return None
-            if wbwd is not None and not pointwise:      # implicit backward-data: no dcol matrix, no col2im pass
+            if (not pointwise and KH == Hin and Hout == 1 and KW == 1 and pad_h == 0 and pad_t == 0 and Tout == T
+                    and w16t.shape[0] == Kreal):
+                # the recipes' "dense" convolution: a kernel as high as its input and one frame wide (run/ctc/cnn/model.py: ksize
+                # (kernel_height, 1)) -- every input element belongs to exactly one output position, so dx is ONE plain product
+                # gy . W^T whose columns (kh, ci) are the input's (height, channel) order.  As an implicit backward-data convolution
+                # it summed KH taps per output row of which all but one lie outside the one-row gradient: 13 x the flops
+                # (0.99 ms instead of 0.11 for the 13 x 128 -> 640 layer at T=1000, B=32)
+                gp = _ops.gemm_nt(g2, w16t, None, BF16).reshape(T, B, Hin, Ci)
+            elif wbwd is not None and not pointwise:      # implicit backward-data: no dcol matrix, no col2im pass
                 gp = _ops.conv_nt(g2.reshape(Tout, B, Hout, Co), wbwd, None, BF16, KH, KW, pad_h, pad_t, -1, T, Hin).reshape(T, B, Hin, Ci)
             else:
                 dcol = _ops.gemm_nt(g2, w16t, None, BF16)
