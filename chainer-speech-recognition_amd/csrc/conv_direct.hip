@@ -49,7 +49,7 @@ constexpr int NSTG = 3;         // LDS stages of the weight ring (three more ste
 // MULTI: more than 128 input channels, i.e. several passes over the channels with the accumulators kept (they then live through the block
 // loads: 169 instead of 117 registers for the 64-column form, two workgroups per CU instead of four -- so the one-pass kernels stay apart).
 template <int NJ, int LOG_NCH, int MI, int KS, bool MULTI>
-__global__ __launch_bounds__(256, MI == 2 ? 2 : 1) void conv_direct_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W,
+__global__ __launch_bounds__(256, MI <= 3 ? 2 : 1) void conv_direct_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ W,
                                                              uint16_t* __restrict__ out, const float* __restrict__ bias, Desc d, unsigned x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NCH = 1 << LOG_NCH, TNW = 16 * NJ, B_HALF = TNW * 64, B_STAGE = KS * B_HALF, BP = NJ / 4;
@@ -260,9 +260,9 @@ extern "C" int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW,
     if (!out_bf16 || (Cs != 32 && Cs != 64 && Cs != 128 && Cs != 256 && Cs != 512) || (N % 8) || (K % 32) || (K % Cs) || K < KH * KW * Cs) return 0;
     if (Hr > 128 || Hr <= 0 || KH > 8 || KW > 8 || Tr <= 0) return 0;
     if ((unsigned long long)Ts * B * Hs * Cs * 2 >= 0xfffffff0ull || (unsigned long long)N * K * 2 >= (1ull << 31)) return 0;
-    const int Tt = 128 / Hr;
-    if (Tt < 1) return 0;
     const int Cb = Cs < 128 ? Cs : 128;
+    const int Tt = (Cb <= 64 ? 192 : 128) / Hr;        // (see asr_conv_direct_nt)
+    if (Tt < 1) return 0;
     const size_t lds = (((size_t)(Tt + KW - 1) * (Hr + KH - 1) * Cb * 2 + 1023) & ~(size_t)1023) + (size_t)NSTG * (N <= 64 ? 2 * 64 : 128) * 64;
     return lds <= 150 * 1024 ? 1 : 0;
 }
@@ -274,7 +274,11 @@ extern "C" int asr_conv_direct_nt(void* stream_, const void* x, const void* W, i
     if (((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)out)) & 15) || (bias && (((uintptr_t)bias) & 15))) return ASR_ERR_UNSUPPORTED;
     Desc d;
     d.B = B; d.Hs = Hs; d.Cs = Cs; d.Ts = Ts; d.KH = KH; d.KW = KW; d.ph = pad_h; d.pt = pad_t; d.sgn = sgn; d.Hr = Hr; d.Tr = Tr;
-    d.Tt = 128 / Hr;
+    // rows of a tile: 128 (two 16-row MFMA tiles per wave) with 128-channel blocks, 192 (three) up to 64 channels, where the block is small
+    // enough for two to four workgroups per CU either way: 64 -> 128 channels forward 132 -> 110 us, 64 -> 64 68 -> 63, 32 -> 64 117 -> 103
+    // (with 128 channels the larger block leaves one workgroup per CU: 128 -> 256 486 -> 596)
+    const bool mi3 = Cs <= 64;
+    d.Tt = (mi3 ? 192 : 128) / Hr;
     d.TB = d.Tt + KW - 1; d.HB = Hr + KH - 1;
     d.dtmin = sgn > 0 ? -pad_t : pad_t - (KW - 1);
     d.dhmin = sgn > 0 ? -pad_h : pad_h - (KH - 1);
@@ -294,20 +298,20 @@ extern "C" int asr_conv_direct_nt(void* stream_, const void* x, const void* W, i
     const long long grid = (long long)d.tiles_t * B * d.tiles_n;
     if (grid > 0x7fffffffLL) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
-#define ASR_CD(NJ_, L_, KS_, MU_)                                                                                                         \
+#define ASR_CD(NJ_, L_, MI_, KS_, MU_)                                                                                                \
     do {                                                                                                                             \
         static bool attr_ = false;                                                                                                   \
         if (!attr_) {                                                                                                                \
-            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, 2, KS_, MU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<NJ_, L_, MI_, KS_, MU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
             attr_ = true;                                                                                                            \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, 2, KS_, MU_>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
+        hipLaunchKernelGGL((conv_direct_kernel<NJ_, L_, MI_, KS_, MU_>), dim3((unsigned)grid), dim3(256), lds, stream, (const uint16_t*)x, (const uint16_t*)W, \
                            (uint16_t*)out, bias, d, x_bytes);                                                                        \
     } while (0)
 #define ASR_CDL(NJ_, KS_)                                                                                                            \
     do {                                                                                                                             \
-        if (Cs == 32) ASR_CD(NJ_, 2, KS_, false); else if (Cs == 64) ASR_CD(NJ_, 3, KS_, false); else if (Cs == 128) ASR_CD(NJ_, 4, KS_, false); \
-        else ASR_CD(NJ_, 4, KS_, true);                                                                                                 \
+        if (Cs == 32) ASR_CD(NJ_, 2, 3, KS_, false); else if (Cs == 64) ASR_CD(NJ_, 3, 3, KS_, false);                                \
+        else if (Cs == 128) ASR_CD(NJ_, 4, 2, KS_, false); else ASR_CD(NJ_, 4, 2, KS_, true);                                         \
     } while (0)
     if (narrow) { if (ks2) ASR_CDL(4, 2); else ASR_CDL(4, 1); } else ASR_CDL(8, 1);
 #undef ASR_CDL
