@@ -59,7 +59,7 @@ def parse():
 
 
 # the GEMM-class entries of the census (gemm_tn_acc_group: the grouped weight gradients of a GRU layer, one launch)
-GEMM_OPS = ("gemm_nt", "gemm_tn_acc", "gemm_tn_acc_group", "conv_nt", "conv_tn_acc")
+GEMM_OPS = ("gemm_nt", "gemm_tn_acc", "gemm_tn_acc_group", "conv_nt", "conv_tn_acc", "conv_mp_fwd", "conv_mp_bwd")
 
 
 class Census(object):
@@ -73,7 +73,7 @@ class Census(object):
         for name in ("gemm_nt", "gemm_tn_acc", "gemm_tn_acc_group", "gru_fwd", "gru_bwd", "im2col", "col2im", "layernorm_fwd", "layernorm_bwd", "layernorm_ctc_bwd",
                      "maxout2_fwd", "maxout2_bwd", "maxpool_h_fwd", "maxpool_h_bwd", "colsum_acc", "adam_ctl",
                      "step_control", "fill_", "cast_bf16", "conv_weight_pack", "conv_weight_grad_unpack", "conv_nt", "pack_input_pad",
-                     "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd"):
+                     "conv_weight_pack_bwd", "conv_tn_acc", "maxout2_pool_fwd", "maxout2_pool_bwd", "conv_mp_fwd", "conv_mp_bwd"):
             fn = getattr(ops, name)
             self._orig[name] = fn
             setattr(ops, name, self._timed(name, fn))
@@ -168,6 +168,17 @@ def gemm_shape(name, a, k, result):
         M, N, K = g2.shape[1], KH * KW * Cs, g2.shape[0]
         return {"key": (M, N, K, 4), "form": "implicit conv TN (weight gradient)", "M": M, "N": N, "K": K, "out": "f32 +=", "flops": 2.0 * M * N * K,
                 "bytes": 2.0 * g2.numel() + 2.0 * x.numel() + 4.0 * M * N}
+    if name == "conv_mp_fwd":           # first block in one pass: the convolution's product; only the pooled output and the winners are written
+        x8, W2, _, KH, KW, _, _, Tout, Hout, _ = a[:10]
+        M, N, K = Tout * x8.shape[1] * Hout, W2.shape[0], KH * KW * 8
+        y, idx = result
+        return {"key": (M, N, K, 2, 3), "form": "first block forward: conv + maxout + pooling, one pass", "M": M, "N": N, "K": K, "out": "bf16 pooled",
+                "flops": 2.0 * M * N * K, "bytes": 2.0 * x8.numel() + 2.0 * W2.numel() + 2.0 * y.numel() + 1.0 * idx.numel()}
+    if name == "conv_mp_bwd":
+        gy, idx, x8, gW, _, KH, KW, _, _, Hout, _ = a[:11]
+        M, N, K = gW.shape[0], KH * KW * 8, gy.shape[0] * gy.shape[1] * Hout
+        return {"key": (M, N, K, 4, 3), "form": "first block backward: weight + bias gradient from the pooled gradient", "M": M, "N": N, "K": K,
+                "out": "f32 +=", "flops": 2.0 * M * N * K, "bytes": 2.0 * gy.numel() + 1.0 * idx.numel() + 2.0 * x8.numel() + 4.0 * M * N}
     return None
 
 

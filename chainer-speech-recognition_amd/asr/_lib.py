@@ -69,6 +69,10 @@ SIGNATURES = {
     "asr_conv_nt": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
     "asr_conv_direct_ok": (c_int, [c_int] * 11),
     "asr_conv_direct_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
+    "asr_conv_mp_ok": (c_int, [c_int] * 5),
+    "asr_conv_mp_fwd": (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int] * 11),
+    "asr_conv_mp_bwd_workspace": (c_longlong, [c_int] * 5),
+    "asr_conv_mp_bwd": (c_int, [c_void_p] * 7 + [c_int] * 12),
     "asr_pack_input_pad": (c_int, [c_void_p, c_void_p, c_int] + [c_longlong] * 4 + [c_int] * 5 + [c_void_p]),
     "asr_conv_weight_pack_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),

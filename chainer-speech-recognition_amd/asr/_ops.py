@@ -818,6 +818,41 @@ def conv_direct_nt(x, W2, bias, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     return out
 
 
+def conv_mp_ok(Ci, KH, KW, Co, k):
+    return bool(_lib.lib().asr_conv_mp_ok(int(Ci), int(KH), int(KW), int(Co), int(k)))
+
+
+def conv_mp_fwd(x8, W2, bias, KH, KW, pad_h, pad_t, Tout, Hout, k):
+    """first block in one pass (csrc/conv_first.hip): x8 (Ts, B, Hs, 8) bf16, W2 (Co, 128) bf16 -> pooled maxout of the convolution
+    (Tout, B, Hp, Co / 2) bf16 and the winners' indices (same shape, uint8)"""
+    Ts, B, Hs, Cs = x8.shape
+    Co = W2.shape[0]
+    assert Cs == 8 and x8.dtype == BF16 and x8.is_contiguous() and W2.dtype == BF16 and W2.is_contiguous() and W2.shape[1] == 128
+    Hp = pooled_height(Hout, k)
+    y = torch.empty((Tout, B, Hp, Co // 2), dtype=BF16, device=x8.device)
+    idx = torch.empty((Tout, B, Hp, Co // 2), dtype=torch.uint8, device=x8.device)
+    CALLS["conv_mp_fwd"] = CALLS.get("conv_mp_fwd", 0) + 1
+    rc = _lib.lib().asr_conv_mp_fwd(stream(), ptr(x8), ptr(W2), 128, ptr(bias), ptr(y), ptr(idx), Ts, B, Hs, KH, KW, pad_h, pad_t, Tout,
+                                    Hout, Co, k)
+    check(rc, "asr_conv_mp_fwd")
+    return y, idx
+
+
+def conv_mp_bwd(gy, idx, x8, gW, gb, KH, KW, pad_h, pad_t, Hout, k):
+    """gW (Co, Ci, KH, KW) f32 += weight gradient, gb (Co) f32 += bias gradient (None: none) of conv_mp_fwd"""
+    Ts, B, Hs, _ = x8.shape
+    Tout, _, Hp, Cp = gy.shape
+    Co, Ci = gW.shape[0], gW.shape[1]
+    assert gy.dtype == BF16 and gy.is_contiguous() and idx.shape == gy.shape and idx.dtype == torch.uint8 and idx.is_contiguous()
+    assert gW.dtype == F32 and gW.is_contiguous() and Co == 2 * Cp and Hp == pooled_height(Hout, k)
+    assert gb is None or (gb.dtype == F32 and gb.is_contiguous() and gb.numel() == Co)
+    nbytes = _lib.lib().asr_conv_mp_bwd_workspace(Tout, B, Hout, Co, k)
+    ws = torch.empty((nbytes // 4,), dtype=F32, device=gy.device)
+    rc = _lib.lib().asr_conv_mp_bwd(stream(), ptr(gy), ptr(idx), ptr(x8), ptr(ws), ptr(gW), ptr(gb), Ts, B, Hs, Ci, KH, KW, pad_h, pad_t,
+                                    Tout, Hout, Co, k)
+    check(rc, "asr_conv_mp_bwd")
+
+
 def conv_weight_pack_bwd(W):
     """(Co, Ci, kh, kw) f32 -> bf16 (Ci, kh*kw*Co), k = (kh, kw, co)."""
     Co, Ci, KH, KW = W.shape

@@ -500,6 +500,82 @@ def convolution_2d_given_weight(x, W, b, link, pad=(0, 0), causal=False, out_f32
     return logical4(y)
 
 
+# ---------------------------------------------------------------------------------------------- first block in one pass
+CONV_MP = [_lib_debug("conv_mp", 1) != 0]        # ASR_DEBUG conv_mp=0: convolution, maxout and pooling as separate passes (comparison)
+
+
+def conv_weight_matrix_pad8_128(W):
+    """operand of the fused first block (csrc/conv_first.hip): conv_weight_matrix_pad8 with rows of exactly 128 entries (16 taps of 8)"""
+    Co, Ci, KH, KW = W.shape
+    Wp = torch.zeros((Co, 8, KH, KW), dtype=W.dtype, device=W.device)
+    Wp[:, :Ci] = W
+    return _ops.conv_weight_pack(Wp, Kp=128)
+
+
+class _ConvMaxoutPool(torch.autograd.Function):
+    """x (B, Ci < 8, H, T), no gradient wanted (the loader's minibatch); W (Co, Ci, kh, kw) f32 master or derived; b (Co) or None.
+    Output physical (Tout, B, Hp, Co / 2): Maxout(2) and MaxPooling2D((k, 1)) of the convolution, which is never written."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, w16q, pad_h, pad_t, causal, k):
+        B, Ci, Hin, T = x.shape
+        Co, _, KH, KW = W.shape
+        Tout = T if causal else T + 2 * pad_t - KW + 1
+        Hout = Hin + 2 * pad_h - KH + 1
+        xpad = _ops.pack_input_pad(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, 8)
+        y, idx = _ops.conv_mp_fwd(xpad, w16q, b.detach() if b is not None else None, KH, KW, pad_h, pad_t, Tout, Hout, k)
+        ctx.save_for_backward(xpad, idx)
+        ctx.params = (W, b)
+        ctx.meta = (KH, KW, pad_h, pad_t, Hout, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xpad, idx = ctx.saved_tensors
+        W, b = ctx.params
+        KH, KW, pad_h, pad_t, Hout, k = ctx.meta
+        gy = gy.contiguous() if gy.dtype == BF16 else _ops.cast_bf16(gy.contiguous())
+        w_is_param = isinstance(W, torch.nn.Parameter)
+        if w_is_param:
+            gW = grad_buffer(W)
+        else:       # a derived weight (weight normalisation): hand its gradient back to the tape
+            gW = torch.empty(W.shape, dtype=F32, device=gy.device)
+            _ops.fill_(gW, 0.0)
+        gb = grad_buffer(b) if b is not None else None
+        if w_is_param:
+            with _OnSide(gy, xpad, idx):
+                _ops.conv_mp_bwd(gy, idx, xpad, gW, gb, KH, KW, pad_h, pad_t, Hout, k)
+            grads_queued(W, b)
+        else:
+            _ops.conv_mp_bwd(gy, idx, xpad, gW, gb, KH, KW, pad_h, pad_t, Hout, k)
+            grads_queued(b)
+        return None, (None if w_is_param else gW), None, None, None, None, None, None
+
+
+def convolution_maxout_pool_ok(x, wshape, pad, causal, k):
+    pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
+    if not CONV_MP[0] or x.dim() != 4 or x.requires_grad or x.dtype not in (F32, BF16) or len(wshape) != 4 or wshape[1] != x.shape[1]:
+        return False
+    Co, Ci, KH, KW = wshape
+    if not _ops.conv_mp_ok(Ci, KH, KW, Co, k) or Ci >= 8:
+        return False
+    return x.shape[2] + 2 * pad_h - KH + 1 >= 1 and (x.shape[3] if causal else x.shape[3] + 2 * pad_t - KW + 1) >= 1
+
+
+def convolution_maxout_pool(x, W, b, link, pad, causal, k, given_weight=False):
+    """convolution_2d -> maxout(., 2) -> max_pooling_2d(., (k, 1)) of the FIRST layer (fewer than 8 input channels, no input gradient) as
+    one pass forward and one backward; None where the fused kernels do not serve the layer (the caller then runs the three functions)."""
+    pad_h, pad_t = (pad, pad) if isinstance(pad, int) else pad
+    if not convolution_maxout_pool_ok(x, tuple(W.shape), pad, causal, k):
+        return None
+    if given_weight:
+        with torch.no_grad():
+            w16q = conv_weight_matrix_pad8_128(W.detach())
+    else:
+        w16q = link.compute_copy("w16q", W, conv_weight_matrix_pad8_128)
+    return logical4(_ConvMaxoutPool.apply(x, W, b, w16q, int(pad_h), int(pad_t), bool(causal), int(k)))
+
+
 # ---------------------------------------------------------------------------------------------- dense (1x1 over time)
 class _Dense(torch.autograd.Function):
     """rows (T*B, Din) bf16 @ W (Dout, Din)^T + b."""

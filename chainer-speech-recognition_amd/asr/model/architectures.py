@@ -21,6 +21,9 @@ def _crop(x):
     return x
 
 
+_crop._asr_identity = True      # (asr.nn containers look through it when they fuse a convolution with the layers behind it)
+
+
 def build_model(config):
     V, cin, h, dense = config.vocab_size, config.ndim_audio_features, config.ndim_h, config.ndim_dense
     ks = tuple(config.kernel_size)

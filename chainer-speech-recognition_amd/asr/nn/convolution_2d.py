@@ -43,6 +43,15 @@ class PlainConvolution2D(Link):
             self._initialize_params(x.shape[1])
         return functions.convolution_2d(x, self.W, self.b, self, self.pad, self.causal, self.output_float32)
 
+    def fused_maxout_pool(self, x, k):
+        """this layer, Maxout(2) and MaxPooling2D((k, 1)) as one pass where the layer is a model's first (functions.convolution_maxout_pool);
+        None: run the three layers"""
+        if self.output_float32:
+            return None
+        if self.W.numel() == 0:
+            self._initialize_params(x.shape[1])
+        return functions.convolution_maxout_pool(x, self.W, self.b, self, self.pad, self.causal, k)
+
 
 class _WeightNorm(torch.autograd.Function):
     """W = g * V / (||V|| + 1e-9) and its gradient (asr/nn/convolution_2d.py:21-25,62-64,92-93)."""
@@ -115,3 +124,12 @@ class Convolution2D(Link):
             return y.permute(1, 3, 2, 0)
         W = _WeightNorm.apply(self.V, self.g)
         return functions.convolution_2d_given_weight(x, W, self.b, self, self.pad, self.causal, self.output_float32)
+
+    def fused_maxout_pool(self, x, k):
+        """as PlainConvolution2D.fused_maxout_pool; the call that initialises g and b from the data runs the plain layers"""
+        if self.output_float32 or self.g.numel() == 0 or self.V.numel() == 0:
+            return None
+        if not functions.convolution_maxout_pool_ok(x, self.V.shape, self.pad, self.causal, k):
+            return None
+        W = _WeightNorm.apply(self.V, self.g)
+        return functions.convolution_maxout_pool(x, W, self.b, self, self.pad, self.causal, k, given_weight=True)

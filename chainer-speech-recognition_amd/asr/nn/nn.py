@@ -246,6 +246,20 @@ def _apply_layers(layers, x):
     i = 0
     while i < len(layers):
         layer = layers[i]
+        if x.dim() == 4 and hasattr(layer, "fused_maxout_pool"):
+            # a model's first convolution directly followed by Maxout(2) and MaxPooling2D((k, 1)): one pass, the convolution's output is
+            # never written (functions.convolution_maxout_pool; None where that does not serve the layer)
+            m = i + 1
+            while m < len(layers) and getattr(layers[m], "_asr_identity", False):
+                m += 1
+            j = _fusable_pool(layers, m) if m < len(layers) else -1
+            if j > 0:
+                ks = layers[j].ksize
+                y = layer.fused_maxout_pool(x, ks[0] if isinstance(ks, (tuple, list)) else ks)
+                if y is not None:
+                    x = y
+                    i = j + 1
+                    continue
         j = _fusable_pool(layers, i) if x.dim() == 4 else -1
         if j > 0:
             ks = layers[j].ksize

@@ -186,6 +186,22 @@ int asr_conv_nt(void* stream, const void* x, const void* W, int ldw, void* out, 
 int asr_conv_direct_ok(int Ts, int B, int Hs, int Cs, int KH, int KW, int Tr, int Hr, int N, int K, int out_bf16);
 int asr_conv_direct_nt(void* stream, const void* x, const void* W, int ldw, void* out, const float* bias, int Ts, int B, int Hs, int Cs,
                        int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+/* The first block of the models -- Convolution2D over the 8-channel padded features, Maxout(2), MaxPooling2D((k, 1)) (asr/nn/nn.py:235-238,
+ * :45-50, :95-103 as run/ctc/cnn/model.py:42-48 stacks them) -- as ONE forward and ONE backward pass (csrc/conv_first.hip): the convolution
+ * output (311 MB at T=1000, B=32 for BASELINE configs[1]) and its gradient never exist.
+ * asr_conv_mp_ok: 1 <= Ci <= 8 real input channels, KH KW <= 15 taps, Co % 128 == 0, 2 <= k <= 4.
+ * asr_conv_mp_fwd: x8 (Ts, B, Hs, 8) bf16 (asr_pack_input_pad); W (Co, 128) bf16, k = (kh KW + kw) 8 + ci, zeros behind 8 KH KW
+ *   (asr_conv_weight_pack with Kp = 128); bias (Co) f32 or NULL; y (Tout, B, Hp, Co / 2) bf16 with Hp = cover_all pooled heights of Hout;
+ *   idx (same shape, bytes): 2 * (row of the window) + (second channel of the pair) of the winner.  Values and tie rules of asr_conv_nt
+ *   (bf16 out) followed by asr_maxout2_pool_fwd.
+ * asr_conv_mp_bwd: gy (Tout, B, Hp, Co / 2) bf16, idx and x8 of the forward call; gW (Co, Ci, KH, KW) f32 += the weight gradient,
+ *   gb (Co) f32 += the bias gradient (NULL: none); workspace: asr_conv_mp_bwd_workspace(Tout, B, Hout, Co, k) bytes, 16-byte aligned. */
+int asr_conv_mp_ok(int Ci, int KH, int KW, int Co, int k);
+int asr_conv_mp_fwd(void* stream, const void* x8, const void* W, int ldw, const float* bias, void* y, void* idx, int Ts, int B, int Hs,
+                    int KH, int KW, int pad_h, int pad_t, int Tout, int Hout, int Co, int k);
+long long asr_conv_mp_bwd_workspace(int Tout, int B, int Hout, int Co, int k);
+int asr_conv_mp_bwd(void* stream, const void* gy, const void* idx, const void* x8, void* workspace, float* gW, float* gb, int Ts, int B,
+                    int Hs, int Ci, int KH, int KW, int pad_h, int pad_t, int Tout, int Hout, int Co, int k);
 /* any strided (T, B, H, C) f32 / bf16 tensor -> dense (T, B, H, Cpad) bf16, channels C..Cpad-1 zero: brings the loader's
  * (B, 3, 40, T) float32 minibatch into the layout of asr_conv_nt (first layer: C = 3 -> Cpad = 8) */
 int asr_pack_input_pad(void* stream, const void* x, int x_bf16, long long sT, long long sB, long long sH, long long sC, int T,

@@ -838,6 +838,70 @@ def test_direct_conv_equals_the_implicit_gemm_conv(device, T, B, Hin, Ci, Co, KH
         assert float((got_dx.float() - ref_dx.float()).abs().max()) <= 2.0 ** -6 * float(ref_dx.float().abs().max())
 
 
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal,k", [(50, 3, 40, 3, 128, 3, 5, 0, True, 3), (37, 2, 17, 1, 256, 3, 3, 1, False, 2),
+                                                            (29, 5, 11, 3, 128, 2, 4, 0, True, 4), (9, 1, 40, 3, 128, 3, 5, 0, True, 3),
+                                                            (300, 8, 40, 3, 128, 3, 5, 0, True, 3), (41, 3, 7, 7, 128, 5, 3, 2, True, 3)])
+def test_fused_first_block_equals_convolution_maxout_pooling(device, T, B, Hin, Ci, Co, KH, KW, ph, causal, k):
+    """csrc/conv_first.hip against the passes it replaces on the same operands -- asr_conv_nt (bf16 out) -> asr_maxout2_pool_fwd, and
+    asr_maxout2_pool_bwd_db -> asr_conv_tn_acc -> unpack: the pooled values bit for bit (the same products in the same K order through the
+    same MFMA; one bf16 ulp allowed where its internal order differs), the winners' indices consistent with them, the weight and bias
+    gradients to float32 summation order"""
+    from asr import _ops
+    rs = np.random.RandomState(T + Hin + Co + k)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    assert _ops.conv_mp_ok(Ci, KH, KW, Co, k)
+    x = torch.from_numpy(rs.randn(B, Ci, Hin, T).astype(np.float32)).to(device)
+    W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.3).astype(np.float32)).to(device)
+    bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
+    x8 = _ops.pack_input_pad(x, (x.stride(3), x.stride(0), x.stride(2), x.stride(1)), T, B, Hin, Ci, 8)
+    Wp = torch.zeros((Co, 8, KH, KW), device=device)
+    Wp[:, :Ci] = W
+    w128 = _ops.conv_weight_pack(Wp, Kp=128)
+    # the three passes
+    conv = _ops.conv_nt(x8, w128, bias, BF16, KH, KW, ph, pt, +1, Tout, Hout).reshape(Tout, B, Hout, Co)
+    want = _ops.maxout2_pool_fwd(conv, k)
+    got, idx = _ops.conv_mp_fwd(x8, w128, bias, KH, KW, ph, pt, Tout, Hout, k)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and idx.shape == want.shape
+    gf, wf = got.float().cpu(), want.float().cpu()
+    assert float((gf - wf).abs().max()) <= 2.0 ** -6 * float(wf.abs().max())
+    assert float((gf != wf).float().mean()) < 1e-3
+    # the index names an element of the window that holds the pooled value
+    Hp = want.shape[2]
+    cpad = torch.full((Tout, B, Hp * k, Co), float("-inf"))
+    cpad[:, :, :Hout] = conv.float().cpu()
+    cand = cpad.reshape(Tout, B, Hp, k, Co // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(Tout, B, Hp, Co // 2, 2 * k)
+    ix = idx.cpu().long()
+    assert int(ix.max()) < 2 * k
+    picked = torch.gather(cand, 4, ix.unsqueeze(-1)).squeeze(-1)
+    assert float((picked - gf).abs().max()) <= 2.0 ** -6 * float(wf.abs().max())
+    same = gf == wf
+    first = cand.argmax(dim=4)          # first maximum in (row, channel) order = the tie rule of asr_maxout2_pool_bwd
+    assert float((ix[same] != first[same]).float().mean()) < 1e-3
+    # backward
+    gy = torch.from_numpy(rs.randn(Tout, B, Hp, Co // 2).astype(np.float32)).to(device).to(BF16)
+    gW_ref = torch.zeros(Co, Ci, KH, KW, device=device)
+    gb_ref = torch.zeros(Co, device=device)
+    g = _ops.maxout2_pool_bwd(conv, gy, k)
+    scratch = torch.zeros(Co, KH * KW * 8, device=device)
+    _ops.conv_tn_acc(g.reshape(Tout * B * Hout, Co), x8, scratch, KH, KW, ph, pt, Tout, Hout)
+    _ops.conv_weight_grad_unpack(scratch, gW_ref, 8)
+    _ops.colsum_acc(g.reshape(Tout * B * Hout, Co), gb_ref)
+    gW = torch.full((Co, Ci, KH, KW), 0.5, device=device)          # the entry ACCUMULATES
+    gb = torch.full((Co,), -0.25, device=device)
+    _ops.conv_mp_bwd(gy, idx, x8, gW, gb, KH, KW, ph, pt, Hout, k)
+    torch.cuda.synchronize()
+    # (where an ulp-different convolution value changed a winner the two gradients route one element differently: the bars allow for it)
+    assert _rel((gW - 0.5).cpu(), gW_ref.cpu()) < 2e-3, _rel((gW - 0.5).cpu(), gW_ref.cpu())
+    assert _rel((gb + 0.25).cpu(), gb_ref.cpu()) < 2e-3
+    gW2 = torch.zeros(Co, Ci, KH, KW, device=device)
+    _ops.conv_mp_bwd(gy, idx, x8, gW2, None, KH, KW, ph, pt, Hout, k)
+    torch.cuda.synchronize()
+    assert _rel(gW2.cpu(), (gW - 0.5).cpu()) < 1e-5
+
+
 def _conv_nt_implicit(x, W2, bias, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     """asr_conv_nt with the direct kernel switched off: the float32-output form never dispatches to it"""
     from asr import _ops

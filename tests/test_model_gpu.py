@@ -539,6 +539,59 @@ def test_fused_logit_region_gives_the_gradients_of_the_unfused_one(device):
     assert float((gf[name] - gu[name]).norm() / gu[name].norm()) < 5e-3
 
 
+@pytest.mark.parametrize("kind", ["ds2", "cnn", "cnn+weightnorm"])
+def test_fused_first_block_gives_the_model_the_gradients_of_the_three_passes(device, kind):
+    """model level: the first convolution + Maxout + MaxPooling as one pass (csrc/conv_first.hip, the default where the layer has a
+    multiple of 128 output channels) against the same model with ASR_DEBUG conv_mp=0 semantics: same logits, same loss, every parameter
+    gradient equal up to float32 summation order -- for the conv + recurrent model, a convolutional recipe and its weight-normalised form
+    (whose first convolution hands the gradient of a derived weight back to the tape)"""
+    if BF16 is torch.float16 and kind == "ds2":
+        pytest.skip("the recurrences are bfloat16-only")
+    from asr import functions as F, _ops
+    from asr.loss import connectionist_temporal_classification
+    B, T, V = 3, 40, 23
+    x, labels, x_len, l_len = omodel.synthetic_batch(B, T, V, Lmin=2, Lmax=6, seed=4, ragged=True)
+    xd, ld, xl, ll = x.to(device), labels.to(device), x_len.to(device), l_len.to(device)
+
+    def build():
+        torch.manual_seed(17)
+        if kind == "ds2":
+            from asr.model import ds2
+            cfg = ds2.configure()
+            cfg.vocab_size, cfg.ndim_conv, cfg.ndim_rnn, cfg.ndim_dense, cfg.num_rnn_layers = V, 64, 64, 32, 1
+            return ds2.Model(cfg).to_gpu()
+        from asr.model import cnn
+        from asr.model.architectures import build_model
+        cfg = cnn.configure()
+        cfg.vocab_size, cfg.ndim_audio_features, cfg.ndim_h, cfg.ndim_dense, cfg.num_conv_layers = V, 3, 64, 24, 2
+        cfg.architecture, cfg.weightnorm = "zhang", kind.endswith("weightnorm")
+        return build_model(cfg).to_gpu()
+
+    def run(fused):
+        F.CONV_MP[0] = fused
+        try:
+            model = build()
+            with torch.no_grad():
+                model(xd)                   # lazily sized parameters; data-dependent weight-norm initialisation (never fused)
+            before = _ops.CALLS.get("conv_mp_fwd", 0)
+            ys = model(xd)
+            loss = connectionist_temporal_classification(ys, ld, 0, xl, ll)
+            _seeded_backward(loss)
+            F.join_side_stream()
+            torch.cuda.synchronize()
+            assert (_ops.CALLS.get("conv_mp_fwd", 0) - before) == (1 if fused else 0)
+            return (loss.item(), torch.stack(tuple(ys)).detach().float().cpu(),
+                    {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()})
+        finally:
+            F.CONV_MP[0] = True
+    (lf, yf, gf), (lu, yu, gu) = run(True), run(False)
+    assert torch.equal(yf, yu) and lf == lu
+    assert set(gf) == set(gu)
+    for name in gu:
+        err = float((gf[name] - gu[name]).norm() / (gu[name].norm() + 1e-30))
+        assert err < 1e-4, (name, err)
+
+
 def test_abort_word_of_a_third_stream_is_seen(device):
     """one control buffer per (device, stream) that launched a recurrence; a process that ran recurrences on three
     streams has three abort words, and the step control used to look at the first two.  All of them are ORed on the device now
