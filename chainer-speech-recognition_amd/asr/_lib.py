@@ -27,7 +27,7 @@ def act_dtype():
 
 def debug_flag(key, default):
     """integer value of `key` in ASR_DEBUG="key=value,key=value" -- the ONE table of what-if switches (csrc/common.hpp: debug_flag lists
-    the keys the library reads; this layer reads tn_group, gru_gates_f16, side_join, side_priority).  Nothing in a normal run sets it."""
+    the keys the library reads; this layer reads tn_group, gru_gates_f16, side_join, side_priority, conv_mp).  Nothing in a normal run sets it."""
     for item in os.environ.get("ASR_DEBUG", "").split(","):
         k, _, v = item.strip().partition("=")
         if k == key and v:

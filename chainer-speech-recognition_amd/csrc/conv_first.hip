@@ -435,7 +435,7 @@ extern "C" int asr_conv_mp_bwd(void* stream_, const void* gy, const void* idx, c
     hipLaunchKernelGGL(bwd_kernel, dim3(nparts, Co / 128), dim3(256), 0, stream, (const uint16_t*)gy, (const uint8_t*)idx, (const uint16_t*)x8,
                        (float*)workspace, d, ktiles, kt_per_wg);
     ASR_LAUNCH_CHECK();
-    const int slices = nparts >= 64 ? 4 : 1;
+    const int slices = nparts >= 256 ? 16 : (nparts >= 64 ? 4 : 1);        // (16 adds per address; 1024 workgroups keep the 33 MB of shares streaming)
     hipLaunchKernelGGL(bwd_reduce_kernel, dim3((Co * 128 + 255) / 256, slices), dim3(256), 0, stream, (const float*)workspace, nparts, gW, gb, d);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
