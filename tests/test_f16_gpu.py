@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_kernels_gpu.py", "tests/test_nn_gpu.py", "tests/test_model_gpu.py", "tests/test_ctc_gpu.py", "tests/test_f16_gpu.py"]
 SELECTION = ("(gemm or conv or maxout or layernorm or colsum or cast_transpose or pack_input or layer_stack or clip_decay or non_finite or step_control "
              "or activations or crelu or glu or weightnorm or upsampling or batch_normalization or generic_layout or gaussian or handover "
-             "or projection_bias or cnn_recipes or half_build_only) and not gru and not sru and not recurrence")
+             "or projection_bias or cnn_recipes or first_block or half_build_only) and not gru and not sru and not recurrence")
 
 
 def test_the_half_build_over_the_convolutional_path_in_a_child_process(device):

@@ -840,7 +840,10 @@ def test_direct_conv_equals_the_implicit_gemm_conv(device, T, B, Hin, Ci, Co, KH
 
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal,k", [(50, 3, 40, 3, 128, 3, 5, 0, True, 3), (37, 2, 17, 1, 256, 3, 3, 1, False, 2),
                                                             (29, 5, 11, 3, 128, 2, 4, 0, True, 4), (9, 1, 40, 3, 128, 3, 5, 0, True, 3),
-                                                            (300, 8, 40, 3, 128, 3, 5, 0, True, 3), (41, 3, 7, 7, 128, 5, 3, 2, True, 3)])
+                                                            (300, 8, 40, 3, 128, 3, 5, 0, True, 3), (41, 3, 7, 7, 128, 5, 3, 2, True, 3),
+                                                            (3, 1, 4, 3, 128, 3, 5, 0, True, 3),           # two output heights: ONE short window
+                                                            (1, 2, 9, 2, 128, 3, 1, 0, True, 2),           # one frame per utterance, a (3, 1) filter
+                                                            (2, 1, 40, 3, 128, 3, 5, 0, False, 3)])        # fewer frames than filter taps in time
 def test_fused_first_block_equals_convolution_maxout_pooling(device, T, B, Hin, Ci, Co, KH, KW, ph, causal, k):
     """csrc/conv_first.hip against the passes it replaces on the same operands -- asr_conv_nt (bf16 out) -> asr_maxout2_pool_fwd, and
     asr_maxout2_pool_bwd_db -> asr_conv_tn_acc -> unpack: the pooled values bit for bit (the same products in the same K order through the
