@@ -4,7 +4,7 @@
 //
 // Unfused, this block is pure memory traffic around a convolution with K = 120: the convolution writes 311 MB (T=1000, B=32, 38 heights,
 // 128 channels), maxout + pooling read them and keep one value in six; backward scatters the pooled gradient back into a 311 MB tensor of
-// which five sixths are zeros, and the weight-gradient product reads that.  0.45 ms of the BASELINE configs[1] step for 0.1 GFLOP-class work.
+// which five sixths are zeros, and the weight-gradient product reads that.  0.45 - 0.49 ms of the BASELINE configs[1] step around 37 GFLOP (15 us of MFMA time) each way.
 //
 // Forward: the input is (Ts, B, Hs, 8) bf16 (three real channels, asr_pack_input_pad), so ONE 16-byte chunk is one filter tap and one lane's
 // share of an MFMA 16x16x32 A operand: the fragments come straight from global memory (L1 / L2 hits: every chunk is used by KH KW taps),
@@ -328,6 +328,183 @@ __global__ __launch_bounds__(256, 2) void bwd_kernel(const uint16_t* __restrict_
             }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, one frame per iteration
+// The same product with a frame (t, b) as the unit of work -- the form the BASELINE layers take (at most 16 pooling windows per frame).
+// What the general kernel above spends its vector instructions on is the im2col image: 512 chunks per k tile, each with its own
+// (frame, height, tap) address and seven bounds checks.  Here the frame's input neighbourhood -- KW time steps x (heights + filter
+// margin) chunks, 260 for the BASELINE layer against the 832 im2col chunks of its 52 rows -- goes to LDS as it is, rows and time steps
+// outside the tensor as zeros, and a transposing read takes its four channels of (row, tap) straight from that block at
+// (kw HR + h + kh) 16 + (4-channel half) 8: the addresses of a lane's reads do not change from frame to frame, so the loop computes none.
+// The k dimension of a frame is its 4 Hp virtual rows padded to 32 or 64; G as above, one (window, 8-channel chunk) per thread.
+// The ones for the bias column and the zeros for taps / windows that do not exist are two constant chunks in LDS.
+constexpr int FR_MAX_CHUNKS = 512;          // chunks of the raw block: at most two per thread
+
+__global__ __launch_bounds__(256, 2) void bwd_frame_kernel(const uint16_t* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                          const uint16_t* __restrict__ x, float* __restrict__ part, Desc d, int HR,
+                                                          int nks, int frames_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [0, 16): a one in front (bias column); [16, 32): zeros; then two stages of { G: 32 nks rows x TP, raw block: KW x HR chunks }
+    const int g_bytes = 32 * nks * TP * 2, x_bytes = d.KW * HR * 16, stage_bytes = g_bytes + x_bytes;
+    char* const stages = smem + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int cb = blockIdx.y, Cp = d.Co >> 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int p = xcd * (int)(gridDim.x >> 3) + slot;       // an XCD's workgroups own a contiguous run of frames
+    const int f0 = p * frames_per_wg, f1 = min(d.frames, f0 + frames_per_wg);
+    if (tid < 8) reinterpret_cast<uint32_t*>(smem)[tid] = tid == 0 ? (uint32_t)f32_to_bf16(1.f) : 0u;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const unsigned gy_bytes = (unsigned)((long long)d.frames * d.Hp * Cp * 2);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)d.Ts * d.B * d.Hs * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc((void*)gy, 0, (int)gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_i = __builtin_amdgcn_make_buffer_rsrc((void*)idx, 0, (int)(gy_bytes >> 1), 0x00020000);
+
+    // raw block: chunk c = time slot c / HR (input time t + slot - pt), block row c % HR (input height row - ph)
+    const int nchunks = d.KW * HR;
+    int xc_off[2], xc_lo[2], xc_hi[2];
+    bool xc_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        const int sl = c / HR, r = c - sl * HR, h = r - d.ph, dt = sl - d.pt;
+        xc_row[i] = (c < nchunks) & ((unsigned)h < (unsigned)d.Hs);
+        xc_off[i] = (dt * d.B * d.Hs + h) * 16;
+        xc_lo[i] = -dt * d.B;                               // t + dt >= 0 <=> frame >= -dt B;  t + dt < Ts <=> frame < (Ts - dt) B
+        xc_hi[i] = (d.Ts - dt) * d.B;
+    }
+    // G: thread = (window tid >> 4, chunk tid & 15 = pairs 4 fc .. 4 fc + 3)
+    const int fw = tid >> 4, fc = tid & 15;
+    const bool g_row = fw < d.Hp;
+    const bool g_store = fw < 8 * nks;
+
+    struct Stage {
+        uint2 rg;
+        uint32_t ri;
+        u32x4 rx[2];
+    };
+    auto load_global = [&](Stage& st, int f) {
+        const bool fok = f < f1;
+        const unsigned at = ((unsigned)f * (unsigned)d.Hp + fw) * (unsigned)Cp + cb * 64 + 4 * fc;
+        const bool gok = fok & g_row;
+        const u32x2 rg = __builtin_amdgcn_raw_buffer_load_b64(rsrc_g, gok ? at * 2 : OOB, 0, 0);
+        st.rg = make_uint2(rg[0], rg[1]);
+        st.ri = __builtin_amdgcn_raw_buffer_load_b32(rsrc_i, gok ? at : OOB, 0, 0);
+        const unsigned fbase = (unsigned)f * (unsigned)d.Hs * 16u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = fok & xc_row[i] & (f >= xc_lo[i]) & (f < xc_hi[i]);
+            st.rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? fbase + (unsigned)xc_off[i] : OOB, 0, 0);
+        }
+    };
+    auto store_lds = [&](const Stage& st, int buf) {
+        char* const base = stages + buf * stage_bytes;
+        if (g_store) {
+            const uint32_t gv[4] = {st.rg.x & 0xffffu, st.rg.x >> 16, st.rg.y & 0xffffu, st.rg.y >> 16};
+            uint32_t val[4], row[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const uint32_t b = (st.ri >> (8 * jj)) & 0xffu;             // winner: 2 * row + (second channel of the pair)
+                val[jj] = (b & 1u) ? gv[jj] << 16 : gv[jj];
+                row[jj] = b >> 1;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i) {
+                uint4 o;
+                o.x = row[0] == i ? val[0] : 0u;
+                o.y = row[1] == i ? val[1] : 0u;
+                o.z = row[2] == i ? val[2] : 0u;
+                o.w = row[3] == i ? val[3] : 0u;
+                *reinterpret_cast<uint4*>(base + ((fw * 4 + i) * TP + fc * 8) * 2) = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + 256 * i < nchunks) *reinterpret_cast<u32x4*>(base + g_bytes + (tid + 256 * i) * 16) = st.rx[i];
+    };
+
+    // transposing reads: lane 4 q + pp of 16-lane group g points at k row 4 g + q (second read: 16 + 4 g + q), columns 4 pp .. 4 pp + 3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int trow0 = 4 * g + q, tcol = 4 * pp;
+    // X operand: k row (k step ks, half hf) = virtual row 32 ks + 16 hf + 4 g + q = window 8 ks + 4 hf + g, convolution row q of it;
+    // column tile j of this wave = taps 2 (4 wn + j) and + 1, this lane's tap by pp >> 1, its channel half by pp & 1
+    int xrow[2][2], xtap[4];
+    bool xabs[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int w = 8 * ks + 4 * hf + g;
+            xrow[ks][hf] = w < d.Hp ? (w * d.k + q) * 16 : -1;               // -1: a window that does not exist (G is zero there)
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tap = 2 * (4 * wn + j) + (pp >> 1);
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        xabs[j] = tap >= d.taps;                                             // the column of ones, or a tap that does not exist
+        xtap[j] = tap < d.taps ? 32 + g_bytes + (kw * HR + kh) * 16 + (pp & 1) * 8 : (tap == d.taps ? (pp & 1) * 8 : 16);
+    }
+    auto work = [&](int buf) {
+        const int sb = buf * stage_bytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < nks) {
+                const uint16_t* Gb = reinterpret_cast<const uint16_t*>(stages + sb) + ks * 32 * TP;
+                Frag a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ac = wm * 64 + i * 16 + tcol;
+                    a[i].h[0] = lds_tr16(Gb + trow0 * TP + ac);
+                    a[i].h[1] = lds_tr16(Gb + (trow0 + 16) * TP + ac);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int at = (xabs[i] | (xrow[ks][hf] < 0)) ? (xabs[i] ? xtap[i] : 16) : sb + xtap[i] + xrow[ks][hf];
+                        b[i].h[hf] = lds_tr16(reinterpret_cast<const uint16_t*>(smem + at));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = ASR_MFMA_16x16x32(a[i].v, b[j].v, acc[i][j]);
+            }
+        }
+    };
+
+    if (f0 < f1) {
+        Stage s0, s1;
+        load_global(s0, f0);
+        load_global(s1, f0 + 1);
+        store_lds(s0, 0);
+        __syncthreads();
+        for (int f = f0; f < f1; f += 2) {      // frames in pairs: the two register stages keep their names; a frame beyond f1 is all zeros
+            load_global(s0, f + 2);
+            work(0);
+            store_lds(s1, 1);
+            __syncthreads();
+            load_global(s1, f + 3);
+            work(1);
+            store_lds(s0, 0);
+            __syncthreads();
+        }
+    }
+    float* out = part + ((size_t)p * d.Co + cb * 128) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int gn = wn * 64 + j * 16 + (lane & 15);
+                out[gm * 128 + gn] = acc[i][j][r];
+            }
+}
+
 // gW[ch][ci][kh][kw] += sum_p part[p][ch][(kh KW + kw) 8 + ci],  gb[ch] += sum_p part[p][ch][8 KH KW]; blockIdx.y = a slice of the shares
 __global__ void bwd_reduce_kernel(const float* __restrict__ part, int nparts, float* __restrict__ gW, float* __restrict__ gb, Desc d) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,6 +609,29 @@ extern "C" int asr_conv_mp_bwd(void* stream_, const void* gy, const void* idx, c
     const int nparts = parts_for(Co, ktiles > 4096 ? 4096 : ktiles);
     const int kt_per_wg = (ktiles + nparts - 1) / nparts;
     hipStream_t stream = (hipStream_t)stream_;
+    // one frame per iteration where a frame has at most 16 pooling windows and its input neighbourhood at most 512 chunks
+    // (ASR_DEBUG conv_mp_frame=0: the general kernel)
+    // block rows: every height a (window, row, tap) can name; HR = 4 (mod 8) puts the two taps of a transposing read 64 bytes (mod 128) apart
+    int HR = d.Hp * k + KH + 3 > Hs + KH - 1 ? d.Hp * k + KH + 3 : Hs + KH - 1;
+    HR += (4 - HR % 8 + 8) % 8;
+    static int use_frame = -1;
+    if (use_frame < 0) use_frame = debug_flag("conv_mp_frame", 1);
+    if (use_frame && d.Hp <= 16 && KW * HR <= FR_MAX_CHUNKS && (long long)d.frames * Hs * 16 < (1ll << 31)) {
+        const int nks = d.Hp <= 8 ? 1 : 2;
+        const int lds = 32 + 2 * (32 * nks * TP * 2 + KW * HR * 16);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)bwd_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr = true; }
+        if (lds <= 64 * 1024) {
+            const int frames_per_wg = (d.frames + nparts - 1) / nparts;
+            hipLaunchKernelGGL(bwd_frame_kernel, dim3(nparts, Co / 128), dim3(256), lds, stream, (const uint16_t*)gy, (const uint8_t*)idx,
+                               (const uint16_t*)x8, (float*)workspace, d, HR, nks, frames_per_wg);
+            ASR_LAUNCH_CHECK();
+            const int slices_f = nparts >= 256 ? 16 : (nparts >= 64 ? 4 : 1);
+            hipLaunchKernelGGL(bwd_reduce_kernel, dim3((Co * 128 + 255) / 256, slices_f), dim3(256), 0, stream, (const float*)workspace, nparts, gW, gb, d);
+            ASR_LAUNCH_CHECK();
+            return ASR_OK;
+        }
+    }
     hipLaunchKernelGGL(bwd_kernel, dim3(nparts, Co / 128), dim3(256), 0, stream, (const uint16_t*)gy, (const uint8_t*)idx, (const uint16_t*)x8,
                        (float*)workspace, d, ktiles, kt_per_wg);
     ASR_LAUNCH_CHECK();

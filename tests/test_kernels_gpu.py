@@ -905,6 +905,19 @@ def test_fused_first_block_equals_convolution_maxout_pooling(device, T, B, Hin, 
     assert _rel(gW2.cpu(), (gW - 0.5).cpu()) < 1e-5
 
 
+def test_fused_first_block_backward_general_form_in_a_child_process(device):
+    """the backward kernel has two forms -- one frame per iteration (at most 16 pooling windows per frame: the default wherever it applies) and
+    the general one (virtual im2col rows); ASR_DEBUG conv_mp_frame=0 selects the general form for every shape: the same test cases again"""
+    import os, subprocess, sys
+    if "conv_mp_frame=0" in os.environ.get("ASR_DEBUG", ""):
+        pytest.skip("this IS the child process")
+    env = dict(os.environ, ASR_DEBUG=",".join(filter(None, [os.environ.get("ASR_DEBUG", ""), "conv_mp_frame=0"])))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "tests/test_kernels_gpu.py", "-k",
+                        "fused_first_block_equals"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-4000:]
+
+
 def _conv_nt_implicit(x, W2, bias, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     """asr_conv_nt with the direct kernel switched off: the float32-output form never dispatches to it"""
     from asr import _ops
