@@ -31,5 +31,5 @@ print("steps %d in %.2f s (%.2f ms per step), applied %d" % (N, dt, dt / N * 1e3
 print("loss:", ", ".join("%d: %.1f" % (i, float(l.detach())) for i, l in losses))
 print("ms per step between marks:", ", ".join("%.2f" % (marks[k][1].elapsed_time(marks[k + 1][1]) / (marks[k + 1][0] - marks[k][0])) for k in range(len(marks) - 1)))
 _ops.gru_check_all()
-assert opt.applied_steps() == N and all(bool(torch.isfinite(l)) for _, l in losses) and float(losses[-1][1]) < float(losses[0][1])
+assert opt.applied_steps() == N and all(bool(torch.isfinite(l.detach())) for _, l in losses) and float(losses[-1][1].detach()) < float(losses[0][1].detach())
 print("ok")
