@@ -543,6 +543,54 @@ def time_sru(dev, T=1000, B=32, D=512, iters=20):
             "fwd_frac": fb / f / 1e6 / 6300.0, "bwd_frac": bb / b / 1e6 / 6300.0}
 
 
+def time_features(dev, B=32, N=160672, iters=50):
+    """SURVEY 8(d) logfbank row (a1-a4 + a7): int16 signals resident in HBM -> (B, 3, 40, T) float32 normalised features, the two
+    kernels of asr.fft.Processor.logfbank_batch (specgram + mel + log in one, deltas + normalisation + layout in the other).
+    Algorithmic bytes: 2 N in + 3 * 40 * T * 4 out per utterance (0.8 MB at N = 160672 -> 1002 frames -> T = 1000); HIP events around
+    `iters` back-to-back kernel pairs on the launch stream (outputs preallocated: what the kernels cost), and the wall time of the
+    whole `logfbank_batch` call (host arithmetic, small H2D copies and allocations included: what a data loader pays)."""
+    from asr import fft
+    proc = fft.Processor(device=dev)
+    g = torch.Generator().manual_seed(0)
+    sig = torch.round(torch.randn(B, N, generator=g) * 3000).to(torch.int16).to(dev)
+    lens = [N] * B
+    mean = torch.zeros(3, 40)
+    std = torch.ones(3, 40)
+    x, xl = proc.logfbank_batch((sig, lens), mean.numpy(), std.numpy())
+    T = int(x.shape[3])
+    F = fft.num_frames(N, proc.frame_len, proc.frame_step)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=dev)
+    nfr = torch.tensor([F] * B, dtype=torch.int32, device=dev)
+    m, sd = mean.reshape(-1).to(dev), std.reshape(-1).to(dev)
+
+    def pair():
+        _, lm = fft._specgram(sig, lengths, nfr, F, proc.frame_len, proc.frame_step, proc.num_fft, 0.97, proc._window_d, proc._fbank_d, False)
+        return fft._deltas(lm, nfr, T, m, sd)
+    for _ in range(3):
+        pair()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        pair()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    t0 = time.perf_counter()
+    for _ in range(10):
+        proc.logfbank_batch((sig, lens), mean.numpy(), std.numpy())
+    torch.cuda.synchronize()
+    wall_us = (time.perf_counter() - t0) / 10 * 1e6
+    alg = B * (2.0 * N + 3 * 40 * T * 4)
+    flops = B * F * 45e3
+    return {"workload": "logfbank of %d x %d int16 samples -> (%d, 3, 40, %d) f32 (Hann-512, hop 160, 40 mels, deltas, normalised)" % (B, N, B, T),
+            "kernels": "asr::fbank::specgram (+ mel + log) and asr::fbank::deltas (+ normalisation)", "bound": "hbm",
+            "us_per_batch": us, "algorithmic_bytes": alg, "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "utterances_per_s": B / (us * 1e-6),
+            "gflops": flops / (us * 1e-6) / 1e9, "flops_note": "~45 kFLOP per frame (SURVEY 8d): the FFT, not the traffic, is what the kernel does",
+            "call_wall_us": wall_us, "step_share": "one batch of features per train step: us_per_batch against ms_per_step"}
+
+
 def settled_steps(step, steps, max_warmup=12):
     """`extra_configs` timing (one kept line had a 2.3 x outlier -- hipMalloc calls of the caching allocator inside a
     five-step region entered after two warm-ups, see asr/functions.py: _OnSide).  Warm-up runs until the allocator is quiescent -- two
@@ -1158,6 +1206,7 @@ def main():
                                            "utterance's last frame)" % (int(0.6 * T), T, float(xlr.float().mean().item())),
                                "ms_per_step": spr["ms_per_step"], "utterances_per_s": B * 1e3 / spr["ms_per_step"], "step_spread": spr,
                                "final_loss": float(lossr.item())}
+        out["features"] = time_features(dev, B)
         extra["gram_ctc"] = time_gram_ctc(dev, T, B, V, 120)
         extra["sru"] = time_sru(dev, T, B, 512)
         del model, opt

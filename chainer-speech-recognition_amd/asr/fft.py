@@ -1,7 +1,7 @@
 """Log-mel filterbank features on the GPU -- drop-in for asr/fft.py plus the batched path Processor uses.
 
-Same function names as the reference (asr/fft.py): ``get_specgram``, ``compute_logmel``, ``compute_deltas``,
-``compute_delta``, ``get_filterbanks``, ``hz2mel``, ``mel2hz``; they take / return torch GPU tensors where the
+Same function names as the reference (asr/fft.py): ``get_specgram``, ``augment_specgram``, ``compute_logmel``,
+``compute_deltas``, ``compute_delta``, ``get_filterbanks``, ``hz2mel``, ``mel2hz``; they take / return torch GPU tensors where the
 reference used NumPy arrays.  ``logfbank_batch`` is the fused batched form of
 Processor.extract_batch_features + features_to_minibatch (asr/data/processing.py:67-173) for a list of signals.
 The filterbank matrix and the window are small host-side constants built once (asr/fft.py:68-82,
@@ -81,6 +81,27 @@ def get_specgram(signal, samplerate=16000, winlen=0.025, winstep=0.01, nfft=512,
     window = _dev_const(winfunc(frame_len), dev)
     pspec, _ = _specgram(signal.reshape(1, -1).contiguous(), lengths, nfr, F, frame_len, frame_step, nfft, preemph, window, None, True)
     return pspec[0]
+
+
+def augment_specgram(pspec, change_speech_rate=True, change_vocal_tract=True):
+    """asr/fft.py:21-50 with the reference's signature and the reference's random draws: the speed factor, then the vocal-tract
+    ratio, each ``max(min(np.random.normal(1, 0.15), 1.2), 0.8)`` from NumPy's GLOBAL generator in that order, each drawn only when its
+    switch is on -- ``np.random.seed(s)`` before the call reproduces the reference's output for the same seed (tests/golden/augment.npz).
+    pspec: (F, nbins) power spectrum on the GPU; returns (int(F / speed), nbins): frame t is input frame int(t * speed), bin d is input
+    bin int(d * ratio) (the last bin beyond the end) -- one gather kernel (asr_augment_specgram).  The reference raises NameError for
+    change_speech_rate=False with change_vocal_tract=True (``new_length`` undefined, :41); here that case keeps the length."""
+    speed = max(min(np.random.normal(1, 0.15), 1.2), 0.8) if change_speech_rate == True else 1.0      # noqa: E712 (the reference's test)
+    ratio = max(min(np.random.normal(1, 0.15), 1.2), 0.8) if change_vocal_tract == True else 1.0      # noqa: E712
+    if change_speech_rate != True and change_vocal_tract != True:                                   # noqa: E712
+        return pspec
+    F = pspec.shape[0]
+    new_length = int(F / speed)
+    assert new_length > 0
+    dev = pspec.device
+    out = _ops_mod().augment_specgram(pspec.to(F32).contiguous().reshape(1, F, -1), torch.tensor([new_length], dtype=torch.int32, device=dev),
+                                      torch.tensor([speed], dtype=torch.float64, device=dev),
+                                      torch.tensor([ratio], dtype=torch.float64, device=dev), new_length)
+    return out[0]
 
 
 def compute_logmel(pspec, samplerate=16000, winlen=0.025, winstep=0.01, nfilt=26, nfft=512, lowfreq=0, highfreq=None,

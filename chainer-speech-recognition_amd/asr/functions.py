@@ -27,9 +27,13 @@ BF16, F32 = _ops.BF16, torch.float32       # BF16: the library's 16-bit activati
 # Weight-gradient GEMMs do not feed the activation-gradient chain: they run on a second HIP stream, beside the next
 # (earlier) layer's latency-bound GRU recurrence, which occupies only 64 of the 256 CUs.  The optimiser joins the stream.
 # One side stream per launching stream (a data prefetcher or an evaluation pass may launch from streams of their own).
-_SIDE = {"streams": {}, "origins": {}, "enabled": True, "dirty": set(), "keep": [],
+_SIDE = {"streams": {}, "origins": {}, "enabled": True, "dirty": set(), "keep": [], "keep_bytes": 0,
          "join_before_recurrence": _lib_debug("side_join", 0) != 0}
 _KEEP_LIMIT = 512       # tensors held for a side stream by a caller that never joins (see _OnSide)
+# ... and bytes: what a backward pass pins until the optimiser joins is every layer's gradient / column operand at once (hundreds of
+# MB per convolution at T = 1000, B = 32: DESIGN.md 14.2); several passes without a join (gradient accumulation, bare backward loops) stop
+# pinning beyond this and hand the older tensors to the allocator's own stream bookkeeping
+_KEEP_BYTES_LIMIT = int(_lib_debug("side_keep_gb", 48)) << 30
 
 
 def side_stream():
@@ -58,7 +62,18 @@ def join_side_stream():
         if origin is not None and origin.cuda_stream != cur.cuda_stream:
             origin.wait_stream(st)
     _SIDE["dirty"].clear()
-    del _SIDE["keep"][:]
+    release_side_keeps()
+
+
+def release_side_keeps(to_allocator=False):
+    """drop the references held for the side streams.  After a join they are stream-ordered already; `to_allocator`: no join happened (an
+    exception left the backward pass half queued, or the limits were hit) -- the allocator's record_stream bookkeeping takes over."""
+    keep = _SIDE["keep"]
+    if to_allocator:
+        for t, st in keep:
+            t.record_stream(st)
+    del keep[:]
+    _SIDE["keep_bytes"] = 0
 
 
 def _empty_chip_for_recurrence():
@@ -102,13 +117,12 @@ class _OnSide(object):
         self.side.wait_stream(torch.cuda.current_stream())
         _SIDE["dirty"].add(self.side)
         keep = _SIDE["keep"]
-        if len(keep) > _KEEP_LIMIT:         # nobody joins (a loop of bare backward passes): fall back to the allocator's own bookkeeping
-            for t, st in keep:
-                t.record_stream(st)
-            del keep[:]
+        if len(keep) > _KEEP_LIMIT or _SIDE["keep_bytes"] > _KEEP_BYTES_LIMIT:
+            release_side_keeps(to_allocator=True)   # nobody joins (a loop of bare backward passes): the allocator's own bookkeeping
         for t in self.tensors:
             if t is not None:
                 keep.append((t, self.side))
+                _SIDE["keep_bytes"] += t.numel() * t.element_size()
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self

@@ -104,6 +104,8 @@ class Optimizer(object):
             except BaseException:
                 if self.communicator is not None:
                     self.communicator.abort_backward()      # no listener / recurrence hooks left behind
+                from .functions import release_side_keeps
+                release_side_keeps(to_allocator=True)       # nothing stays pinned for a join that will not come
                 raise
         self._ensure_flat()
         from .functions import join_side_stream

@@ -705,8 +705,9 @@ __global__ void maxout2_pool_bwd_kernel(const uint16_t* __restrict__ x, const ui
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[e * pitch + threadIdx.x] = bsum[e];
         __syncthreads();
-        const int t = threadIdx.x;
-        if (t < c8n * 16) {
+        // 16 c8n = 2 C sums to fold: more than one round of the 256 threads once C > 128 (a single `if (t < 16 c8n)`
+        // round silently dropped the sums of e >= 256 / c8n, i.e. half of the bias gradient at C = 256)
+        for (int t = threadIdx.x; t < c8n * 16; t += blockDim.x) {
             const int e = t / c8n, c8 = t - e * c8n;
             float s = 0.f;
             for (int u = c8; u < 256; u += c8n) s += red[e * pitch + u];

@@ -9,10 +9,17 @@
 //   fft.compute_deltas asr/fft.py:6-19,90-99   delta[t] = (x[t+1] - x[t-1]) / 2 with edge padding, delta of delta, last 2 frames dropped
 //   Loader normalisation asr/data/loaders/base.py:22-24   (x - mean) / std per (channel, mel)
 //
-// specgram: one workgroup (256 threads) per frame: samples -> LDS with pre-emphasis and window, radix-2 FFT in LDS
-// (nfft/2 butterflies per stage, one barrier per stage), power spectrum, optional mel + log in the same kernel.
-// deltas:   one thread per (utterance, mel, t): reads 5 neighbouring log-mel frames, writes the three channels of the
-// reference's (B, 3, nmel, Tmax) float32 minibatch (zero padded beyond each utterance's length, asr/data/processing.py:124).
+// specgram, nfft = 512 (the reference's 0.032 s x 16 kHz: asr/data/processing.py:54) -- specgram512_kernel: persistent workgroups of four
+// waves, ONE FRAME PER WAVE.  The real 512-point transform is a 256-point complex one (z[n] = x[2n] + i x[2n+1]) plus a split pass; the 256
+// points live four per lane in registers, four radix-4 stages, three exchanges through a padded LDS plane private to the wave (no workgroup
+// barrier: a wave's LDS operations execute in order).  Twiddles and window are PER-LANE CONSTANTS (a lane meets the same butterfly of every
+// frame): computed once per wave with sincospi, no table, no sin/cos in the loop.  Four consecutive frames share one staged, pre-emphasised
+// span of samples (double-buffered: one workgroup barrier per four frames).  The mel stage runs on the filters' non-zero bands only (band
+// start / length found once per workgroup from the dense matrix the caller passes: 454 of 10280 entries at 40 x 257).
+// Other sizes: specgram_kernel, one workgroup per frame, radix-2 in LDS.
+// deltas:   a workgroup per (utterance, 64 frames): the 68 log-mel rows it needs come in as ONE contiguous block, staged in LDS; a wave
+// writes 64 consecutive frames of one (channel, mel) row of the reference's (B, 3, nmel, Tmax) float32 minibatch (zero padded beyond each
+// utterance's length, asr/data/processing.py:124).
 #include "common.hpp"
 #include "../../include/asr_hip.h"
 
@@ -87,6 +94,231 @@ __global__ __launch_bounds__(256) void specgram_kernel(const SigT* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ nfft = 512: one frame per wave
+namespace f512 {
+constexpr int kPts = 256;                           // complex points of the packed real transform
+constexpr int kPlane = kPts + (kPts >> 4) * 4;      // phys(p) = p + 4 (p >> 4): every exchange below is free of LDS bank conflicts
+constexpr int kFramesPerGroup = 4;                  // = waves of the workgroup
+constexpr int kSpanMax = 3 * 512 + 512;             // samples four frames span at frame_step <= 512
+constexpr int kMaxFilt = 128, kMaxTaps = 1024;      // sparse mel table in LDS (else: the dense rows from global memory)
+
+__device__ __forceinline__ int phys(int p) { return p + ((p >> 4) << 2); }
+
+// a wave's LDS operations execute in issue order: between a wave's own writes and its reads of other lanes' words only the compiler
+// has to be held back
+__device__ __forceinline__ void wave_exchange_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// forward radix-4 decimation-in-frequency butterfly on x[p] = x(j + p L/4): y[q] = sum_p x[p] (-i)^(p q), then y[q] *= w[q] (q = 1..3)
+__device__ __forceinline__ void bfly4(float (&xr)[4], float (&xi)[4]) {
+    const float ar = xr[0] + xr[2], ai = xi[0] + xi[2], cr = xr[0] - xr[2], ci = xi[0] - xi[2];
+    const float br = xr[1] + xr[3], bi = xi[1] + xi[3], er = xr[1] - xr[3], ei = xi[1] - xi[3];
+    xr[0] = ar + br; xi[0] = ai + bi;
+    xr[2] = ar - br; xi[2] = ai - bi;
+    xr[1] = cr + ei; xi[1] = ci - er;               // c - i e
+    xr[3] = cr - ei; xi[3] = ci + er;               // c + i e
+}
+__device__ __forceinline__ void twiddle(float (&xr)[4], float (&xi)[4], const float (&wr)[3], const float (&wi)[3]) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float r = xr[q] * wr[q - 1] - xi[q] * wi[q - 1], i = xr[q] * wi[q - 1] + xi[q] * wr[q - 1];
+        xr[q] = r; xi[q] = i;
+    }
+}
+// w[q - 1] = exp(-2 pi i j q / L)
+__device__ __forceinline__ void make_twiddles(int j, int L, float (&wr)[3], float (&wi)[3]) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        float sn, cs;
+        sincospif(2.0f * (float)(j * q) / (float)L, &sn, &cs);
+        wr[q - 1] = cs; wi[q - 1] = -sn;
+    }
+}
+
+template <typename SigT>
+__global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict__ signals, const int* __restrict__ lengths,
+                                                          long long sig_pitch, int frame_len, int frame_step, float preemph,
+                                                          const float* __restrict__ window, const int* __restrict__ nframes,
+                                                          int Fmax, int B, int groups_per_utt, float* __restrict__ pspec_out,
+                                                          const float* __restrict__ fbank, int nfilt, float* __restrict__ logmel_out) {
+    constexpr int nbins = 257;
+    __shared__ __attribute__((aligned(16))) float stage[2][kSpanMax];
+    __shared__ __attribute__((aligned(16))) float plane_re[kFramesPerGroup][kPlane], plane_im[kFramesPerGroup][kPlane];
+    __shared__ float ps[kFramesPerGroup][nbins + 3];
+    __shared__ float taps[kMaxTaps];
+    __shared__ int fstart[kMaxFilt], flen[kMaxFilt], foff[kMaxFilt];
+    __shared__ int sparse_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* pr = plane_re[wave];
+    float* pi_ = plane_im[wave];
+
+    // ---- once per workgroup: the non-zero band of every mel filter
+    if (logmel_out) {
+        for (int m = wave; m < nfilt && m < kMaxFilt; m += 4) {
+            int lo = nbins, hi = -1;
+            for (int k = lane; k < nbins; k += 64)
+                if (fbank[(size_t)m * nbins + k] != 0.f) { lo = min(lo, k); hi = max(hi, k); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+            if (lane == 0) { fstart[m] = hi < 0 ? 0 : lo; flen[m] = hi < 0 ? 0 : hi - lo + 1; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int off = 0;
+            for (int m = 0; m < nfilt && m < kMaxFilt; ++m) { foff[m] = off; off += flen[m]; }
+            sparse_ok = (nfilt <= kMaxFilt && off <= kMaxTaps) ? 1 : 0;
+        }
+        __syncthreads();
+        if (sparse_ok)
+            for (int m = wave; m < nfilt; m += 4)
+                for (int i = lane; i < flen[m]; i += 64) taps[foff[m] + i] = fbank[(size_t)m * nbins + fstart[m] + i];
+        __syncthreads();
+    }
+
+    // ---- once per wave: the lane's constants
+    float w0r[3], w0i[3], w1r[3], w1i[3], w2r[3], w2i[3];
+    make_twiddles(lane, 256, w0r, w0i);
+    make_twiddles(lane & 15, 64, w1r, w1i);
+    make_twiddles(lane & 3, 16, w2r, w2i);
+    float win[8];                       // window at samples 2 n, 2 n + 1 for the lane's points n = lane + 64 p
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i0 = 2 * (lane + 64 * p);
+        win[2 * p] = i0 < frame_len ? window[i0] : 0.f;
+        win[2 * p + 1] = i0 + 1 < frame_len ? window[i0 + 1] : 0.f;
+    }
+    float sr[3], si[3];                 // exp(-2 pi i k / 512) for the split pass: k = lane, lane + 64, 128
+    {
+        const int ks[3] = {lane, lane + 64, 128};
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            float sn, cs;
+            sincospif((float)ks[u] / 256.0f, &sn, &cs);
+            sr[u] = cs; si[u] = -sn;
+        }
+    }
+    const int span = 3 * frame_step + 512;
+    const int groups = B * groups_per_utt;
+    int buf = 0;
+    for (int g = blockIdx.x; g < groups; g += gridDim.x, buf ^= 1) {
+        const int b = g / groups_per_utt, f0 = (g - b * groups_per_utt) * kFramesPerGroup;
+        const int F = nframes[b];
+        if (f0 >= F) continue;          // (uniform over the workgroup)
+        const SigT* sig = signals + (size_t)b * sig_pitch;
+        const int N = lengths[b];
+        const int n0 = f0 * frame_step;
+        float* st = stage[buf];
+        // pre-emphasised samples of the four frames' span; the padding behind the signal is zero (framesig pads AFTER pre-emphasis)
+        for (int i = tid; i < span; i += 256) {
+            const int n = n0 + i;
+            float v = 0.f;
+            if (n < N) {
+                const float x = (float)sig[n];
+                v = n == 0 ? x : x - preemph * (float)sig[n - 1];
+            }
+            st[i] = v;
+        }
+        __syncthreads();                // (the other buffer is still being read by slower waves: two buffers, one barrier)
+        const int f = f0 + wave;
+        if (f >= F) continue;           // (per wave; no workgroup barrier below)
+        const float* fr = st + wave * frame_step;
+        float xr[4], xi[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float2 v = *reinterpret_cast<const float2*>(fr + 2 * (lane + 64 * p));
+            xr[p] = v.x * win[2 * p];
+            xi[p] = v.y * win[2 * p + 1];
+        }
+        // stage 0: L = 256, butterfly j = lane on points lane + 64 p
+        bfly4(xr, xi);
+        twiddle(xr, xi, w0r, w0i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pr[phys(lane + 64 * q)] = xr[q]; pi_[phys(lane + 64 * q)] = xi[q]; }
+        wave_exchange_fence();
+        // stage 1: L = 64, lane (j, m) = (lane & 15, lane >> 4) on points 64 m + j + 16 p
+        const int j1 = lane & 15, m1 = lane >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { xr[p] = pr[phys(64 * m1 + j1 + 16 * p)]; xi[p] = pi_[phys(64 * m1 + j1 + 16 * p)]; }
+        wave_exchange_fence();
+        bfly4(xr, xi);
+        twiddle(xr, xi, w1r, w1i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pr[phys(64 * m1 + j1 + 16 * q)] = xr[q]; pi_[phys(64 * m1 + j1 + 16 * q)] = xi[q]; }
+        wave_exchange_fence();
+        // stage 2: L = 16, lane (j, b) = (lane & 3, lane >> 2) on points 16 b + j + 4 p
+        const int j2 = lane & 3, b2 = lane >> 2;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { xr[p] = pr[phys(16 * b2 + j2 + 4 * p)]; xi[p] = pi_[phys(16 * b2 + j2 + 4 * p)]; }
+        wave_exchange_fence();
+        bfly4(xr, xi);
+        twiddle(xr, xi, w2r, w2i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pr[phys(16 * b2 + j2 + 4 * q)] = xr[q]; pi_[phys(16 * b2 + j2 + 4 * q)] = xi[q]; }
+        wave_exchange_fence();
+        // stage 3: L = 4, points 4 lane + p (16 contiguous bytes per plane), no twiddle
+        {
+            const float4 a = *reinterpret_cast<const float4*>(pr + phys(4 * lane));
+            const float4 c = *reinterpret_cast<const float4*>(pi_ + phys(4 * lane));
+            xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w;
+            xi[0] = c.x; xi[1] = c.y; xi[2] = c.z; xi[3] = c.w;
+        }
+        wave_exchange_fence();
+        bfly4(xr, xi);
+        // position 4 lane + q = (d3 d2 d1 d0) base 4 holds Z[k], k = (d0 d1 d2 d3): into natural order
+        {
+            const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pr[phys(kb + 64 * q)] = xr[q]; pi_[phys(kb + 64 * q)] = xi[q]; }
+        }
+        wave_exchange_fence();
+        // split pass: X[k] = E + W O, X[256 - k] = conj(E - W O), E = (Z[k] + conj Z[256 - k]) / 2, O = -i (Z[k] - conj Z[256 - k]) / 2,
+        // W = exp(-2 pi i k / 512); power = |X|^2 / 512.  Pairs k = lane, lane + 64 and (every lane, lane 0 stores) k = 128.
+        const size_t frame = (size_t)b * Fmax + f;
+        float* psw = ps[wave];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int k = u == 0 ? lane : (u == 1 ? lane + 64 : 128), kk = (256 - k) & 255;
+            const float ar = pr[phys(k)], ai = pi_[phys(k)], br = pr[phys(kk)], bi = pi_[phys(kk)];
+            const float er = ar + br, ei = ai - bi;             // 2 E
+            const float dr = ar - br, di = ai + bi;             // Z[k] - conj Z[256 - k];  2 O = -i (dr + i di) = (di, -dr)
+            const float tr = di * sr[u] + dr * si[u], ti = di * si[u] - dr * sr[u];     // 2 W O
+            const float pr_ = er + tr, pi2 = ei + ti, mr = er - tr, mi = ei - ti;
+            const float pk = (pr_ * pr_ + pi2 * pi2) * (1.0f / 2048.0f), pm = (mr * mr + mi * mi) * (1.0f / 2048.0f);
+            if (u < 2 || lane == 0) {
+                psw[k] = pk;
+                if (u < 2) psw[256 - k] = pm;
+                if (pspec_out) {
+                    pspec_out[frame * nbins + k] = pk;
+                    if (u < 2) pspec_out[frame * nbins + 256 - k] = pm;
+                }
+            }
+        }
+        if (logmel_out) {
+            wave_exchange_fence();
+            for (int m = lane; m < nfilt; m += 64) {
+                float acc = 0.f;
+                if (sparse_ok) {
+                    const float* w = taps + foff[m];
+                    const float* p = psw + fstart[m];
+                    const int n = flen[m];
+                    for (int i = 0; i < n; ++i) acc += p[i] * w[i];
+                } else {
+                    const float* w = fbank + (size_t)m * nbins;
+                    for (int k = 0; k < nbins; ++k) acc += psw[k] * w[k];
+                }
+                if (acc == 0.f) acc = 2.220446049250313e-16f;          // np.finfo(float).eps (asr/fft.py:64)
+                logmel_out[frame * nfilt + m] = logf(acc);
+            }
+            wave_exchange_fence();      // (the next frame's split pass writes ps again)
+        }
+    }
+}
+}  // namespace f512
+
 // log(pspec . fbank^T) for a caller-supplied power spectrum (F, nbins) -> (F, nfilt)
 __global__ void logmel_kernel(const float* __restrict__ pspec, const float* __restrict__ fbank, long long F, int nbins,
                               int nfilt, float* __restrict__ out) {
@@ -117,6 +349,54 @@ __global__ void deltas_kernel(const float* __restrict__ logmel, const int* __res
         if (t < F - 2) {
             const float* lm = logmel + (size_t)b * Fmax * nfilt + m;
             auto at = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return lm[(size_t)q * nfilt]; };
+            auto dl = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return (at(q + 1) - at(q - 1)) * 0.5f; };
+            v0 = at(t);
+            v1 = dl(t);
+            v2 = (dl(t + 1) - dl(t - 1)) * 0.5f;
+        }
+        if (mean) {     // the reference normalises the zero padding as well (asr/data/loaders/base.py:24)
+            v0 = (v0 - mean[m]) / stdv[m];
+            v1 = (v1 - mean[nfilt + m]) / stdv[nfilt + m];
+            v2 = (v2 - mean[2 * nfilt + m]) / stdv[2 * nfilt + m];
+        }
+        float* o = out + ((size_t)b * 3 * nfilt + m) * Tmax + t;
+        o[0] = v0;
+        o[(size_t)nfilt * Tmax] = v1;
+        o[(size_t)2 * nfilt * Tmax] = v2;
+    }
+}
+
+
+// the same through an LDS tile: workgroup = (utterance, 64 output frames); rows t0 - 2 .. t0 + 65 of the log-mel matrix are one contiguous
+// block of global memory (clamped rows at the utterance's ends); a wave then owns one mel row at a time and its lanes 64 consecutive
+// frames: 256-byte runs of the (B, 3, nmel, Tmax) output.  Row pitch nfilt + 1 (odd for the usual 40): conflict-free column reads.
+constexpr int kDeltaTile = 64, kDeltaMaxFilt = 64;
+__global__ __launch_bounds__(256) void deltas_tile_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes, int Fmax, int nfilt,
+                                                          int Tmax, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                          float* __restrict__ out) {
+    __shared__ float tile[(kDeltaTile + 4) * (kDeltaMaxFilt + 1)];
+    const int b = blockIdx.y, t0 = blockIdx.x * kDeltaTile;
+    const int F = nframes[b];
+    const int pitch = nfilt | 1;
+    const int rows = kDeltaTile + 4;
+    const bool any = t0 < F - 2;
+    if (any) {
+        const float* lm = logmel + (size_t)b * Fmax * nfilt;
+        for (int i = threadIdx.x; i < rows * nfilt; i += 256) {
+            const int r = i / nfilt, c = i - r * nfilt;
+            int q = t0 - 2 + r;
+            q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q);
+            tile[r * pitch + c] = lm[(size_t)q * nfilt + c];
+        }
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 63, t = t0 + tl;
+    if (t >= Tmax) return;
+    for (int m = threadIdx.x >> 6; m < nfilt; m += 4) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (t < F - 2) {
+            // at(q) = logmel[clamp(q)]; the tile row of frame q is q - t0 + 2 (rows are stored clamped already)
+            auto at = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return tile[(q - t0 + 2) * pitch + m]; };
             auto dl = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return (at(q + 1) - at(q - 1)) * 0.5f; };
             v0 = at(t);
             v1 = dl(t);
@@ -262,6 +542,21 @@ extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, c
     while ((1 << logn) < nfft) ++logn;
     if ((1 << logn) != nfft || nfft > kMaxFft || nfft < 64 || frame_len > nfft || frame_len <= 0) return ASR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    static const int fast = debug_flag("fbank_fast", 1);
+    if (fast && nfft == 512 && (frame_step & 1) == 0 && frame_step <= 512) {
+        // one frame per wave, persistent workgroups of four frames (4 workgroups per CU keep every SIMD at 4 waves)
+        const int gpu = (Fmax + f512::kFramesPerGroup - 1) / f512::kFramesPerGroup;
+        const long long groups = (long long)B * gpu;
+        const dim3 grid((unsigned)(groups < 1024 ? groups : 1024)), block(256);
+        if (sig_is_f32)
+            hipLaunchKernelGGL(f512::specgram512_kernel<float>, grid, block, 0, s, (const float*)signals, lengths, sig_pitch, frame_len,
+                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out);
+        else
+            hipLaunchKernelGGL(f512::specgram512_kernel<short>, grid, block, 0, s, (const short*)signals, lengths, sig_pitch, frame_len,
+                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     const dim3 grid(Fmax, B), block(256);
     if (sig_is_f32)
         hipLaunchKernelGGL(specgram_kernel<float>, grid, block, 0, s, (const float*)signals, lengths, sig_pitch, frame_len,
@@ -287,6 +582,13 @@ extern "C" int asr_deltas(void* stream, const float* logmel, const int32_t* nfra
                           const float* mean, const float* stdv, float* out) {
     if (!logmel || !nframes || !out || B <= 0 || Fmax <= 0 || nfilt <= 0 || Tmax <= 0) return ASR_ERR_BAD_ARG;
     if ((mean == nullptr) != (stdv == nullptr)) return ASR_ERR_BAD_ARG;
+    static const int fast = debug_flag("fbank_fast", 1);
+    if (fast && nfilt <= kDeltaMaxFilt) {
+        hipLaunchKernelGGL(deltas_tile_kernel, dim3((Tmax + kDeltaTile - 1) / kDeltaTile, B), dim3(256), 0, (hipStream_t)stream, logmel, nframes,
+                           Fmax, nfilt, Tmax, mean, stdv, out);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     long long g = ((long long)B * nfilt * Tmax + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(deltas_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, logmel, nframes, Fmax, nfilt, Tmax,

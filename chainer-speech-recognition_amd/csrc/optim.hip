@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void step_control_kernel(const float* __restri
     if (ls) {
         grad_scale /= ls[0];
         if (drop && !gave_up) {
-            ls[0] = fmaxf(ls[0] * 0.5f, 1.f / 16777216.f);        // below 1 when the unscaled gradients already leave the half range
+            // static scale (growth interval 0, chainer's loss_scaling(scale=s)): the step is dropped and counted, the scale stays
+            if (ls[2] > 0.f) ls[0] = fmaxf(ls[0] * 0.5f, 1.f / 16777216.f);   // below 1 when the unscaled gradients already leave the half range
             ls[1] = 0.f;
             ls[3] += 1.f;
         } else if (!drop) {

@@ -218,10 +218,28 @@ def test_eval_loop_on_a_model(device):
 
 
 def test_augment_specgram_against_reference(device):
-    """asr/fft.py:21-50 under the reference's seeds (tests/golden/augment.npz): bit-identical gather"""
-    from asr import _ops
+    """asr/fft.py:21-50 under the reference's seeds (tests/golden/augment.npz): the PUBLIC asr.fft.augment_specgram, seeded through
+    np.random.seed as the reference is, returns the reference's array bit for bit; then the batched kernel entry underneath"""
+    from asr import _ops, fft
     g = np.load(os.path.join(GOLD, "augment.npz"))
     pspec = g["pspec"].astype(np.float32)
+    pd1 = torch.from_numpy(pspec).to(device)
+    for seed, want, rate, tract in ((int(g["seed_both"]), g["aug_both"], True, True), (int(g["seed_speed"]), g["aug_speed"], True, False)):
+        np.random.seed(seed)
+        got = fft.augment_specgram(pd1, change_speech_rate=rate, change_vocal_tract=tract)
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got.cpu().numpy(), want.astype(np.float32))
+    np.random.seed(int(g["seed_both"]))
+    a = fft.augment_specgram(pd1)                                    # defaults = both, as in the reference
+    np.testing.assert_array_equal(a.cpu().numpy(), g["aug_both"].astype(np.float32))
+    state = np.random.get_state()[1].copy()
+    assert fft.augment_specgram(pd1, False, False) is pd1 and (np.random.get_state()[1] == state).all()      # nothing drawn, nothing done
+    np.random.seed(5)
+    r = max(min(np.random.normal(1, 0.15), 1.2), 0.8)
+    np.random.seed(5)
+    v = fft.augment_specgram(pd1, False, True).cpu().numpy()         # (NameError in the reference) vocal tract only: length kept
+    idx = np.minimum((np.arange(pspec.shape[1]) * r).astype(np.int64), pspec.shape[1] - 1)
+    np.testing.assert_array_equal(v, pspec[:, idx])
     for seed, want, use_ratio in ((int(g["seed_both"]), g["aug_both"], True), (int(g["seed_speed"]), g["aug_speed"], False)):
         rs = np.random.RandomState(seed)
         speed = max(min(rs.normal(1, 0.15), 1.2), 0.8)

@@ -331,10 +331,11 @@ def test_layernorm_one_sweep_backward(device, rows, D, C):
 
 
 @pytest.mark.parametrize("T,B,H,C,k", [(7, 3, 38, 64, 3), (5, 2, 13, 16, 2), (4, 2, 11, 24, 3), (3, 1, 4, 8, 2), (6, 2, 6, 32, 1),
-                                       (300, 16, 38, 64, 3)])
+                                       (300, 16, 38, 64, 3), (9, 4, 13, 128, 2), (9, 4, 13, 256, 2), (40, 8, 6, 256, 3), (5, 3, 4, 512, 2)])
 def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
     """asr_maxout2_pool_fwd / _bwd against asr_maxout2_* followed by asr_maxpool_h_* (cover_all windows, ties included):
-    bit-identical outputs and input gradients"""
+    bit-identical outputs and input gradients.  C = 256 / 512: the bias-gradient fold needs more than one round of the workgroup's
+    threads (half of db was dropped at C = 256)"""
     from asr import _ops
     g = torch.Generator().manual_seed(T * 100 + H)
     x = torch.randn(T, B, H, 2 * C, generator=g)
@@ -745,7 +746,9 @@ def test_step_control_with_a_loss_scale_on_the_device(device):
     for _ in range(5):
         c, s, a = step(grad * 256.0, scale=static)
     assert s[0] == 256.0 and a == 8
-    tiny = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device)            # S may go below 1 (gradients beyond the half range WITHOUT a scale)
+    c, s, a = step(bad, scale=static)                                   # a static scale stays put on an overflow too: dropped, counted
+    assert c[0] == 1.0 and a == 8 and s == [256.0, 0.0, 0.0, 1.0]
+    tiny = torch.tensor([1.0, 0.0, 7.0, 0.0], device=device)            # a dynamic S may go below 1 (gradients beyond the half range WITHOUT a scale)
     c, s, a = step(bad, scale=tiny)
     assert s[0] == 0.5 and s[3] == 1.0
     c, s, a = step(grad, scale=None)                                    # no scale: asr_step_control
