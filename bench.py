@@ -564,7 +564,7 @@ def time_features(dev, B=32, N=160672, iters=50):
     m, sd = mean.reshape(-1).to(dev), std.reshape(-1).to(dev)
 
     def pair():
-        _, lm = fft._specgram(sig, lengths, nfr, F, proc.frame_len, proc.frame_step, proc.num_fft, 0.97, proc._window_d, proc._fbank_d, False)
+        _, lm = fft._specgram(sig, lengths, nfr, F, proc.frame_len, proc.frame_step, proc.num_fft, 0.97, proc._window_d, proc._fbank_d, False, proc._bands_d)
         return fft._deltas(lm, nfr, T, m, sd)
     for _ in range(3):
         pair()

@@ -51,6 +51,10 @@ SIGNATURES = {
     "asr_ctc_loss_grad": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_float] + [c_void_p] * 4 + [c_size_t]),
     "asr_specgram": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_int,
                                c_void_p, c_void_p, c_int, c_void_p]),
+    "asr_mel_bands_bytes": (c_size_t, []),
+    "asr_mel_bands": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t]),
+    "asr_specgram_bands": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "asr_logmel": (c_int, [c_void_p] * 3 + [c_longlong, c_int, c_int, c_void_p]),
     "asr_deltas": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 3),
     "asr_batchnorm_stats": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_float, c_float] + [c_void_p] * 5),

@@ -56,7 +56,16 @@ def _dev_const(a, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=F32).to(device)
 
 
-def _specgram(signals, lengths, nframes, Fmax, frame_len, frame_step, nfft, preemph, window, fbank, want_pspec):
+def mel_bands(fbank):
+    """asr_mel_bands: the sparse form of a (nfilt, nbins) mel matrix on the device (band start / padded length / offset per filter + taps),
+    built once per matrix and handed to asr_specgram_bands with it"""
+    table = torch.empty(int(_lib.lib().asr_mel_bands_bytes()) // 4, dtype=torch.int32, device=fbank.device)
+    fb = fbank.to(F32).contiguous()
+    check(_lib.lib().asr_mel_bands(stream(), ptr(fb), fb.shape[0], fb.shape[1], ptr(table), table.numel() * 4), "asr_mel_bands")
+    return table
+
+
+def _specgram(signals, lengths, nframes, Fmax, frame_len, frame_step, nfft, preemph, window, fbank, want_pspec, bands=None):
     dev = signals.device
     B = signals.shape[0]
     nfilt = 0 if fbank is None else fbank.shape[0]
@@ -65,9 +74,10 @@ def _specgram(signals, lengths, nframes, Fmax, frame_len, frame_step, nfft, pree
     is_f32 = 1 if signals.dtype == F32 else 0
     if not is_f32 and signals.dtype != torch.int16:
         raise TypeError("signals must be int16 or float32")
-    rc = _lib.lib().asr_specgram(stream(), ptr(signals), is_f32, ptr(lengths), signals.stride(0), B, frame_len, frame_step, nfft,
-                                 float(preemph), ptr(window), ptr(nframes), Fmax, ptr(pspec), ptr(fbank), nfilt, ptr(logmel))
-    check(rc, "asr_specgram")
+    rc = _lib.lib().asr_specgram_bands(stream(), ptr(signals), is_f32, ptr(lengths), signals.stride(0), B, frame_len, frame_step, nfft,
+                                       float(preemph), ptr(window), ptr(nframes), Fmax, ptr(pspec), ptr(fbank), nfilt, ptr(logmel),
+                                       ptr(bands) if fbank is not None else None)
+    check(rc, "asr_specgram_bands")
     return pspec, logmel
 
 
@@ -174,7 +184,7 @@ class Processor(object):
         self.window = np.hanning(self.frame_len) if window_func == "hanning" else np.hamming(self.frame_len)
         self.fbank = get_filterbanks(nfft=self.num_fft, nfilt=num_mel_filters, samplerate=sampling_rate)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._window_d = self._fbank_d = None
+        self._window_d = self._fbank_d = self._bands_d = None
 
     def logfbank_batch(self, signals, mean=None, std=None, noise=None, apply_cmn=False, warp=None):
         """signals: list of 1-d int16 arrays/tensors (or a padded (B, N) tensor + lengths tuple).  Returns
@@ -184,13 +194,14 @@ class Processor(object):
         dev = self.device
         if self._window_d is None:
             self._window_d, self._fbank_d = _dev_const(self.window, dev), _dev_const(self.fbank, dev)
+            self._bands_d = mel_bands(self._fbank_d)        # the filters' non-zero bands, once per Processor
         if isinstance(signals, tuple):
             padded, lens = signals
             lens = [int(v) for v in lens]
             padded = padded.to(dev)
         else:
             lens = [int(len(s)) for s in signals]
-            host = np.zeros((len(signals), max(lens)), dtype=np.int16)
+            host = np.zeros((len(signals), (max(lens) + 3) // 4 * 4), dtype=np.int16)      # rows of 4 n samples: the four-sample loads of asr_specgram
             for i, s in enumerate(signals):
                 host[i, :lens[i]] = np.asarray(s.cpu() if isinstance(s, torch.Tensor) else s, dtype=np.int16)
             padded = torch.from_numpy(host).to(dev)
@@ -218,7 +229,7 @@ class Processor(object):
             logmel = compute_logmel(pspec.reshape(len(lens) * Fmax, -1), fbank=self._fbank_d).reshape(len(lens), Fmax, -1)
         else:
             _, logmel = _specgram(padded, lengths, nfr, Fmax, self.frame_len, self.frame_step, self.num_fft, 0.97,
-                                  self._window_d, self._fbank_d, False)
+                                  self._window_d, self._fbank_d, False, self._bands_d)
         m = None if mean is None else _dev_const(mean, dev).reshape(-1)
         s = None if std is None else _dev_const(std, dev).reshape(-1)
         x = _deltas(logmel, nfr, Tmax, m, s)

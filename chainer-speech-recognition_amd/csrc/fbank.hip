@@ -100,8 +100,9 @@ namespace f512 {
 constexpr int kPts = 256;                           // complex points of the packed real transform
 constexpr int kPlane = kPts + (kPts >> 4) * 4;      // phys(p) = p + 4 (p >> 4): every exchange below is free of LDS bank conflicts
 constexpr int kFramesPerGroup = 4;                  // = waves of the workgroup
-constexpr int kSpanMax = 3 * 512 + 512;             // samples four frames span at frame_step <= 512
-constexpr int kMaxFilt = 128, kMaxTaps = 1024;      // sparse mel table in LDS (else: the dense rows from global memory)
+constexpr int kSpanMax = 1024;                      // samples four frames span: 3 frame_step + 512, four per thread
+constexpr int kBandFilt = 64, kMaxTaps = 1024;      // asr_mel_bands' table: 3 x 64 ints + 1024 taps (else: the dense rows from global memory)
+constexpr int kMaxFilt = kBandFilt;
 
 __device__ __forceinline__ int phys(int p) { return p + ((p >> 4) << 2); }
 
@@ -139,43 +140,84 @@ __device__ __forceinline__ void make_twiddles(int j, int L, float (&wr)[3], floa
     }
 }
 
+
+// The mel matrix is triangles on a few bins each (454 of 10280 entries non-zero at 40 x 257): asr_mel_bands writes, once per matrix,
+//   int start[64], len8[64], off[64]; float taps[1024]
+// -- per filter its first non-zero bin, the band's length rounded up to a multiple of 8, the offset of its taps; the taps of a band in
+// ascending bin order, zeros behind its end.  len8[0] = -1: the matrix does not fit (more than 64 filters or 1024 padded taps); the
+// transform then reads the dense rows.  One workgroup; two passes over the dense matrix.
+__global__ __launch_bounds__(256) void mel_bands_kernel(const float* __restrict__ fbank, int nfilt, int nbins, int* __restrict__ table) {
+    __shared__ int lo[kBandFilt], hi[kBandFilt], off[kBandFilt], ok;
+    const int tid = threadIdx.x, lane = tid & 63;
+    float* taps = reinterpret_cast<float*>(table + 3 * kBandFilt);
+    for (int i = tid; i < kMaxTaps; i += 256) taps[i] = 0.f;
+    if (tid < kBandFilt) { lo[tid] = nbins; hi[tid] = -1; }
+    __syncthreads();
+    const bool fits = nfilt <= kBandFilt;
+    if (fits)
+        for (int e = tid; e < nfilt * nbins; e += 256)
+            if (fbank[e] != 0.f) {
+                const int m = e / nbins, k = e - m * nbins;
+                atomicMin(&lo[m], k);
+                atomicMax(&hi[m], k);
+            }
+    __syncthreads();
+    if (tid < 64) {
+        const int h = (fits && lane < nfilt) ? hi[lane] : -1;
+        const int len = h >= 0 ? ((h - lo[lane] + 1 + 7) & ~7) : 0;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int total = __shfl(incl, 63, 64);
+        const bool good = fits && total <= kMaxTaps;
+        off[lane] = incl - len;
+        if (h < 0) lo[lane] = 0;
+        table[lane] = lo[lane];
+        table[kBandFilt + lane] = good ? len : (lane == 0 ? -1 : 0);
+        table[2 * kBandFilt + lane] = incl - len;
+        if (lane == 0) ok = good ? 1 : 0;
+    }
+    __syncthreads();
+    if (ok)
+        for (int e = tid; e < nfilt * nbins; e += 256) {
+            const float v = fbank[e];
+            if (v != 0.f) {
+                const int m = e / nbins, k = e - m * nbins;
+                taps[off[m] + k - lo[m]] = v;
+            }
+        }
+}
+
 template <typename SigT>
 __global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict__ signals, const int* __restrict__ lengths,
                                                           long long sig_pitch, int frame_len, int frame_step, float preemph,
                                                           const float* __restrict__ window, const int* __restrict__ nframes,
                                                           int Fmax, int B, int groups_per_utt, float* __restrict__ pspec_out,
-                                                          const float* __restrict__ fbank, int nfilt, float* __restrict__ logmel_out) {
+                                                          const float* __restrict__ fbank, int nfilt, float* __restrict__ logmel_out,
+                                                          const int* __restrict__ bands) {
     constexpr int nbins = 257;
+    constexpr int kPsRow = 272;         // 257 bins + zeros: the mel loop reads whole groups of 8 taps
     __shared__ __attribute__((aligned(16))) float stage[2][kSpanMax];
-    __shared__ __attribute__((aligned(16))) float plane_re[kFramesPerGroup][kPlane], plane_im[kFramesPerGroup][kPlane];
-    __shared__ float ps[kFramesPerGroup][nbins + 3];
-    __shared__ float taps[kMaxTaps];
-    __shared__ int fstart[kMaxFilt], flen[kMaxFilt], foff[kMaxFilt];
+    __shared__ __attribute__((aligned(16))) float2 plane[kFramesPerGroup][kPlane];      // (re, im) of point p at phys(p)
+    __shared__ __attribute__((aligned(16))) float ps[kFramesPerGroup][kPsRow];
+    __shared__ __attribute__((aligned(16))) float taps[kMaxTaps];
+    __shared__ int fstart[kMaxFilt], flen8[kMaxFilt], foff[kMaxFilt];
     __shared__ int sparse_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* pr = plane_re[wave];
-    float* pi_ = plane_im[wave];
+    float2* pl = plane[wave];
+    float* psw = ps[wave];
 
-    // ---- once per workgroup: the non-zero band of every mel filter
+    // ---- once per workgroup: the mel filters' non-zero bands (asr_mel_bands' table: start, padded length, offset per filter and the
+    // taps, each band padded with zeros to a multiple of 8) -- one 16-byte load per thread
     if (logmel_out) {
-        for (int m = wave; m < nfilt && m < kMaxFilt; m += 4) {
-            int lo = nbins, hi = -1;
-            for (int k = lane; k < nbins; k += 64)
-                if (fbank[(size_t)m * nbins + k] != 0.f) { lo = min(lo, k); hi = max(hi, k); }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
-            if (lane == 0) { fstart[m] = hi < 0 ? 0 : lo; flen[m] = hi < 0 ? 0 : hi - lo + 1; }
+        const bool have = bands != nullptr && nfilt <= kBandFilt;
+        if (have) {
+            if (tid < kBandFilt) { fstart[tid] = bands[tid]; flen8[tid] = bands[kBandFilt + tid]; foff[tid] = bands[2 * kBandFilt + tid]; }
+            reinterpret_cast<float4*>(taps)[tid] = reinterpret_cast<const float4*>(bands + 3 * kBandFilt)[tid];
         }
+        for (int i = nbins + lane; i < kPsRow; i += 64) psw[i] = 0.f;
         __syncthreads();
-        if (tid == 0) {
-            int off = 0;
-            for (int m = 0; m < nfilt && m < kMaxFilt; ++m) { foff[m] = off; off += flen[m]; }
-            sparse_ok = (nfilt <= kMaxFilt && off <= kMaxTaps) ? 1 : 0;
-        }
-        __syncthreads();
-        if (sparse_ok)
-            for (int m = wave; m < nfilt; m += 4)
-                for (int i = lane; i < flen[m]; i += 64) taps[foff[m] + i] = fbank[(size_t)m * nbins + fstart[m] + i];
+        if (tid == 0) sparse_ok = (have && flen8[0] >= 0) ? 1 : 0;      // (a table that did not fit says so in its first length)
         __syncthreads();
     }
 
@@ -203,26 +245,46 @@ __global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict
     }
     const int span = 3 * frame_step + 512;
     const int groups = B * groups_per_utt;
+
+    // the samples of a group's span travel one group ahead of the transform: asked for before the wave starts on its frame, they are
+    // in registers when the next round stores them (raw: x[n] and x[n - 1]; the pre-emphasis is formed at the store)
+    // (the window loads above retire HERE: left pending, the compiler can only cover them inside the loop with vmcnt(0), which would also
+    // wait for the samples fetched one group ahead)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // thread tid owns samples 4 tid .. 4 tid + 3 of the span (span = 3 frame_step + 512 <= 1024 here): ONE aligned load of four samples + the
+    // sample in front of them, branch-free (a piece outside the signal loads the utterance's first samples and is dropped at the store)
+    typedef SigT sig4_t __attribute__((ext_vector_type(4)));
+    sig4_t cur;
+    SigT prv;
+    auto fetch = [&](int g) {
+        const int b = g / groups_per_utt, f0 = (g - b * groups_per_utt) * kFramesPerGroup;
+        const SigT* sig = signals + (size_t)b * sig_pitch;
+        const int N = f0 < nframes[b] ? lengths[b] : 0;
+        const int n = f0 * frame_step + 4 * tid;
+        const bool ok = 4 * tid < span && n < N;        // (the buffer behind a signal is the row's padding: sig_pitch >= N rounded up to 4)
+        cur = *reinterpret_cast<const sig4_t*>(sig + (ok ? n : 0));
+        prv = sig[ok && n > 0 ? n - 1 : 0];
+    };
+    int g = blockIdx.x;
+    if (g < groups) fetch(g);
     int buf = 0;
-    for (int g = blockIdx.x; g < groups; g += gridDim.x, buf ^= 1) {
+    for (; g < groups; g += gridDim.x, buf ^= 1) {
         const int b = g / groups_per_utt, f0 = (g - b * groups_per_utt) * kFramesPerGroup;
         const int F = nframes[b];
-        if (f0 >= F) continue;          // (uniform over the workgroup)
-        const SigT* sig = signals + (size_t)b * sig_pitch;
-        const int N = lengths[b];
-        const int n0 = f0 * frame_step;
+        const int N = f0 < F ? lengths[b] : 0, n = f0 * frame_step + 4 * tid;
         float* st = stage[buf];
         // pre-emphasised samples of the four frames' span; the padding behind the signal is zero (framesig pads AFTER pre-emphasis)
-        for (int i = tid; i < span; i += 256) {
-            const int n = n0 + i;
-            float v = 0.f;
-            if (n < N) {
-                const float x = (float)sig[n];
-                v = n == 0 ? x : x - preemph * (float)sig[n - 1];
-            }
-            st[i] = v;
+        if (4 * tid < span) {
+            const float x0 = (float)cur.x, x1 = (float)cur.y, x2 = (float)cur.z, x3 = (float)cur.w;
+            float4 v;
+            v.x = n < N ? x0 - (n > 0 ? preemph * (float)prv : 0.f) : 0.f;
+            v.y = n + 1 < N ? x1 - preemph * x0 : 0.f;
+            v.z = n + 2 < N ? x2 - preemph * x1 : 0.f;
+            v.w = n + 3 < N ? x3 - preemph * x2 : 0.f;
+            *reinterpret_cast<float4*>(st + 4 * tid) = v;
         }
         __syncthreads();                // (the other buffer is still being read by slower waves: two buffers, one barrier)
+        if (g + (int)gridDim.x < groups) fetch(g + gridDim.x);
         const int f = f0 + wave;
         if (f >= F) continue;           // (per wave; no workgroup barrier below)
         const float* fr = st + wave * frame_step;
@@ -237,34 +299,34 @@ __global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict
         bfly4(xr, xi);
         twiddle(xr, xi, w0r, w0i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[phys(lane + 64 * q)] = xr[q]; pi_[phys(lane + 64 * q)] = xi[q]; }
+        for (int q = 0; q < 4; ++q) pl[phys(lane + 64 * q)] = make_float2(xr[q], xi[q]);
         wave_exchange_fence();
         // stage 1: L = 64, lane (j, m) = (lane & 15, lane >> 4) on points 64 m + j + 16 p
         const int j1 = lane & 15, m1 = lane >> 4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { xr[p] = pr[phys(64 * m1 + j1 + 16 * p)]; xi[p] = pi_[phys(64 * m1 + j1 + 16 * p)]; }
+        for (int p = 0; p < 4; ++p) { const float2 v = pl[phys(64 * m1 + j1 + 16 * p)]; xr[p] = v.x; xi[p] = v.y; }
         wave_exchange_fence();
         bfly4(xr, xi);
         twiddle(xr, xi, w1r, w1i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[phys(64 * m1 + j1 + 16 * q)] = xr[q]; pi_[phys(64 * m1 + j1 + 16 * q)] = xi[q]; }
+        for (int q = 0; q < 4; ++q) pl[phys(64 * m1 + j1 + 16 * q)] = make_float2(xr[q], xi[q]);
         wave_exchange_fence();
         // stage 2: L = 16, lane (j, b) = (lane & 3, lane >> 2) on points 16 b + j + 4 p
         const int j2 = lane & 3, b2 = lane >> 2;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { xr[p] = pr[phys(16 * b2 + j2 + 4 * p)]; xi[p] = pi_[phys(16 * b2 + j2 + 4 * p)]; }
+        for (int p = 0; p < 4; ++p) { const float2 v = pl[phys(16 * b2 + j2 + 4 * p)]; xr[p] = v.x; xi[p] = v.y; }
         wave_exchange_fence();
         bfly4(xr, xi);
         twiddle(xr, xi, w2r, w2i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[phys(16 * b2 + j2 + 4 * q)] = xr[q]; pi_[phys(16 * b2 + j2 + 4 * q)] = xi[q]; }
+        for (int q = 0; q < 4; ++q) pl[phys(16 * b2 + j2 + 4 * q)] = make_float2(xr[q], xi[q]);
         wave_exchange_fence();
-        // stage 3: L = 4, points 4 lane + p (16 contiguous bytes per plane), no twiddle
+        // stage 3: L = 4, points 4 lane + p (32 contiguous bytes), no twiddle
         {
-            const float4 a = *reinterpret_cast<const float4*>(pr + phys(4 * lane));
-            const float4 c = *reinterpret_cast<const float4*>(pi_ + phys(4 * lane));
-            xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w;
-            xi[0] = c.x; xi[1] = c.y; xi[2] = c.z; xi[3] = c.w;
+            const float4 a = *reinterpret_cast<const float4*>(pl + phys(4 * lane));
+            const float4 c = *reinterpret_cast<const float4*>(pl + phys(4 * lane) + 2);
+            xr[0] = a.x; xi[0] = a.y; xr[1] = a.z; xi[1] = a.w;
+            xr[2] = c.x; xi[2] = c.y; xr[3] = c.z; xi[3] = c.w;
         }
         wave_exchange_fence();
         bfly4(xr, xi);
@@ -272,22 +334,21 @@ __global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict
         {
             const int kb = (lane >> 4) + 4 * ((lane >> 2) & 3) + 16 * (lane & 3);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { pr[phys(kb + 64 * q)] = xr[q]; pi_[phys(kb + 64 * q)] = xi[q]; }
+            for (int q = 0; q < 4; ++q) pl[phys(kb + 64 * q)] = make_float2(xr[q], xi[q]);
         }
         wave_exchange_fence();
         // split pass: X[k] = E + W O, X[256 - k] = conj(E - W O), E = (Z[k] + conj Z[256 - k]) / 2, O = -i (Z[k] - conj Z[256 - k]) / 2,
         // W = exp(-2 pi i k / 512); power = |X|^2 / 512.  Pairs k = lane, lane + 64 and (every lane, lane 0 stores) k = 128.
         const size_t frame = (size_t)b * Fmax + f;
-        float* psw = ps[wave];
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int k = u == 0 ? lane : (u == 1 ? lane + 64 : 128), kk = (256 - k) & 255;
-            const float ar = pr[phys(k)], ai = pi_[phys(k)], br = pr[phys(kk)], bi = pi_[phys(kk)];
-            const float er = ar + br, ei = ai - bi;             // 2 E
-            const float dr = ar - br, di = ai + bi;             // Z[k] - conj Z[256 - k];  2 O = -i (dr + i di) = (di, -dr)
+            const float2 za = pl[phys(k)], zb = pl[phys(kk)];
+            const float er = za.x + zb.x, ei = za.y - zb.y;             // 2 E
+            const float dr = za.x - zb.x, di = za.y + zb.y;             // Z[k] - conj Z[256 - k];  2 O = -i (dr + i di) = (di, -dr)
             const float tr = di * sr[u] + dr * si[u], ti = di * si[u] - dr * sr[u];     // 2 W O
-            const float pr_ = er + tr, pi2 = ei + ti, mr = er - tr, mi = ei - ti;
-            const float pk = (pr_ * pr_ + pi2 * pi2) * (1.0f / 2048.0f), pm = (mr * mr + mi * mi) * (1.0f / 2048.0f);
+            const float ar = er + tr, ai = ei + ti, mr = er - tr, mi = ei - ti;
+            const float pk = (ar * ar + ai * ai) * (1.0f / 2048.0f), pm = (mr * mr + mi * mi) * (1.0f / 2048.0f);
             if (u < 2 || lane == 0) {
                 psw[k] = pk;
                 if (u < 2) psw[256 - k] = pm;
@@ -301,11 +362,18 @@ __global__ __launch_bounds__(256) void specgram512_kernel(const SigT* __restrict
             wave_exchange_fence();
             for (int m = lane; m < nfilt; m += 64) {
                 float acc = 0.f;
-                if (sparse_ok) {
+                if (sparse_ok) {        // the band's taps in ascending order, eight at a time (zero taps behind the band's end)
                     const float* w = taps + foff[m];
                     const float* p = psw + fstart[m];
-                    const int n = flen[m];
-                    for (int i = 0; i < n; ++i) acc += p[i] * w[i];
+                    const int n8 = flen8[m];
+                    for (int i = 0; i < n8; i += 8) {
+                        const float4 wa = *reinterpret_cast<const float4*>(w + i), wb = *reinterpret_cast<const float4*>(w + i + 4);
+                        float pv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pv[u] = p[i + u];
+                        acc += pv[0] * wa.x; acc += pv[1] * wa.y; acc += pv[2] * wa.z; acc += pv[3] * wa.w;
+                        acc += pv[4] * wb.x; acc += pv[5] * wb.y; acc += pv[6] * wb.z; acc += pv[7] * wb.w;
+                    }
                 } else {
                     const float* w = fbank + (size_t)m * nbins;
                     for (int k = 0; k < nbins; ++k) acc += psw[k] * w[k];
@@ -531,10 +599,10 @@ __global__ void normalize_bcmt_kernel(float* __restrict__ x, const float* __rest
 using namespace asr;
 using namespace asr::fbank;
 
-extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch,
-                            int B, int frame_len, int frame_step, int nfft, float preemph, const float* window,
-                            const int32_t* nframes, int Fmax, float* pspec_out, const float* fbank, int nfilt,
-                            float* logmel_out) {
+static int specgram_launch(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch,
+                           int B, int frame_len, int frame_step, int nfft, float preemph, const float* window,
+                           const int32_t* nframes, int Fmax, float* pspec_out, const float* fbank, int nfilt,
+                           float* logmel_out, const void* bands) {
     if (!signals || !lengths || !window || !nframes || B <= 0 || Fmax <= 0 || frame_step <= 0) return ASR_ERR_BAD_ARG;
     if (!pspec_out && !logmel_out) return ASR_ERR_BAD_ARG;
     if (logmel_out && (!fbank || nfilt <= 0)) return ASR_ERR_BAD_ARG;
@@ -543,17 +611,21 @@ extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, c
     if ((1 << logn) != nfft || nfft > kMaxFft || nfft < 64 || frame_len > nfft || frame_len <= 0) return ASR_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     static const int fast = debug_flag("fbank_fast", 1);
-    if (fast && nfft == 512 && (frame_step & 1) == 0 && frame_step <= 512) {
-        // one frame per wave, persistent workgroups of four frames (4 workgroups per CU keep every SIMD at 4 waves)
+    // one frame per wave (nfft 512): four samples per load need 4-sample alignment of every group's first sample (frame_step % 4 == 0 does
+    // it: a group starts at frame 4 i), of the rows (sig_pitch % 4 == 0) and of the buffer; the span of four frames must fit 1024 samples
+    const size_t esz = sig_is_f32 ? 4 : 2;
+    if (fast && nfft == 512 && (frame_step & 3) == 0 && 3 * frame_step + 512 <= f512::kSpanMax && (sig_pitch & 3) == 0 &&
+        (((uintptr_t)signals) & (4 * esz - 1)) == 0 && (((uintptr_t)bands) & 15) == 0) {
+        // persistent workgroups of four frames (4 workgroups per CU keep every SIMD at 4 waves)
         const int gpu = (Fmax + f512::kFramesPerGroup - 1) / f512::kFramesPerGroup;
         const long long groups = (long long)B * gpu;
         const dim3 grid((unsigned)(groups < 1024 ? groups : 1024)), block(256);
         if (sig_is_f32)
             hipLaunchKernelGGL(f512::specgram512_kernel<float>, grid, block, 0, s, (const float*)signals, lengths, sig_pitch, frame_len,
-                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out);
+                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out, (const int*)bands);
         else
             hipLaunchKernelGGL(f512::specgram512_kernel<short>, grid, block, 0, s, (const short*)signals, lengths, sig_pitch, frame_len,
-                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out);
+                               frame_step, preemph, window, nframes, Fmax, B, gpu, pspec_out, fbank, nfilt, logmel_out, (const int*)bands);
         ASR_LAUNCH_CHECK();
         return ASR_OK;
     }
@@ -564,6 +636,32 @@ extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, c
     else
         hipLaunchKernelGGL(specgram_kernel<short>, grid, block, 0, s, (const short*)signals, lengths, sig_pitch, frame_len,
                            frame_step, nfft, logn, preemph, window, nframes, Fmax, pspec_out, fbank, nfilt, logmel_out);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+extern "C" int asr_specgram(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch,
+                            int B, int frame_len, int frame_step, int nfft, float preemph, const float* window,
+                            const int32_t* nframes, int Fmax, float* pspec_out, const float* fbank, int nfilt,
+                            float* logmel_out) {
+    return specgram_launch(stream, signals, sig_is_f32, lengths, sig_pitch, B, frame_len, frame_step, nfft, preemph, window, nframes, Fmax,
+                           pspec_out, fbank, nfilt, logmel_out, nullptr);
+}
+
+extern "C" int asr_specgram_bands(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch,
+                                  int B, int frame_len, int frame_step, int nfft, float preemph, const float* window,
+                                  const int32_t* nframes, int Fmax, float* pspec_out, const float* fbank, int nfilt,
+                                  float* logmel_out, const void* bands) {
+    return specgram_launch(stream, signals, sig_is_f32, lengths, sig_pitch, B, frame_len, frame_step, nfft, preemph, window, nframes, Fmax,
+                           pspec_out, fbank, nfilt, logmel_out, bands);
+}
+
+extern "C" size_t asr_mel_bands_bytes(void) { return (size_t)(3 * f512::kBandFilt + f512::kMaxTaps) * 4; }
+
+extern "C" int asr_mel_bands(void* stream, const float* fbank, int nfilt, int nbins, void* table, size_t table_bytes) {
+    if (!fbank || !table || nfilt <= 0 || nbins <= 0) return ASR_ERR_BAD_ARG;
+    if (table_bytes < asr_mel_bands_bytes() || (((uintptr_t)table) & 15) != 0) return ASR_ERR_WORKSPACE;
+    hipLaunchKernelGGL(f512::mel_bands_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fbank, nfilt, nbins, (int*)table);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -72,8 +72,10 @@ int asr_ctc_loss_grad(void* stream, const float* xs, const int32_t* label_unigra
  * (asr/data/loaders/base.py:22-24), batched over utterances.
  *   asr_specgram  signals (B, sig_pitch) int16 or f32, lengths (B); frame f of utterance b covers samples
  *                 [f*frame_step, f*frame_step+frame_len) zero padded, pre-emphasised, times window (frame_len);
- *                 nframes (B) frames are produced per utterance (grid is Fmax x B).  Writes the power spectrum
+ *                 nframes (B) frames are produced per utterance.  Writes the power spectrum
  *                 (B, Fmax, nfft/2+1) and/or log(pspec . fbank^T) (B, Fmax, nfilt); nfft a power of two <= 1024.
+ *                 nfft = 512 (the reference's frame, asr/data/processing.py:54) with frame_step % 4 == 0, sig_pitch % 4 == 0 and an
+ *                 aligned buffer: one frame per wave, 256-point complex radix-4 transform in registers; else one workgroup per frame.
  *   asr_logmel    log-mel of a caller-supplied power spectrum (F, nbins) with fbank (nfilt, nbins)
  *   asr_deltas    (B, Fmax, nfilt) log-mel -> the minibatch x (B, 3, nfilt, Tmax) f32: static / delta / delta-delta,
  *                 T_b = nframes[b] - 2 frames, zero beyond; mean/std (3, nfilt) optional
@@ -81,6 +83,16 @@ int asr_ctc_loss_grad(void* stream, const float* xs, const int32_t* label_unigra
 int asr_specgram(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch, int B,
                  int frame_len, int frame_step, int nfft, float preemph, const float* window, const int32_t* nframes,
                  int Fmax, float* pspec_out, const float* fbank, int nfilt, float* logmel_out);
+/*   asr_mel_bands       the sparse form of a mel matrix fbank (nfilt, nbins) (asr/fft.py:68-82 builds triangles: 454 of 10280 entries are
+ *                       non-zero at 40 x 257): per filter the first non-zero bin, the band length padded to a multiple of 8, the offset of its
+ *                       taps, then the taps -- written ONCE per matrix into a caller-owned table of asr_mel_bands_bytes() bytes (16-byte aligned)
+ *   asr_specgram_bands  asr_specgram with that table of ITS fbank (nbins = nfft / 2 + 1): the mel stage touches the bands only; a null table,
+ *                       or one whose matrix did not fit it (more than 64 filters / 1024 padded taps), falls back to the dense rows */
+size_t asr_mel_bands_bytes(void);
+int asr_mel_bands(void* stream, const float* fbank, int nfilt, int nbins, void* table, size_t table_bytes);
+int asr_specgram_bands(void* stream, const void* signals, int sig_is_f32, const int32_t* lengths, long long sig_pitch, int B,
+                       int frame_len, int frame_step, int nfft, float preemph, const float* window, const int32_t* nframes,
+                       int Fmax, float* pspec_out, const float* fbank, int nfilt, float* logmel_out, const void* bands);
 int asr_logmel(void* stream, const float* pspec, const float* fbank, long long F, int nbins, int nfilt, float* out);
 int asr_deltas(void* stream, const float* logmel, const int32_t* nframes, int B, int Fmax, int nfilt, int Tmax,
                const float* mean, const float* stdv, float* out);

@@ -1,0 +1,14 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, "chainer-speech-recognition_amd"); sys.path.insert(0, ".")
+from asr import fft
+from oracle import fft as offt
+rs = np.random.RandomState(1)
+sigs = [np.round(rs.randn(160672) * 3000).astype(np.int16) for _ in range(4)]
+x, xl = fft.Processor(device="cuda:0").logfbank_batch(sigs)
+xr, _ = offt.logfbank_minibatch(sigs[:1])
+d = np.abs(x[0].cpu().numpy() - xr[0])
+print("max", d.max(), "at", np.unravel_index(d.argmax(), d.shape))
+bad = np.argwhere(d > 2e-4)
+print(len(bad), bad[:20].tolist())
+print("per-frame max of channel 0:", np.round(d[0].max(axis=0)[:12], 6), np.round(d[0].max(axis=0)[-6:], 6))
