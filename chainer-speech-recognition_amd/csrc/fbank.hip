@@ -435,20 +435,22 @@ __global__ void deltas_kernel(const float* __restrict__ logmel, const int* __res
 }
 
 
-// the same through an LDS tile: workgroup = (utterance, 64 output frames); rows t0 - 2 .. t0 + 65 of the log-mel matrix are one contiguous
-// block of global memory (clamped rows at the utterance's ends); a wave then owns one mel row at a time and its lanes 64 consecutive
-// frames: 256-byte runs of the (B, 3, nmel, Tmax) output.  Row pitch nfilt + 1 (odd for the usual 40): conflict-free column reads.
-constexpr int kDeltaTile = 64, kDeltaMaxFilt = 64;
+// the same through an LDS tile: workgroup = (utterance, 32 output frames); rows t0 - 2 .. t0 + 33 of the log-mel matrix are one contiguous
+// block of global memory (clamped rows at the utterance's ends); a half wave then owns one mel row at a time and its lanes 32 consecutive
+// frames: whole 128-byte lines of the (B, 3, nmel, Tmax) output.  Row pitch nfilt | 1 (odd): conflict-free column reads.  1024 workgroups
+// at the BASELINE size (four per CU): the kernel is two dependent memory round trips, so it wants many workgroups in flight.
+constexpr int kDeltaTile = 32, kDeltaMaxFilt = 64;
 __global__ __launch_bounds__(256) void deltas_tile_kernel(const float* __restrict__ logmel, const int* __restrict__ nframes, int Fmax, int nfilt,
                                                           int Tmax, const float* __restrict__ mean, const float* __restrict__ stdv,
                                                           float* __restrict__ out) {
     __shared__ float tile[(kDeltaTile + 4) * (kDeltaMaxFilt + 1)];
+    __shared__ float smean[3 * kDeltaMaxFilt], sstd[3 * kDeltaMaxFilt];      // (read per mel row below: from LDS, not a memory round trip per row)
     const int b = blockIdx.y, t0 = blockIdx.x * kDeltaTile;
+    if (mean && (int)threadIdx.x < 3 * nfilt) { smean[threadIdx.x] = mean[threadIdx.x]; sstd[threadIdx.x] = stdv[threadIdx.x]; }
     const int F = nframes[b];
     const int pitch = nfilt | 1;
     const int rows = kDeltaTile + 4;
-    const bool any = t0 < F - 2;
-    if (any) {
+    if (t0 < F - 2) {
         const float* lm = logmel + (size_t)b * Fmax * nfilt;
         for (int i = threadIdx.x; i < rows * nfilt; i += 256) {
             const int r = i / nfilt, c = i - r * nfilt;
@@ -458,22 +460,28 @@ __global__ __launch_bounds__(256) void deltas_tile_kernel(const float* __restric
         }
     }
     __syncthreads();
-    const int tl = threadIdx.x & 63, t = t0 + tl;
+    const int tl = threadIdx.x & 31, t = t0 + tl;
     if (t >= Tmax) return;
-    for (int m = threadIdx.x >> 6; m < nfilt; m += 4) {
+    const bool live = t < F - 2;
+    // rows of frames t - 2 .. t + 2, clamped the way the reference pads (edge frames repeated): at(q) = logmel[clamp(q)],
+    // dl(q) = (at(clamp(q) + 1) - at(clamp(q) - 1)) / 2 with clamp(q) in [0, F - 1]
+    auto cl = [&](int q) -> int { return q < 0 ? 0 : (q > F - 1 ? F - 1 : q); };
+    const int c0 = cl(t - 1), c1 = cl(t), c2 = cl(t + 1);
+    const int r_t = (c1 - t0 + 2) * pitch;
+    const int r_d0a = (cl(c0 + 1) - t0 + 2) * pitch, r_d0b = (cl(c0 - 1) - t0 + 2) * pitch;       // dl(t - 1)
+    const int r_d1a = (cl(c1 + 1) - t0 + 2) * pitch, r_d1b = (cl(c1 - 1) - t0 + 2) * pitch;       // dl(t)
+    const int r_d2a = (cl(c2 + 1) - t0 + 2) * pitch, r_d2b = (cl(c2 - 1) - t0 + 2) * pitch;       // dl(t + 1)
+    for (int m = threadIdx.x >> 5; m < nfilt; m += 8) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (t < F - 2) {
-            // at(q) = logmel[clamp(q)]; the tile row of frame q is q - t0 + 2 (rows are stored clamped already)
-            auto at = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return tile[(q - t0 + 2) * pitch + m]; };
-            auto dl = [&](int q) -> float { q = q < 0 ? 0 : (q > F - 1 ? F - 1 : q); return (at(q + 1) - at(q - 1)) * 0.5f; };
-            v0 = at(t);
-            v1 = dl(t);
-            v2 = (dl(t + 1) - dl(t - 1)) * 0.5f;
+        if (live) {
+            v0 = tile[r_t + m];
+            v1 = (tile[r_d1a + m] - tile[r_d1b + m]) * 0.5f;
+            v2 = ((tile[r_d2a + m] - tile[r_d2b + m]) * 0.5f - (tile[r_d0a + m] - tile[r_d0b + m]) * 0.5f) * 0.5f;
         }
         if (mean) {     // the reference normalises the zero padding as well (asr/data/loaders/base.py:24)
-            v0 = (v0 - mean[m]) / stdv[m];
-            v1 = (v1 - mean[nfilt + m]) / stdv[nfilt + m];
-            v2 = (v2 - mean[2 * nfilt + m]) / stdv[2 * nfilt + m];
+            v0 = (v0 - smean[m]) / sstd[m];
+            v1 = (v1 - smean[nfilt + m]) / sstd[nfilt + m];
+            v2 = (v2 - smean[2 * nfilt + m]) / sstd[2 * nfilt + m];
         }
         float* o = out + ((size_t)b * 3 * nfilt + m) * Tmax + t;
         o[0] = v0;

@@ -69,9 +69,9 @@ def test_full_size_feature_batch(device):
     assert x.shape == (4, 3, 40, 1000) and (xl.cpu().numpy() == 1000).all()
     xr, _ = offt.logfbank_minibatch(sigs[:1])
     # float32 transform against the float64 oracle: the lowest mel bands sit on bins that pre-emphasis has taken down to 1e-3 of the
-    # spectrum's level, so their logarithm carries the transform's rounding relative to the LARGE bins: sigma ~5e-5 over the 120,000 values
-    # of an utterance, whose largest deviation is therefore 2 - 3e-4 (round 5's radix-4 kernel: 3.1e-4 at one (mel 0, frame) of this seed,
-    # every other value within 2e-4; the radix-2 kernel it replaced: 1.9e-4) -- the short signals above keep the 2e-4 bar
+    # spectrum's level, so in a few frames their logarithm carries the transform's rounding relative to the LARGE bins -- a heavy tail on a
+    # tiny error (round 5's radix-4 kernel, this seed: rms 2.5e-6 over the 120,000 values, 7 of them beyond 1e-4, one -- mel 0 of one
+    # frame -- at 3.1e-4; the radix-2 kernel it replaced drew 1.9e-4 as its largest).  The short signals above keep the 2e-4 bar.
     d = np.abs(x[0].cpu().numpy() - xr[0])
     assert d.max() <= 5e-4 and (d > 2e-4).sum() <= 3 and float(np.sqrt((d ** 2).mean())) <= 3e-5
 

@@ -12,3 +12,4 @@ print("max", d.max(), "at", np.unravel_index(d.argmax(), d.shape))
 bad = np.argwhere(d > 2e-4)
 print(len(bad), bad[:20].tolist())
 print("per-frame max of channel 0:", np.round(d[0].max(axis=0)[:12], 6), np.round(d[0].max(axis=0)[-6:], 6))
+print("rms", float(np.sqrt((d ** 2).mean())), "count > 2e-4:", int((d > 2e-4).sum()), "count > 1e-4:", int((d > 1e-4).sum()))
