@@ -723,6 +723,37 @@ def cnn_extra_in_a_child(args, nconv):
         return {"error": "child timed out"}
 
 
+def pmc_traffic_of_this_build():
+    """`roofline.traffic`: HBM bytes per launch of the recurrence kernels from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command (a process cannot read its own PMC counters: tools/profile_round.sh runs the passes, tools/pmc_traffic.py condenses them
+    into profiles/ and records the sha256 of the kernels' source).  A file taken on OTHER kernel sources is not quoted: the line then says
+    `traffic: null` and why."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
+    why = "no profiles/r*_pmc_traffic*.json"
+    for path in files:
+        try:
+            rec = json.load(open(path))
+        except ValueError:
+            continue
+        want = rec.get("source_sha256")
+        if not want:
+            why = "stale: %s carries no source hash (taken before round 5)" % os.path.basename(path)
+            continue
+        same = True
+        for name, digest in want.items():
+            with open(os.path.join(ROOT, "chainer-speech-recognition_amd", "csrc", name), "rb") as f:
+                same = same and hashlib.sha256(f.read()).hexdigest() == digest
+        if not same:
+            why = "stale: %s was taken on other kernel sources (csrc/gru.hip changed since)" % os.path.basename(path)
+            continue
+        sel = [v for k, v in rec["kernels"].items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k or "gru::bwd_ps_kernel" in k]
+        if sel:
+            return sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel), "profiles/" + os.path.basename(path)
+    return None, why
+
+
 def sq_profile():
     """per-kernel SQ counter summary of a `bench.py` step (rocprofv3 --pmc passes condensed by tools/pmc_sq.py into profiles/): a
     process cannot read its own PMC counters, so the line quotes the committed pass of this same command"""
@@ -1127,15 +1158,7 @@ def main():
         alg = 0.5 * (fwd_bytes + bwd_bytes)
         # measured HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, condensed
         # into profiles/ by tools/pmc_traffic.py (a process cannot read its own PMC counters)
-        traffic, traffic_src = None, None
-        pmc_path = next((os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic_v9.json")
-                         if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
-        if pmc_path is not None:
-            ks = json.load(open(pmc_path))["kernels"]
-            sel = [v for k, v in ks.items() if "gru::fwd_persistent_io_kernel" in k or "gru::bwd_wide_kernel" in k or "gru::bwd_ps_kernel" in k]
-            if sel:
-                traffic = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in sel) / sum(v["dispatches"] for v in sel)
-                traffic_src = "profiles/" + os.path.basename(pmc_path)
+        traffic, traffic_src = pmc_traffic_of_this_build()
         out["roofline"] = {"bound": "hbm", "regime": "latency chain (neither roof binds; priced against HBM as the contract asks)",
                            "kernel": "asr::gru::fwd_persistent_io_kernel / bwd_ps_kernel (one launch per layer)",
                            "hop_price_us": "0.8-1.0 (MI355X_MICROARCH.md: one producer -> consumer hop through the L2, <= 4 KB, idle chip)",

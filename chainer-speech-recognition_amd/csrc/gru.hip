@@ -1192,8 +1192,13 @@ __global__ __launch_bounds__(640, 3) void bwd_ps_kernel(const uint16_t* __restri
 // wave converts on its way from the LDS staging ring to memory (the gate waves, i.e. the step's critical chain, are untouched),
 // 2 store instructions per step instead of 3 and half the gate bytes in the CU's memory queue beside the hand-off (what-if builds of
 // round 2: -5 % per recurrence).  The backward kernel that reads them is bwd_ps_kernel<.., G16 = true>.
-template <int KSW, bool LOCAL, bool GI16, bool RING, bool G16 = false>
-__global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
+// MINW: waves per SIMD the register budget has to allow (__launch_bounds__): 3 (<= 168 VGPRs; the kernel takes 130) for the default, one
+// workgroup per CU; 4 (<= 128) for the four-row what-if of fwd_io_launch, where TWO workgroups share a CU -- a 6-wave workgroup lands on
+// the SIMDs as 2, 2, 1, 1, two of them as up to 4, 4, 2, 2, and at 136 allocated registers a fourth wave does not fit a SIMD: the second
+// workgroup of every CU then waits until the first has LEFT, which a persistent recurrence never does (measured: every workgroup with
+// id >= 256 arrived only after the first 256 had given up).
+template <int KSW, bool LOCAL, bool GI16, bool RING, bool G16 = false, int MINW = 3>
+__global__ __launch_bounds__(384, MINW) void fwd_persistent_io_kernel(const void* __restrict__ gi_, const uint16_t* __restrict__ whh,
                                                                 const float* __restrict__ bhh, float* __restrict__ hseq,
                                                                 uint16_t* hseq16, float* __restrict__ gates, unsigned* sync,
                                                                 int T, int B, int H, int ndir, int rows, int forge, int boff, int Bn) {
@@ -1205,10 +1210,12 @@ __global__ __launch_bounds__(384, 3) void fwd_persistent_io_kernel(const void* _
     float* oring = opring + BIO_GD * 3 * 8 * 16;                                      // [2][5: h r z n q][8 rows][16 units]
     int* s_abort = reinterpret_cast<int*>(oring + 2 * 5 * 8 * 16);
     const int G_ = LOCAL ? (Bn + rows - 1) / rows : (int)gridDim.y;
-    const int rec = LOCAL ? (int)(blockIdx.x & 7) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
+    // (MINW == 4: sixteen recurrences of four rows, two workgroups per CU -- the what-if of fwd_io_launch)
+    constexpr int recbits = MINW == 4 ? 4 : 3;
+    const int rec = LOCAL ? (int)(blockIdx.x & ((1 << recbits) - 1)) : (int)(blockIdx.z * gridDim.y + blockIdx.y);
     if (LOCAL && rec >= G_ * ndir) return;
     const int d = rec / G_, g = rec % G_;
-    const int j0 = (LOCAL ? (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 16, nwg = H / 16;
+    const int j0 = (LOCAL ? (int)(blockIdx.x >> recbits) : (int)blockIdx.x) * 16, nwg = H / 16;
     const int b0 = boff + g * rows, Bl = min(rows, boff + Bn - b0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const bool is_compute = w < 4, is_loader = w == 4, is_storer = w == 5;
@@ -2177,7 +2184,7 @@ using namespace asr::gru;
 extern "C" size_t asr_gru_sync_bytes(int B, int H, int ndir) {
     const int nrec_pad = (ndir * ((B + 3) / 4) + 7) & ~7;
     const size_t ps = ps_exchange_bytes(nrec_pad, H);                  // the partial-sum ring (bwd_ps_kernel)
-    const size_t ring = (size_t)8 * PS_RING * 8 * H * 2;               // the forward kernel's hand-off ring
+    const size_t ring = (size_t)16 * PS_RING * 8 * H * 2;              // the forward kernel's hand-off ring (16 recurrences: its four-row what-if)
     return 4096 + kShardBytes + (ps > ring ? ps : ring);               // control words, sharded counters, the larger exchange area
 }
 
@@ -2348,21 +2355,39 @@ extern "C" int asr_gru_fwd_accepts_bf16_gi(int T, int B, int H, int ndir, int mo
 static int fwd_io_launch(hipStream_t st, void* gi_any, int gi_bf16, const void* whh_bf16, const float* bhh, float* hseq, void* hseq_bf16,
                      float* gates, void* sync_ws, int T, int B, int H, int ndir, int mode, int gates_f16, int boff, int Bn) {
     const int ksw = (H / 32 + 3) / 4;
-    const int io_rows = 8, io_lds = kPersistLds;
+    // ASR_DEBUG gru_fwd_rows=4 (what-if of round 5, VERDICT r4 next 2: "hide the hand-off of one half slab behind the compute of the
+    // other"): recurrences of FOUR rows, sixteen of them, 2 x 256 workgroups that ask for 72 KB of LDS so that exactly two share a CU --
+    // the hardware then interleaves two independent half slabs per CU, each with its own waves (an upper bound for what one workgroup
+    // alternating between two half slabs could reach: there the halves would also queue for the same four compute waves).  Needs the
+    // full slab (all sixteen recurrences live: a grid whose workgroups partly leave at once starves the rest of dispatch slots), the
+    // ring hand-off, half gates and bf16 input projections (the default kernel instance).  Measured (tools/time_gru_fwd_rows.py,
+    // profiles/r05_gru_fwd_half_slabs_whatif.txt): 1.33 us per time step against 1.27 for the 8-row form, outputs bit-identical.
+    static const int rows_env = debug_flag("gru_fwd_rows", 8);
+    const bool rows4 = rows_env == 4 && (mode == 0 || mode == 8) && ndir * ((Bn + 3) / 4) == 16 && ksw == 4 && gi_bf16 && gates_f16;
+    const int io_rows = rows4 ? 4 : 8, io_lds = rows4 ? 72 * 1024 : kPersistLds;
+    const int nrecmax = rows4 ? 16 : 8;
     const int Gio = (Bn + io_rows - 1) / io_rows;
-    const bool local = (mode == 0 || mode == 4 || mode == 7 || mode == 8) && ndir * Gio <= 8;     // try the XCD-local hand-off
+    const bool local = (mode == 0 || mode == 4 || mode == 7 || mode == 8) && ndir * Gio <= nrecmax;     // try the XCD-local hand-off
     // data polling (kernel comment): the default of the XCD-local form; mode 4 keeps the flag line for comparison
     const int forge = (mode == 7 ? 1 : (local && (mode == 0 || mode == 8) && ksw >= 2 ? 8 : 0));
     static int ring_env = -1;
     if (ring_env < 0) ring_env = debug_flag("fwd_ring", 1);      // (0: the payload is polled in the bf16 sequence itself)
-    const bool use_ring = local && (forge & 8) && ring_env && io_rows == 8;
+    const bool use_ring = local && (forge & 8) && ring_env;
+    if (rows4 && !use_ring) return ASR_ERR_UNSUPPORTED;
     if (gates_f16 && !use_ring) return ASR_ERR_UNSUPPORTED;
     if (!use_ring && (forge & 8) && (boff != 0 || Bn != B)) return ASR_ERR_UNSUPPORTED;      // (slabs: not the form that fills / polls the whole sequence)
     if (use_ring) {
-        if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)8 * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
+        if (!clear_sync_fill(sync_ws, kShardBytes, (char*)sync_ws + kPsOffset, (size_t)nrecmax * PS_RING * 8 * H * 2, st)) return ASR_ERR_LAUNCH;
     } else if (!clear_sync_fill(sync_ws, kShardBytes, (forge & 8) ? hseq_bf16 : nullptr, (size_t)T * B * ndir * H * 2, st)) return ASR_ERR_LAUNCH;
     const int forge_k = forge | (fwd_poll_delay(H, use_ring) << 8);
-    const dim3 igrid = local ? dim3(8 * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
+    const dim3 igrid = local ? dim3(nrecmax * (H / 16)) : dim3(H / 16, Gio, ndir), iblock(384);
+    if (rows4) {
+        (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<4, true, true, true, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
+        hipLaunchKernelGGL((fwd_persistent_io_kernel<4, true, true, true, true, 4>), igrid, iblock, io_lds, st, gi_any, (const uint16_t*)whh_bf16, bhh, hseq,
+                           (uint16_t*)hseq_bf16, gates, (unsigned*)sync_ws, T, B, H, ndir, io_rows, forge_k, boff, Bn);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
 #define ASR_FWDIO_(K, L, G, R)                                                                                            \
     do {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)fwd_persistent_io_kernel<K, L, G, R>, hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds); \

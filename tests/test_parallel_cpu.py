@@ -330,3 +330,33 @@ def test_headline_of_a_full_record_fits_the_driver():
     full["config"]["workload"] = full["config"]["workload"] * 40
     text = bench.headline(full)
     assert len(text.encode()) < 4096 and json.loads(text)["value"] == line["value"]
+
+
+def test_bench_line_quotes_pmc_traffic_only_from_the_same_kernel_sources(tmp_path):
+    """`roofline.traffic` comes from a committed rocprofv3 --pmc pass; a pass taken on other kernel sources must not end
+    up in a fresh line -- bench.pmc_traffic_of_this_build compares the sha256 the pass recorded with the sources that are there now."""
+    import hashlib
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_traffic", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = tmp_path / "chainer-speech-recognition_amd" / "csrc"
+    src.mkdir(parents=True)
+    (src / "gru.hip").write_text("kernel v1")
+    (tmp_path / "profiles").mkdir()
+    bench.ROOT = str(tmp_path)
+    assert bench.pmc_traffic_of_this_build()[0] is None                                   # nothing there
+    kernels = {"asr::gru::fwd_persistent_io_kernel<4>": {"dispatches": 4, "hbm_bytes_per_dispatch": 100.0},
+               "asr::gru::bwd_ps_kernel<2>": {"dispatches": 4, "hbm_bytes_per_dispatch": 300.0}, "other": {"dispatches": 9, "hbm_bytes_per_dispatch": 1e9}}
+    rec = {"kernels": kernels, "source_sha256": {"gru.hip": hashlib.sha256(b"kernel v1").hexdigest()}}
+    (tmp_path / "profiles" / "r05_pmc_traffic.json").write_text(json.dumps(rec))
+    traffic, source = bench.pmc_traffic_of_this_build()
+    assert traffic == 200.0 and source == "profiles/r05_pmc_traffic.json"
+    (src / "gru.hip").write_text("kernel v2")                                             # the kernel changed: the pass is stale
+    traffic, source = bench.pmc_traffic_of_this_build()
+    assert traffic is None and "stale" in source
+    (tmp_path / "profiles" / "r04_pmc_traffic.json").write_text(json.dumps({"kernels": kernels}))      # an old pass without a hash: never quoted
+    (src / "gru.hip").write_text("kernel v1")
+    assert bench.pmc_traffic_of_this_build()[1] == "profiles/r05_pmc_traffic.json"

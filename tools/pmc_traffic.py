@@ -4,7 +4,19 @@ Units and correction as MI355X_MICROARCH.md (HBM section) prescribes: both count
 half of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is.
 usage: pmc_traffic.py fetch_summary.csv write_summary.csv out.json
 """
-import csv, json, sys
+import csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hashes():
+    """sha256 of the kernel sources the bench line's `roofline.traffic` speaks about: bench.py quotes this file only while they are unchanged"""
+    out = {}
+    for name in ("gru.hip", "common.hpp"):
+        with open(os.path.join(ROOT, "chainer-speech-recognition_amd", "csrc", name), "rb") as f:
+            out[name] = hashlib.sha256(f.read()).hexdigest()
+    return out
+
 
 def load(path, counter):
     out = {}
@@ -21,7 +33,8 @@ def main(fetch_csv, write_csv, out_json):
         wb = w.get(k, (0, 0.0))[1] * 1024.0
         res[k] = {"dispatches": f.get(k, w.get(k))[0], "fetch_bytes_per_dispatch": fb, "write_bytes_per_dispatch": wb,
                   "hbm_bytes_per_dispatch": fb + wb}
-    json.dump({"note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024, mean per dispatch", "kernels": res},
+    json.dump({"note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction) + WRITE_SIZE KiB x 1024, mean per dispatch", "kernels": res,
+               "source_sha256": source_hashes()},
               open(out_json, "w"), indent=1, sort_keys=True)
 
 if __name__ == "__main__":
