@@ -70,6 +70,8 @@ SIGNATURES = {
     "asr_ctc_collapse": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2),
     "asr_edit_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "asr_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 4),
+    "asr_gemm_nt_8ph_ok": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int]),
+    "asr_gemm_nt_8ph": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int]),
     "asr_conv_nt": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
     "asr_conv_direct_ok": (c_int, [c_int] * 11),
     "asr_conv_direct_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),

@@ -36,6 +36,22 @@ def gemm_nt(a, b, bias=None, out_dtype=BF16, out=None):
     return out
 
 
+def gemm_nt_8ph(a, b, bias=None, out_dtype=BF16, out=None):
+    """gemm_nt on the 256 x 256 tile / eight-wave kernel only (asr_gemm_nt_8ph: tests and timings; asr_gemm_nt routes to it by itself);
+    raises when the product does not qualify (K % 64, N % 4, alignment)"""
+    assert a.dtype == BF16 and b.dtype == BF16 and a.dim() == 2 and b.dim() == 2
+    assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] == b.shape[1]
+    M, K = a.shape
+    N = b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    assert out.stride(1) == 1
+    rc = _lib.lib().asr_gemm_nt_8ph(stream(), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                                    out.stride(0), ptr(bias), M, N, K, _is_bf16(out))
+    check(rc, "asr_gemm_nt_8ph")
+    return out
+
+
 def gemm_tn_acc(a, b, c):
     """c[M,N] += a[K,M]^T @ b[K,N]; a, b bf16 row-major (unit inner stride), c f32."""
     assert a.dtype == BF16 and b.dtype == BF16 and c.dtype == F32

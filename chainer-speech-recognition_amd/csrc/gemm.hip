@@ -1495,6 +1495,18 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
     const bool b_fits_l2 = (size_t)N * K * 2 <= (size_t)5 * 512 * 1024;      // 2.5 MB of the 4 MB per XCD
     const bool aligned = (lda % 8) == 0 && (ldb % 8) == 0 && (((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0;
     {
+        // The 256 x 256 tile / eight-wave kernel of csrc/gemm8.hip wherever it qualifies (K % 64 == 0, N % 4 == 0, aligned) -- measured against
+        // the kernels below (tools/time_nt8.py, us, same process, alternating): 32000 x 512 x 3072 118 -> 73, x 3072 x 512 122 -> 106, x 384 x 3072
+        // 109 -> 72, x 3072 x 384 104 -> 92, x 3000 x 320 (f32) 151 -> 121, x 512 x 640 32 -> 25, 8192^3 1082 -> 753 (1017 -> 1460 TFLOP/s) -- except
+        // where short K meets a ragged last column tile (32000 x 640 x 512: a third 256-wide tile for 128 columns, 34 -> 36).
+        // ASR_DEBUG nt_8ph=0: never (comparison, and the tests that pin the kernels below).
+        static const int use8 = debug_flag("nt_8ph", 1);
+        const long long n_padded = (long long)cdiv(N, 256) * 256;
+        if (use8 && nt_wide_mode() <= 0 && (K >= 1024 || n_padded * 10 <= (long long)N * 11) && M >= 256 &&
+            asr_gemm_nt_8ph_ok(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16))
+            return asr_gemm_nt_8ph(stream_, A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16);
+    }
+    {
         const int wide = nt_wide_mode() > 0 ? nt_wide_mode() : 0;      // plain GEMMs: only on request
         if (wide && aligned && (K % ((wide == 2 || wide == 4) ? 64 : 32)) == 0 && N >= 256 && ((long long)cdiv(M, 256) * cdiv(N, 256) >= 512 || nt_wide_force())) {
             if (out_bf16) return launch_nt_wide<uint16_t, false>(stream, (const uint16_t*)A, lda, (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, b_fits_l2, ConvDesc{}, wide);

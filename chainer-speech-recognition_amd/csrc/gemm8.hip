@@ -1,0 +1,285 @@
+// NT GEMM, 256 x 256 tile, eight waves in two staggered groups: C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]), bf16 operands, K % 64 == 0.
+//
+// The one-barrier-per-K-step kernels of gemm.hip leave the matrix pipes 20 - 28 % busy (profiles/r04_pmc_sq.json): every K step a wave
+// reads its fragments, issues its MFMAs and then waits for the next stage, and what hides that wait is only the other workgroups of the CU.
+// This kernel is the "8-phase" schedule of the CDNA guide (cdna_hip_programming.md section 5), written for this library's conventions:
+//
+//  * ONE workgroup of 8 waves per CU: 2 (M) x 4 (N), a wave owns 128 x 64 of the tile = 8 x 4 MFMA tiles (128 accumulator registers).
+//    Waves i and i + 4 share a SIMD; the two M-halves (wm = 0 / 1) run ONE BARRIER APART, so that on every SIMD one wave is in its
+//    compute segment (16 MFMAs) while its partner is in its load segment (fragment reads + one LDS-DMA half tile): the matrix pipe of a
+//    SIMD is handed from one wave to the other at every barrier.
+//  * A K step of 64 is FOUR phases, one quadrant of the wave's tile each: (A half 0, B half 0), (A0, B1), (A1, B1), (A1, B0); a phase
+//    reads only the half it has not yet in registers (12 / 4 / 8 / 0 ds_read_b128: B half 0 stays in registers for its second use).
+//    phase := [fragment reads; LDS-DMA of one half tile; s_waitcnt vmcnt(8); s_barrier] [lgkmcnt(0); 16 MFMAs at raised priority; s_barrier]
+//  * LDS: 2 (parity of the K step) x {A0, A1, B0, B1} x 16 KiB = 128 KiB.  A "half tile" is 128 rows x 64 k: for A the 64 rows of each
+//    M-half's quadrant row block, for B the 32 columns of each of the four N-waves' quadrant column block -- the loader picks its source
+//    rows freely (LDS-DMA: lane-linear destination, per-lane source), so LDS row rho of a half tile simply IS the row the reader wants.
+//    Rows are 128 B; 16-B chunk c of row rho sits at position c ^ (rho & 7) (source-side swizzle, the same XOR on the read).
+//  * Four half tiles (8 LDS-DMA instructions per thread) are always in flight: the half tile issued in phase p is read six (A0) or five
+//    phases later, and `vmcnt(8)` at the end of every load segment retires exactly the half tile the NEXT phase reads -- never a
+//    vmcnt(0) in the loop.  Issue order: ... A1(t+1) | A0(t+2) B0(t+2) B1(t+2) A1(t+2) | ... in phases (t,Q1) (t,Q2) (t,Q3) (t+1,Q0) (t+1,Q1).
+//    Read-after-DMA: the wait that retires a half tile sits in the load segment BEFORE the one that reads it, in every wave, with a
+//    barrier between (the guide's rule "read a staged buffer one phase after the wait that retires it"; with the two groups one barrier
+//    apart every reader is still at least one barrier behind every waiter).  Write-after-read: a region is restaged two or three phases
+//    after its last fragment read (two: the other group's reads of that phase are retired by its lgkmcnt(0) one barrier later).
+//  * Beyond the last K step the loader re-fetches the last step into regions nobody reads any more: the loop has no tail variants and
+//    the in-flight count stays what vmcnt(8) assumes.
+//  * Epilogue from the accumulators: B's LDS rows are dealt such that lane (q, r) holds columns 4 r .. 4 r + 3 of rows 4 q + reg:
+//    one 8-byte (bf16) or 16-byte (f32) store per row, 16 lanes = 128 / 256 contiguous bytes.
+#include <type_traits>
+
+#include "common.hpp"
+#include "../../include/asr_hip.h"
+
+namespace asr {
+namespace gemm8 {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+union Frag {
+    bf16x8 v;
+    uint4 u;
+    u32x4 w;
+};
+
+// 16 B out of LDS by inline asm, NOT waited for here: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it can see in a kernel
+// that also uses LDS-DMA (the DMA writes LDS and may alias), which would drain the four half tiles in flight at every phase.  The
+// compute segment opens with s_waitcnt lgkmcnt(0) + sched_barrier(0) (an MFMA is register-only: only the scheduling barrier keeps it
+// behind the wait).
+template <int OFF>
+__device__ __forceinline__ void lds_rd16(Frag& f, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.w) : "v"(addr), "n"(OFF) : "memory");
+}
+
+constexpr int HALF = 128 * 64 * 2;          // one half tile: 128 rows x 64 k of bf16 = 16 KiB
+constexpr int LDS_BYTES = 8 * HALF;         // [2 parities][A0 A1 B0 B1]
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voffset, soffset, 0, 0);
+}
+
+#define ASR8_LOAD_END() asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory")
+#define ASR8_COMPUTE_BEGIN()                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    __builtin_amdgcn_s_setprio(1)
+#define ASR8_COMPUTE_END()                                   \
+    __builtin_amdgcn_s_setprio(0);                           \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    asm volatile("s_barrier" ::: "memory")
+
+template <typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
+                                                            OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    // tiles: XCD x (= bid % 8 under round-robin dispatch; a locality hint only) takes a contiguous range of tile ids, so the column tiles of a
+    // row panel of A meet in one L2.  The map is a bijection for any number of tiles.
+    int wg;
+    {
+        const int nwg = tiles_m * tiles_n, qq = nwg >> 3, rr = nwg & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq) + idx;
+    }
+    const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = K >> 6;
+
+    // ---- loader: slot s = i * 512 + tid of a half tile = (LDS row rho = s / 8, position s % 8), holding chunk (s % 8) ^ (rho % 8)
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+    unsigned oa[2][2], ob[2][2];            // [half][i]: byte offset of this thread's source chunk at k = 0
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = i * 512 + tid, rho = s >> 3, c = (s & 7) ^ (rho & 7);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // A half h: LDS row rho = wm' * 64 + rr  <-  row m0 + wm' * 128 + h * 64 + rr
+            const int grow = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63);
+            oa[h][i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
+            // B half h: LDS row rho = wn' * 32 + j * 16 + r  <-  column n0 + wn' * 64 + 4 r + (2 h + j)
+            const int gcol = n0 + (rho >> 5) * 64 + 4 * (rho & 15) + 2 * h + ((rho >> 4) & 1);
+            ob[h][i] = (unsigned)min(gcol, N - 1) * (unsigned)(ldb * 2) + (unsigned)(c * 16);
+        }
+    }
+    // KIND: 0 A0, 1 A1, 2 B0, 3 B1; region (PAR, KIND) at (PAR * 4 + KIND) * HALF
+    auto issue = [&](auto kind_c, auto par_c, int kt) {
+        constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value;
+        char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
+        const int so = kt * 128;
+        if (KIND < 2) {
+            lds_dma16(rsrc_a, base, oa[KIND & 1][0], so);
+            lds_dma16(rsrc_a, base + 8192, oa[KIND & 1][1], so);
+        } else {
+            lds_dma16(rsrc_b, base, ob[KIND & 1][0], so);
+            lds_dma16(rsrc_b, base + 8192, ob[KIND & 1][1], so);
+        }
+    };
+#define ASR8_ISSUE(KIND, PAR, KT) issue(std::integral_constant<int, KIND>{}, std::integral_constant<int, PAR>{}, (KT))
+
+    // ---- reader: lane (q, r) reads row (block base) + r, chunk (4 ks + q) ^ (r % 8); the region's kind and the tile index are the
+    // instruction's immediate offset (< 64 KiB), the parity is in the address register
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned al0 = lds0 + (unsigned)((wm * 64 + r) * 128 + ((q ^ (r & 7)) << 4)), al1 = al0 ^ 64u;
+    const unsigned bl0 = lds0 + (unsigned)((wn * 32 + r) * 128 + ((q ^ (r & 7)) << 4)), bl1 = bl0 ^ 64u;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag a[4][2], b0[2][2], b1[2][2];
+
+    auto read_a = [&](auto par_c, auto h_c) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
+        const unsigned p0 = al0 + PAR * 4 * HALF, p1 = al1 + PAR * 4 * HALF;
+        lds_rd16<H * HALF + 0 * 2048>(a[0][0], p0); lds_rd16<H * HALF + 0 * 2048>(a[0][1], p1);
+        lds_rd16<H * HALF + 1 * 2048>(a[1][0], p0); lds_rd16<H * HALF + 1 * 2048>(a[1][1], p1);
+        lds_rd16<H * HALF + 2 * 2048>(a[2][0], p0); lds_rd16<H * HALF + 2 * 2048>(a[2][1], p1);
+        lds_rd16<H * HALF + 3 * 2048>(a[3][0], p0); lds_rd16<H * HALF + 3 * 2048>(a[3][1], p1);
+    };
+    auto read_b = [&](auto par_c, auto h_c, Frag (&b)[2][2]) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
+        const unsigned p0 = bl0 + PAR * 4 * HALF, p1 = bl1 + PAR * 4 * HALF;
+        lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][0], p0); lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][1], p1);
+        lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][0], p0); lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][1], p1);
+    };
+    // one quadrant: rows I0 .. I0 + 3 (x 16), column tiles J0, J0 + 1, K = 64
+    auto quadrant = [&](auto i0_c, auto j0_c, const Frag (&b)[2][2]) {
+        constexpr int I0 = decltype(i0_c)::value, J0 = decltype(j0_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[I0 + i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[I0 + i][J0 + j]);
+    };
+#define ASR8_C(V) std::integral_constant<int, V>{}
+
+    // the four phases of K step t (parity PAR of its LDS regions)
+    auto kstep = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int t1 = min(t + 1, nk - 1), t2 = min(t + 2, nk - 1);
+        // (A0, B0)
+        read_b(ASR8_C(PAR), ASR8_C(0), b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(ASR8_C(PAR), ASR8_C(0));
+        ASR8_ISSUE(3, PAR ^ 1, t1);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+        // (A0, B1)
+        read_b(ASR8_C(PAR), ASR8_C(1), b1);
+        ASR8_ISSUE(1, PAR ^ 1, t1);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(2), b1);
+        ASR8_COMPUTE_END();
+        // (A1, B1)
+        read_a(ASR8_C(PAR), ASR8_C(1));
+        ASR8_ISSUE(0, PAR, t2);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(4), ASR8_C(2), b1);
+        ASR8_COMPUTE_END();
+        // (A1, B0)
+        ASR8_ISSUE(2, PAR, t2);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(4), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+    };
+
+    // prologue: K step 0 whole, A0 and B0 of step 1 -- six half tiles; the first phase issues the seventh and retires the third
+    {
+        const int t1 = min(1, nk - 1);
+        ASR8_ISSUE(0, 0, 0);
+        ASR8_ISSUE(2, 0, 0);
+        ASR8_ISSUE(3, 0, 0);
+        ASR8_ISSUE(1, 0, 0);
+        ASR8_ISSUE(0, 1, t1);
+        ASR8_ISSUE(2, 1, t1);
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
+    if (wm == 1) asm volatile("s_barrier" ::: "memory");        // the second M-half runs one barrier behind the first
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        kstep(ASR8_C(0), t);
+        kstep(ASR8_C(1), t + 1);
+    }
+    if (t < nk) kstep(ASR8_C(0), t);
+    if (wm == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the re-fetches beyond K still write LDS: drained before the workgroup leaves)
+
+    // ---- epilogue: acc[I][J][reg] = C[m0 + wm * 128 + I * 16 + 4 q + reg][n0 + wn * 64 + 4 r + J]
+    const int col = n0 + wn * 64 + 4 * r;
+    if (col >= N) return;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + col);
+        bv[0] = bb.x; bv[1] = bb.y; bv[2] = bb.z; bv[3] = bb.w;
+    }
+    const int row0 = m0 + wm * 128 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + i * 16 + reg;
+            if (row >= M) continue;
+            OutT* dst = C + (size_t)row * ldc + col;
+            const float v0 = acc[i][0][reg] + bv[0], v1 = acc[i][1][reg] + bv[1], v2 = acc[i][2][reg] + bv[2], v3 = acc[i][3][reg] + bv[3];
+            if (sizeof(OutT) == 4) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            }
+        }
+}
+
+}  // namespace gemm8
+}  // namespace asr
+
+using namespace asr;
+
+// 1 if asr_gemm_nt_8ph serves the product (K a multiple of 64, whole groups of four columns, aligned operands, 32-bit byte offsets)
+extern "C" int asr_gemm_nt_8ph_ok(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, const float* bias, int M, int N, int K,
+                                  int out_bf16) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K < 64 || (K & 63) || (N & 3)) return 0;
+    if (lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7) || (ldc & 3)) return 0;
+    if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 0;
+    if (((uintptr_t)C) & (out_bf16 ? 7 : 15)) return 0;
+    if (bias && (((uintptr_t)bias) & 15)) return 0;
+    if ((unsigned long long)M * lda * 2 >= (1ull << 31) || (unsigned long long)N * ldb * 2 >= (1ull << 31)) return 0;
+    return 1;
+}
+
+extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, int M, int N,
+                               int K, int out_bf16) {
+    if (!asr_gemm_nt_8ph_ok(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16)) return ASR_ERR_UNSUPPORTED;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    const unsigned a_bytes = (unsigned)((unsigned long long)M * lda * 2), b_bytes = (unsigned)((unsigned long long)N * ldb * 2);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        attr = true;
+    }
+    if (out_bf16)
+        hipLaunchKernelGGL(gemm8::gemm_nt_8ph_kernel<uint16_t>, dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda,
+                           (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes);
+    else
+        hipLaunchKernelGGL(gemm8::gemm_nt_8ph_kernel<float>, dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda,
+                           (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}

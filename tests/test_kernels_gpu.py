@@ -58,6 +58,64 @@ def test_gemm_nt_many_tiles(device, M, N, K, bias_on, out_dtype):
     assert (out.float() - ref).abs().max().item() < (1e-3 if out_dtype == F32 else 0.02 * ref.abs().max().item())      # no stray tile
 
 
+@pytest.mark.parametrize("M,N,K,bias_on,lda", [(256, 256, 64, False, None), (300, 260, 192, True, None), (1000, 384, 320, False, None), (777, 132, 448, True, None),
+                                                (513, 1024, 1024, True, 1088), (255, 4, 64, False, None), (8000, 512, 3072, True, None), (4096, 1280, 1024, False, None),
+                                                (32000, 3072, 512, True, None)])
+@pytest.mark.parametrize("out_dtype", [BF16, F32])
+def test_gemm_nt_8ph(device, M, N, K, bias_on, lda, out_dtype):
+    """asr_gemm_nt_8ph (csrc/gemm8.hip: 256 x 256 tile, eight waves in two staggered groups, four half tiles of LDS-DMA in flight) called
+    directly: one K step, an odd number of K steps, ragged M and N (a last column tile of 4), strided rows, bias, both output types --
+    against the float32 product of the same bf16 operands on the GPU"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, lda or K, generator=g)).to(device, BF16)[:, :K]
+    b = _bf(torch.randn(N, K, generator=g)).to(device, BF16)
+    bias = torch.randn(N, generator=g).to(device) if bias_on else None
+    out = _ops.gemm_nt_8ph(a, b, bias, out_dtype)
+    ref = a.float() @ b.float().T
+    if bias_on:
+        ref = ref + bias
+    tol = 2e-5 if out_dtype == F32 else 4e-3
+    assert _rel(out.float().cpu(), ref.cpu()) < tol
+    assert (out.float() - ref).abs().max().item() < (1e-3 if out_dtype == F32 else 0.02 * ref.abs().max().item())      # no stray tile
+
+
+def test_gemm_nt_8ph_exact_and_repeatable(device):
+    """small integers are exact in bf16 and float32: any mix-up of rows, columns or K slices between the loader's permuted LDS rows and the
+    epilogue's column map shows as a wrong integer; and twenty launches on large operands give the same bits every time (a fragment read
+    that overtakes its LDS-DMA shows up as a tile that differs between runs: the guide's warning about this schedule)"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 700, 516, 320
+    a = torch.randint(-4, 5, (M, K), generator=g).float()
+    b = torch.randint(-4, 5, (N, K), generator=g).float()
+    out = _ops.gemm_nt_8ph(a.to(device, BF16), b.to(device, BF16), None, F32).cpu()
+    assert torch.equal(out, a @ b.T)
+    eye = torch.eye(512)
+    bb = (torch.arange(512 * 512, dtype=F32).reshape(512, 512) % 251 - 100)
+    assert torch.equal(_ops.gemm_nt_8ph(eye.to(device, BF16), bb.to(device, BF16), None, F32).cpu(), bb.T.contiguous())
+    a = torch.randn(16384, 2048, generator=g).to(device, BF16)
+    b = torch.randn(2048, 2048, generator=g).to(device, BF16)
+    first = _ops.gemm_nt_8ph(a, b, None, BF16).clone()
+    scratch = torch.empty(1 << 26, device=device)
+    for i in range(20):
+        if i % 4 == 0:
+            scratch.fill_(float(i))            # other traffic between the launches: different arrival orders of the half tiles
+        assert torch.equal(_ops.gemm_nt_8ph(a, b, None, BF16), first)
+    assert _rel(first.float().cpu(), (a.float() @ b.float().T).cpu()) < 4e-3
+
+
+def test_nt_kernels_without_the_8ph_kernel_in_a_forced_process():
+    """asr_gemm_nt routes qualifying products to the 256 x 256 / eight-wave kernel; ASR_DEBUG nt_8ph=0 (read once per process) keeps the
+    kernels it replaced (persistent 256 x 128, 128 x 128) under the NT tests of this file"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_DEBUG="nt_8ph=0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gemm_nt and not 8ph"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_gemm_nt_asymmetric_identity(device):
     """A = I with an asymmetric B catches a transposed accumulator write (row/col swap)."""
     from asr import _ops
