@@ -83,6 +83,8 @@ SIGNATURES = {
     "asr_conv_weight_pack_bwd": (c_int, [c_void_p] * 3 + [c_int] * 4),
     "asr_gemm_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int] + [c_int] * 3),
     "asr_gemm_tn_acc_group": (c_int, [c_void_p, c_int] + [c_void_p] * 9),
+    "asr_gemm_tn_8ph_ok": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int]),
+    "asr_gemm_tn_acc_group_8ph": (c_int, [c_void_p, c_int] + [c_void_p] * 9),
     "asr_cast_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     "asr_cast_bf16_many": (c_int, [c_void_p, c_void_p, c_int, c_longlong]),
     "asr_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong]),

@@ -90,6 +90,20 @@ def gemm_tn_acc_group(products):
     check(rc, "asr_gemm_tn_acc_group")
 
 
+def gemm_tn_acc_group_8ph(products):
+    """gemm_tn_acc_group on the 256 x 256 tile / eight-wave kernel only (asr_gemm_tn_acc_group_8ph: tests and timings)"""
+    n = len(products)
+    assert 1 <= n <= 4
+    import ctypes
+    ptrs = lambda k: (ctypes.c_void_p * n)(*[p[k].data_ptr() for p in products])
+    ints = lambda f: (ctypes.c_int * n)(*[f(p) for p in products])
+    rc = _lib.lib().asr_gemm_tn_acc_group_8ph(stream(), n, ptrs(0), ints(lambda p: p[0].stride(0)), ptrs(1),
+                                              ints(lambda p: p[1].stride(0)), ptrs(2), ints(lambda p: p[2].stride(0)),
+                                              ints(lambda p: p[0].shape[1]), ints(lambda p: p[1].shape[1]),
+                                              ints(lambda p: p[0].shape[0]))
+    check(rc, "asr_gemm_tn_acc_group_8ph")
+
+
 def cast_bf16(src, transpose=False, out=None):
     """f32 (rows, cols) -> bf16 copy, optionally transposed; `out`: a contiguous bf16 tensor of the result's size."""
     assert src.dtype == F32 and src.is_contiguous()

@@ -1624,6 +1624,17 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return ASR_ERR_BAD_ARG;
     if (lda < M || ldb < N || ldc < N) return ASR_ERR_BAD_ARG;
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        // the eight-wave kernel of csrc/gemm8.hip (tools/time_tn8.py: 32000 x 3000 x 320 116 -> 102 us, 416000 x 256 x 1920 554 -> 382;
+        // the small dense gradients 640 x 512 / 640 x 320 tie); ASR_DEBUG tn_8ph=0 / tn256=2: never
+        static const int use8 = debug_flag("tn_8ph", 1), tn256_forced = debug_flag("tn256", 1);
+        if (use8 && tn256_forced != 2 && K >= 2048 && (long long)M * N >= 256 * 256 && asr_gemm_tn_8ph_ok(A, lda, B, ldb, C, ldc, M, N, K)) {
+            const void* a1[1] = {A};
+            const void* b1[1] = {B};
+            float* c1[1] = {C};
+            return asr_gemm_tn_acc_group_8ph(stream_, 1, a1, &lda, b1, &ldb, c1, &ldc, &M, &N, &K);
+        }
+    }
     if (tn256_ok(M, lda, ldb, A, B, false) && (N & 7) == 0) {
         const int t2m = cdiv(M, T2M), t2n = cdiv(N, T2N);
         int kps;
@@ -1652,6 +1663,15 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
 extern "C" int asr_gemm_tn_acc_group(void* stream_, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                      float* const* C, const int* ldc, const int* M, const int* N, const int* K) {
     if (!A || !B || !C || !lda || !ldb || !ldc || !M || !N || !K || n < 1 || n > 4) return ASR_ERR_BAD_ARG;
+    {
+        // the eight-wave kernel of csrc/gemm8.hip where every product qualifies (tools/time_tn8.py: the three weight gradients of a GRU
+        // layer, K = 32000: 275 -> 194 us); ASR_DEBUG tn_8ph=0: never
+        static const int use8 = debug_flag("tn_8ph", 1);
+        bool all8 = use8 != 0;
+        for (int i = 0; i < n && all8; ++i)
+            all8 = A[i] && B[i] && C[i] && K[i] >= 2048 && asr_gemm_tn_8ph_ok(A[i], lda[i], B[i], ldb[i], C[i], ldc[i], M[i], N[i], K[i]);
+        if (all8) return asr_gemm_tn_acc_group_8ph(stream_, n, A, lda, B, ldb, C, ldc, M, N, K);
+    }
     TnGroup grp{};
     int tiles = 0, kmax = 0;
     bool vec = true;

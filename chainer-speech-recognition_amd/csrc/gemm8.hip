@@ -245,6 +245,211 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------ TN: C[M,N] += A[K,M]^T B[K,N]
+// The weight gradients (dW = dy^T x: K = T B = 32000 rows, M and N a few hundred to a few thousand) on the same schedule.  Both
+// operands are k-strided in memory, so the LDS images keep the memory order -- a half tile is 64 k rows x 128 columns (256 B per row) --
+// and the fragments come out of LDS through ds_read_b64_tr_b16 (16 / 8 transposing reads per A / B half instead of 8 / 4 plain ones:
+// the same bytes).  16-B chunk c of k row kr sits at position c ^ 2 (kr % 8): the eight k rows a 32-lane group of a transposing read
+// touches then cover all 64 banks.  A lane of such a read points at k row 4 g + q (+ 16) of the 32-row K slice and at columns
+// 4 p .. 4 p + 3 of the 16-column tile (g = lane / 16, q = lane / 4 % 4, p = lane % 4) -- the convention of gemm.hip's TN kernels: A and
+// B fragments hold their k slots in the same (permuted) order, which is all the product needs.
+// Work item = (K split, output tile of one of up to four products); a workgroup adds its 256 x 256 partial product with float atomics.
+// K splits are multiples of 64 rows; the rows beyond K are beyond the operand's buffer and arrive as zeros.
+struct Tn8Prob {
+    const uint16_t* A;
+    const uint16_t* B;
+    float* C;
+    int lda, ldb, ldc, M, N, K, tiles_n;
+    int tile_end;                        // tiles of this and all earlier products
+};
+struct Tn8Group {
+    Tn8Prob p[4];
+    int n;
+};
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+union FragT {
+    bf16x8 v;
+    u32x2 d[2];
+};
+template <int OFF>
+__device__ __forceinline__ void lds_tr8(u32x2& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    // (split, tile) pairs in split-major order, dealt to the XCDs (workgroup id % 8 under round-robin dispatch: a locality hint) in
+    // eight contiguous runs: the tiles of one K split meet in one L2 and share the rows of A and B they read
+    const int item = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int split = item / tiles;
+    int tile = item - split * tiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (i + 1 < grp.n && tile >= grp.p[i].tile_end) pi = i + 1;
+    const Tn8Prob& P = grp.p[pi];
+    if (pi > 0) tile -= grp.p[pi - 1].tile_end;
+    const uint16_t* __restrict__ A = P.A;
+    const uint16_t* __restrict__ B = P.B;
+    const int lda = P.lda, ldb = P.ldb, M = P.M, N = P.N, K = P.K;
+    const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int kbeg = split * k_per_split;
+    if (kbeg >= K) return;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = (kend - kbeg + 63) >> 6;
+
+    // ---- loader: slot s = i * 512 + tid = (k row kr = s / 16, position s % 16) holds chunk (s % 16) ^ 2 (kr % 8); the K advance
+    // goes into the VECTOR offset (the range check of a raw buffer access does not see the scalar offset): rows beyond K read zeros
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((unsigned)K * (unsigned)lda * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((unsigned)K * (unsigned)ldb * 2u), 0x00020000);
+    unsigned oa[2][2], ob[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = i * 512 + tid, kr = s >> 4, c = (s & 15) ^ ((kr & 7) << 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // A half h: chunk c = 8 columns of the M-wave c / 8: m0 + (c / 8) 128 + h 64 + (c % 8) 8
+            const int m = m0 + (c >> 3) * 128 + h * 64 + (c & 7) * 8;
+            oa[h][i] = m < M ? (unsigned)(kbeg + kr) * (unsigned)(lda * 2) + (unsigned)(m * 2) : 0xfffffff0u;
+            // B half h: chunk c = 8 columns of the N-wave c / 4: n0 + (c / 4) 64 + h 32 + (c % 4) 8
+            const int n = n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;
+            ob[h][i] = n < N ? (unsigned)(kbeg + kr) * (unsigned)(ldb * 2) + (unsigned)(n * 2) : 0xfffffff0u;
+        }
+    }
+    const unsigned stepa = (unsigned)(lda * 128), stepb = (unsigned)(ldb * 128);      // 64 k rows in bytes
+    auto issue = [&](auto kind_c, auto par_c, int kt) {
+        constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value;
+        char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
+        if (KIND < 2) {
+            const unsigned ko = (unsigned)kt * stepa;
+            const unsigned v0 = oa[KIND & 1][0], v1 = oa[KIND & 1][1];
+            lds_dma16(rsrc_a, base, v0 == 0xfffffff0u ? v0 : v0 + ko, 0);
+            lds_dma16(rsrc_a, base + 8192, v1 == 0xfffffff0u ? v1 : v1 + ko, 0);
+        } else {
+            const unsigned ko = (unsigned)kt * stepb;
+            const unsigned v0 = ob[KIND & 1][0], v1 = ob[KIND & 1][1];
+            lds_dma16(rsrc_b, base, v0 == 0xfffffff0u ? v0 : v0 + ko, 0);
+            lds_dma16(rsrc_b, base + 8192, v1 == 0xfffffff0u ? v1 : v1 + ko, 0);
+        }
+    };
+
+    // ---- reader (transposing): lane (g, q, p) -> k row 4 g + q of a 16-row group, columns 4 p .. 4 p + 3 of a 16-column tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int kq = 4 * g + q, sw = (kq & 7) << 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned ra[4], rb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = lds0 + (unsigned)(kq * 256 + (((wm * 8 + i * 2 + (p >> 1)) ^ sw) << 4) + (p & 1) * 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rb[j] = lds0 + (unsigned)(kq * 256 + (((wn * 4 + j * 2 + (p >> 1)) ^ sw) << 4) + (p & 1) * 8);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    FragT a[4][2], b0[2][2], b1[2][2];
+    // fragment (tile, ks): k rows ks 32 + {kq, 16 + kq}: immediates ks * 8192 and + 4096
+    auto read_a = [&](auto par_c, auto h_c) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value, R = (PAR * 4 + H) * HALF;
+        static_assert(R + 8192 + 4096 < 65536 || PAR == 1, "immediate range");
+        const unsigned po = PAR ? 4u * HALF : 0u;       // (the parity's 64 KiB go into the address register: the immediate is 16 bits)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ad = ra[i] + po;
+            lds_tr8<H * HALF + 0>(a[i][0].d[0], ad); lds_tr8<H * HALF + 4096>(a[i][0].d[1], ad);
+            lds_tr8<H * HALF + 8192>(a[i][1].d[0], ad); lds_tr8<H * HALF + 12288>(a[i][1].d[1], ad);
+        }
+    };
+    auto read_b = [&](auto par_c, auto h_c, FragT (&b)[2][2]) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
+        const unsigned po = PAR ? 4u * HALF : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned ad = rb[j] + po;
+            lds_tr8<(2 + H) * HALF + 0>(b[j][0].d[0], ad); lds_tr8<(2 + H) * HALF + 4096>(b[j][0].d[1], ad);
+            lds_tr8<(2 + H) * HALF + 8192>(b[j][1].d[0], ad); lds_tr8<(2 + H) * HALF + 12288>(b[j][1].d[1], ad);
+        }
+    };
+    auto quadrant = [&](auto i0_c, auto j0_c, const FragT (&b)[2][2]) {
+        constexpr int I0 = decltype(i0_c)::value, J0 = decltype(j0_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[I0 + i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[I0 + i][J0 + j]);
+    };
+    auto kstep = [&](auto par_c, int t) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int t1 = min(t + 1, nk - 1), t2 = min(t + 2, nk - 1);
+        read_b(ASR8_C(PAR), ASR8_C(0), b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(ASR8_C(PAR), ASR8_C(0));
+        ASR8_ISSUE(3, PAR ^ 1, t1);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+        read_b(ASR8_C(PAR), ASR8_C(1), b1);
+        ASR8_ISSUE(1, PAR ^ 1, t1);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(2), b1);
+        ASR8_COMPUTE_END();
+        read_a(ASR8_C(PAR), ASR8_C(1));
+        ASR8_ISSUE(0, PAR, t2);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(4), ASR8_C(2), b1);
+        ASR8_COMPUTE_END();
+        ASR8_ISSUE(2, PAR, t2);
+        ASR8_LOAD_END();
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(4), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+    };
+    {
+        const int t1 = min(1, nk - 1);
+        ASR8_ISSUE(0, 0, 0);
+        ASR8_ISSUE(2, 0, 0);
+        ASR8_ISSUE(3, 0, 0);
+        ASR8_ISSUE(1, 0, 0);
+        ASR8_ISSUE(0, 1, t1);
+        ASR8_ISSUE(2, 1, t1);
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
+    if (wm == 1) asm volatile("s_barrier" ::: "memory");
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        kstep(ASR8_C(0), t);
+        kstep(ASR8_C(1), t + 1);
+    }
+    if (t < nk) kstep(ASR8_C(0), t);
+    if (wm == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: acc[I][J][reg] += into C[m0 + wm 128 + I 16 + 4 (lane / 16) + reg][n0 + wn 64 + J 16 + lane % 16]
+    float* __restrict__ C = P.C;
+    const int ldc = P.ldc;
+    const int col0 = n0 + wn * 64 + (lane & 15), row0 = m0 + wm * 128 + 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + i * 16 + reg;
+            if (row >= M) continue;
+            float* dst = C + (size_t)row * ldc + col0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col0 + j * 16 < N) atomicAdd(dst + j * 16, acc[i][j][reg]);
+        }
+}
+
 }  // namespace gemm8
 }  // namespace asr
 
@@ -280,6 +485,52 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     else
         hipLaunchKernelGGL(gemm8::gemm_nt_8ph_kernel<float>, dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda,
                            (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// 1 if asr_gemm_tn_acc_8ph serves the product: whole 16-byte chunks of eight columns (M, N, lda, ldb multiples of 8, aligned bases),
+// operands below 2 GiB
+extern "C" int asr_gemm_tn_8ph_ok(const void* A, int lda, const void* B, int ldb, const float* C, int ldc, int M, int N, int K) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (M & 7) || (N & 7) || (lda & 7) || (ldb & 7)) return 0;
+    if (lda < M || ldb < N || ldc < N) return 0;
+    if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 0;
+    if ((unsigned long long)K * lda * 2 >= (1ull << 31) || (unsigned long long)K * ldb * 2 >= (1ull << 31)) return 0;
+    return 1;
+}
+
+// n <= 4 products C_i += A_i^T B_i in one launch on the eight-wave kernel (every product must pass asr_gemm_tn_8ph_ok)
+extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                                         float* const* C, const int* ldc, const int* M, const int* N, const int* K) {
+    if (!A || !B || !C || !lda || !ldb || !ldc || !M || !N || !K || n < 1 || n > 4) return ASR_ERR_BAD_ARG;
+    gemm8::Tn8Group grp{};
+    int tiles = 0, kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!asr_gemm_tn_8ph_ok(A[i], lda[i], B[i], ldb[i], C[i], ldc[i], M[i], N[i], K[i])) return ASR_ERR_UNSUPPORTED;
+        gemm8::Tn8Prob& q = grp.p[i];
+        q.A = (const uint16_t*)A[i]; q.B = (const uint16_t*)B[i]; q.C = C[i];
+        q.lda = lda[i]; q.ldb = ldb[i]; q.ldc = ldc[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
+        q.tiles_n = cdiv(N[i], 256);
+        tiles += cdiv(M[i], 256) * q.tiles_n;
+        q.tile_end = tiles;
+        kmax = K[i] > kmax ? K[i] : kmax;
+    }
+    grp.n = n;
+    // one workgroup per CU holds a whole CU (128 KiB of LDS): K splits so that about every CU gets one item, each split a multiple of 64 rows
+    static const int target = debug_flag("tn8_items", 256);
+    int splits = target / tiles;
+    if (splits < 1) splits = 1;
+    const int max_splits = cdiv(kmax, 512);                  // at least 8 K steps per item
+    if (splits > max_splits) splits = max_splits;
+    const int k_per_split = cdiv(cdiv(kmax, splits), 64) * 64;
+    splits = cdiv(kmax, k_per_split);
+    const int items = tiles * splits, grid = 8 * cdiv(items, 8);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -159,6 +159,12 @@ int asr_gemm_nt_8ph(void* stream, const void* A, int lda, const void* B, int ldb
 int asr_gemm_tn_acc(void* stream, const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K);
 int asr_gemm_tn_acc_group(void* stream, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                           float* const* C, const int* ldc, const int* M, const int* N, const int* K);
+/* asr_gemm_tn_acc_group_8ph: the same products on the 256 x 256 tile / eight-wave kernel of csrc/gemm8.hip (transposing LDS reads);
+ * every product must pass asr_gemm_tn_8ph_ok (M, N, lda, ldb multiples of 8, 16-byte aligned bases, operands below 2 GiB).
+ * asr_gemm_tn_acc / asr_gemm_tn_acc_group route qualifying calls to it. */
+int asr_gemm_tn_8ph_ok(const void* A, int lda, const void* B, int ldb, const float* C, int ldc, int M, int N, int K);
+int asr_gemm_tn_acc_group_8ph(void* stream, int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                              float* const* C, const int* ldc, const int* M, const int* N, const int* K);
 
 /* ---------------------------------------------------------------------------------------- layout / activations
  * Internal activations are (T, B, H, C) bf16 (time-major, channel-last); see DESIGN.md "Data layout in HBM".

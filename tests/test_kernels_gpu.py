@@ -139,6 +139,61 @@ def test_gemm_tn_acc(device, K, M, N):
     assert _rel(c.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("K,M,N,lda", [(64, 256, 256, None), (96, 40, 24, None), (333, 48, 960, None), (1000, 136, 72, None), (4096, 1536, 512, None),
+                                        (2048, 3000, 320, None), (5000, 264, 520, 320), (20000, 640, 512, None)])
+def test_gemm_tn_8ph(device, K, M, N, lda):
+    """asr_gemm_tn_acc_group_8ph (csrc/gemm8.hip: eight waves, transposing LDS reads, split K with float atomics) called directly: one K
+    step, K not a multiple of 64 (the rows beyond K arrive as zeros), ragged M and N, a strided operand -- small integers give EXACT sums
+    (any mix-up of k slots between the A and B fragments, or of columns in the epilogue, is a wrong integer), random data the float32 bar"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(K + M + N)
+    a = torch.randint(-4, 5, (K, lda or M), generator=g).float()
+    b = torch.randint(-4, 5, (K, N), generator=g).float()
+    c = torch.full((M, N), 3.0, device=device)
+    _ops.gemm_tn_acc_group_8ph([(a.to(device, BF16)[:, :M], b.to(device, BF16), c)])
+    assert torch.equal(c.cpu(), 3.0 + a[:, :M].T @ b)
+    a = _bf(torch.randn(K, lda or M, generator=g))
+    b = _bf(torch.randn(K, N, generator=g))
+    c0 = torch.randn(M, N, generator=g)
+    c = c0.to(device)
+    _ops.gemm_tn_acc_group_8ph([(a.to(device, BF16)[:, :M], b.to(device, BF16), c)])
+    assert _rel(c.cpu(), c0.double() + a[:, :M].double().T @ b.double()) < 1e-5
+
+
+def test_gemm_tn_8ph_group_repeatable(device):
+    """the three weight gradients of a GRU layer in one launch, five times over: the float atomics of the K splits may land in any order
+    (last-bit differences), a fragment read overtaking its LDS-DMA would be a wrong tile: every run within the float32 bar of the others and
+    of the products formed one by one"""
+    from asr import _ops
+    T, B, H = 250, 32, 512
+    g = torch.Generator().manual_seed(7)
+    dgi = torch.randn(T * B, 6 * H, generator=g).to(device, BF16)
+    x = torch.randn(T * B, H, generator=g).to(device, BF16)
+    dgh = torch.randn(T * B, 6 * H, generator=g).to(device, BF16)
+    h16 = torch.randn(T * B, 2 * H, generator=g).to(device, BF16)
+    ref_ih = (dgi.float().T @ x.float())
+    ref_hh = [dgh[B:, :3 * H].float().T @ h16[:-B, :H].float(), dgh[:-B, 3 * H:].float().T @ h16[B:, H:].float()]
+    scratch = torch.empty(1 << 26, device=device)
+    for it in range(5):
+        dwih = torch.zeros(6 * H, H, device=device)
+        dwhh = torch.zeros(2, 3 * H, H, device=device)
+        scratch.fill_(float(it))
+        _ops.gemm_tn_acc_group_8ph([(dgi, x, dwih), (dgh[B:, :3 * H], h16[:-B, :H], dwhh[0]), (dgh[:-B, 3 * H:], h16[B:, H:], dwhh[1])])
+        assert _rel(dwih.cpu(), ref_ih.cpu()) < 1e-5
+        assert _rel(dwhh[0].cpu(), ref_hh[0].cpu()) < 1e-5 and _rel(dwhh[1].cpu(), ref_hh[1].cpu()) < 1e-5
+
+
+def test_tn_kernels_without_the_8ph_kernel_in_a_forced_process():
+    """asr_gemm_tn_acc / asr_gemm_tn_acc_group route qualifying products to the eight-wave kernel; ASR_DEBUG tn_8ph=0 (read once per process)
+    keeps the kernels it replaced under the TN tests of this file"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_DEBUG="tn_8ph=0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gemm_tn and not 8ph"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_gemm_tn_exact_integers(device):
     """small integers: exact in bf16 and f32, so any k-slot mix-up between A and B shows as a wrong integer."""
     from asr import _ops
