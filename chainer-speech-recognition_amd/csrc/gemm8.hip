@@ -71,13 +71,16 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
     __builtin_amdgcn_sched_barrier(0);                       \
     asm volatile("s_barrier" ::: "memory")
 
-template <typename OutT>
+// KT: K is a multiple of 8 but not of 64 (the logit gradient's K = V = 3000): the chunks of the last K step that lie beyond K are
+// fetched from beyond the buffers' ends, i.e. as zeros -- both operands.
+template <typename OutT, bool KT>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
                                                             OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
                                                             int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
+    // waves 4 (M) x 2 (N): a wave owns 64 rows x 128 columns = 4 x 8 MFMA tiles; waves i and i + 4 (one SIMD) are wm and wm + 2
+    const int wm = wid >> 1, wn = wid & 1;
     // tiles: XCD x (= bid % 8 under round-robin dispatch; a locality hint only) takes a contiguous range of tile ids, so the column tiles of a
     // row panel of A meet in one L2.  The map is a bijection for any number of tiles.
     int wg;
@@ -87,22 +90,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
     }
     const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
-    const int nk = K >> 6;
+    const int nk = KT ? (K + 63) >> 6 : K >> 6;
 
     // ---- loader: slot s = i * 512 + tid of a half tile = (LDS row rho = s / 8, position s % 8), holding chunk (s % 8) ^ (rho % 8)
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
     unsigned oa[2][2], ob[2][2];            // [half][i]: byte offset of this thread's source chunk at k = 0
+    int kc[2];                              // KT: first k of the slot's chunk inside a K step
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int s = i * 512 + tid, rho = s >> 3, c = (s & 7) ^ (rho & 7);
+        kc[i] = c * 8;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // A half h: LDS row rho = wm' * 64 + rr  <-  row m0 + wm' * 128 + h * 64 + rr
-            const int grow = m0 + (rho >> 6) * 128 + h * 64 + (rho & 63);
+            // A half h: LDS row rho = wm' * 32 + rr  <-  row m0 + wm' * 64 + h * 32 + rr
+            const int grow = m0 + (rho >> 5) * 64 + h * 32 + (rho & 31);
             oa[h][i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
-            // B half h: LDS row rho = wn' * 32 + j * 16 + r  <-  column n0 + wn' * 64 + 4 r + (2 h + j)
-            const int gcol = n0 + (rho >> 5) * 64 + 4 * (rho & 15) + 2 * h + ((rho >> 4) & 1);
+            // B half h: LDS row rho = wn' * 64 + j * 16 + r  <-  column n0 + wn' * 128 + 8 r + (4 h + j)
+            const int gcol = n0 + (rho >> 6) * 128 + 8 * (rho & 15) + 4 * h + ((rho >> 4) & 3);
             ob[h][i] = (unsigned)min(gcol, N - 1) * (unsigned)(ldb * 2) + (unsigned)(c * 16);
         }
     }
@@ -111,53 +116,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value;
         char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
         const int so = kt * 128;
+        const bool d0 = KT && kt * 64 + kc[0] >= K, d1 = KT && kt * 64 + kc[1] >= K;
         if (KIND < 2) {
-            lds_dma16(rsrc_a, base, oa[KIND & 1][0], so);
-            lds_dma16(rsrc_a, base + 8192, oa[KIND & 1][1], so);
+            lds_dma16(rsrc_a, base, d0 ? 0xfffffff0u : oa[KIND & 1][0], so);
+            lds_dma16(rsrc_a, base + 8192, d1 ? 0xfffffff0u : oa[KIND & 1][1], so);
         } else {
-            lds_dma16(rsrc_b, base, ob[KIND & 1][0], so);
-            lds_dma16(rsrc_b, base + 8192, ob[KIND & 1][1], so);
+            lds_dma16(rsrc_b, base, d0 ? 0xfffffff0u : ob[KIND & 1][0], so);
+            lds_dma16(rsrc_b, base + 8192, d1 ? 0xfffffff0u : ob[KIND & 1][1], so);
         }
     };
-#define ASR8_ISSUE(KIND, PAR, KT) issue(std::integral_constant<int, KIND>{}, std::integral_constant<int, PAR>{}, (KT))
+#define ASR8_ISSUE(KIND, PAR, KT_) issue(std::integral_constant<int, KIND>{}, std::integral_constant<int, PAR>{}, (KT_))
 
     // ---- reader: lane (q, r) reads row (block base) + r, chunk (4 ks + q) ^ (r % 8); the region's kind and the tile index are the
     // instruction's immediate offset (< 64 KiB), the parity is in the address register
     const int q = lane >> 4, r = lane & 15;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned al0 = lds0 + (unsigned)((wm * 64 + r) * 128 + ((q ^ (r & 7)) << 4)), al1 = al0 ^ 64u;
-    const unsigned bl0 = lds0 + (unsigned)((wn * 32 + r) * 128 + ((q ^ (r & 7)) << 4)), bl1 = bl0 ^ 64u;
+    const unsigned al0 = lds0 + (unsigned)((wm * 32 + r) * 128 + ((q ^ (r & 7)) << 4)), al1 = al0 ^ 64u;
+    const unsigned bl0 = lds0 + (unsigned)((wn * 64 + r) * 128 + ((q ^ (r & 7)) << 4)), bl1 = bl0 ^ 64u;
 
-    f32x4 acc[8][4];
+    f32x4 acc[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Frag a[4][2], b0[2][2], b1[2][2];
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag a[2][2], b0[4][2], b1[4][2];
 
     auto read_a = [&](auto par_c, auto h_c) {
         constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
         const unsigned p0 = al0 + PAR * 4 * HALF, p1 = al1 + PAR * 4 * HALF;
         lds_rd16<H * HALF + 0 * 2048>(a[0][0], p0); lds_rd16<H * HALF + 0 * 2048>(a[0][1], p1);
         lds_rd16<H * HALF + 1 * 2048>(a[1][0], p0); lds_rd16<H * HALF + 1 * 2048>(a[1][1], p1);
-        lds_rd16<H * HALF + 2 * 2048>(a[2][0], p0); lds_rd16<H * HALF + 2 * 2048>(a[2][1], p1);
-        lds_rd16<H * HALF + 3 * 2048>(a[3][0], p0); lds_rd16<H * HALF + 3 * 2048>(a[3][1], p1);
     };
-    auto read_b = [&](auto par_c, auto h_c, Frag (&b)[2][2]) {
+    auto read_b = [&](auto par_c, auto h_c, Frag (&b)[4][2]) {
         constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
         const unsigned p0 = bl0 + PAR * 4 * HALF, p1 = bl1 + PAR * 4 * HALF;
         lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][0], p0); lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][1], p1);
         lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][0], p0); lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][1], p1);
+        lds_rd16<(2 + H) * HALF + 2 * 2048>(b[2][0], p0); lds_rd16<(2 + H) * HALF + 2 * 2048>(b[2][1], p1);
+        lds_rd16<(2 + H) * HALF + 3 * 2048>(b[3][0], p0); lds_rd16<(2 + H) * HALF + 3 * 2048>(b[3][1], p1);
     };
-    // one quadrant: rows I0 .. I0 + 3 (x 16), column tiles J0, J0 + 1, K = 64
-    auto quadrant = [&](auto i0_c, auto j0_c, const Frag (&b)[2][2]) {
+    // one quadrant: row tiles I0, I0 + 1, column tiles J0 .. J0 + 3, K = 64
+    auto quadrant = [&](auto i0_c, auto j0_c, const Frag (&b)[4][2]) {
         constexpr int I0 = decltype(i0_c)::value, J0 = decltype(j0_c)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[I0 + i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[I0 + i][J0 + j]);
+                for (int i = 0; i < 2; ++i) acc[I0 + i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[I0 + i][J0 + j]);
     };
 #define ASR8_C(V) std::integral_constant<int, V>{}
 
@@ -166,9 +172,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         constexpr int PAR = decltype(par_c)::value;
         const int t1 = min(t + 1, nk - 1), t2 = min(t + 2, nk - 1);
         // (A0, B0)
-        read_b(ASR8_C(PAR), ASR8_C(0), b0);
-        __builtin_amdgcn_sched_barrier(0);
         read_a(ASR8_C(PAR), ASR8_C(0));
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(ASR8_C(PAR), ASR8_C(0), b0);
         ASR8_ISSUE(3, PAR ^ 1, t1);
         ASR8_LOAD_END();
         ASR8_COMPUTE_BEGIN();
@@ -179,20 +185,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         ASR8_ISSUE(1, PAR ^ 1, t1);
         ASR8_LOAD_END();
         ASR8_COMPUTE_BEGIN();
-        quadrant(ASR8_C(0), ASR8_C(2), b1);
+        quadrant(ASR8_C(0), ASR8_C(4), b1);
         ASR8_COMPUTE_END();
         // (A1, B1)
         read_a(ASR8_C(PAR), ASR8_C(1));
         ASR8_ISSUE(0, PAR, t2);
         ASR8_LOAD_END();
         ASR8_COMPUTE_BEGIN();
-        quadrant(ASR8_C(4), ASR8_C(2), b1);
+        quadrant(ASR8_C(2), ASR8_C(4), b1);
         ASR8_COMPUTE_END();
         // (A1, B0)
         ASR8_ISSUE(2, PAR, t2);
         ASR8_LOAD_END();
         ASR8_COMPUTE_BEGIN();
-        quadrant(ASR8_C(4), ASR8_C(0), b0);
+        quadrant(ASR8_C(2), ASR8_C(0), b0);
         ASR8_COMPUTE_END();
     };
 
@@ -207,44 +213,65 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         ASR8_ISSUE(2, 1, t1);
         asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     }
-    if (wm == 1) asm volatile("s_barrier" ::: "memory");        // the second M-half runs one barrier behind the first
+    const int grp = wm >> 1;                                    // waves i and i + 4 share a SIMD: the halves wm < 2 / wm >= 2
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");       // the second half runs one barrier behind the first
     int t = 0;
     for (; t + 1 < nk; t += 2) {
         kstep(ASR8_C(0), t);
         kstep(ASR8_C(1), t + 1);
     }
     if (t < nk) kstep(ASR8_C(0), t);
-    if (wm == 0) asm volatile("s_barrier" ::: "memory");
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the re-fetches beyond K still write LDS: drained before the workgroup leaves)
 
-    // ---- epilogue: acc[I][J][reg] = C[m0 + wm * 128 + I * 16 + 4 q + reg][n0 + wn * 64 + 4 r + J]
-    const int col = n0 + wn * 64 + 4 * r;
+    // ---- epilogue: acc[I][J][reg] = C[m0 + wm * 64 + I * 16 + 4 q + reg][n0 + wn * 128 + 8 r + J]: 16 bytes of bf16 (32 of f32) per lane
+    // and row, the 16 lanes of a row 256 (512) contiguous bytes; 16 store instructions per lane (the store tail is issue-bound: 8-byte
+    // stores, 32 per lane, took as long as the eight K steps of a K = 512 product)
+    const int col = n0 + wn * 128 + 8 * r;
     if (col >= N) return;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool full = col + 7 < N;                              // (N % 4 == 0: a lane's eight columns exist as 8 or as the first 4)
     if (bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(bias + col);
-        bv[0] = bb.x; bv[1] = bb.y; bv[2] = bb.z; bv[3] = bb.w;
+        const float4 ba = *reinterpret_cast<const float4*>(bias + col);
+        bv[0] = ba.x; bv[1] = ba.y; bv[2] = ba.z; bv[3] = ba.w;
+        if (full) {
+            const float4 bb = *reinterpret_cast<const float4*>(bias + col + 4);
+            bv[4] = bb.x; bv[5] = bb.y; bv[6] = bb.z; bv[7] = bb.w;
+        }
     }
-    const int row0 = m0 + wm * 128 + 4 * q;
+    const int row0 = m0 + wm * 64 + 4 * q;
+    const bool c16 = (ldc & 7) == 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = row0 + i * 16 + reg;
             if (row >= M) continue;
             OutT* dst = C + (size_t)row * ldc + col;
-            const float v0 = acc[i][0][reg] + bv[0], v1 = acc[i][1][reg] + bv[1], v2 = acc[i][2][reg] + bv[2], v3 = acc[i][3][reg] + bv[3];
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = acc[i][j][reg] + bv[j];
             if (sizeof(OutT) == 4) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (full) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else if (full && c16) {
+                uint4 pk;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
+                *reinterpret_cast<uint4*>(dst) = pk;
+            } else if (full) {      // (a row pitch of 4 (mod 8) columns: rows start 8 bytes off a 16-byte boundary)
+                uint2 pk, pl;
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                pl.x = pack_bf16x2(v[4], v[5]); pl.y = pack_bf16x2(v[6], v[7]);
+                *reinterpret_cast<uint2*>(dst) = pk;
+                *reinterpret_cast<uint2*>(dst + 4) = pl;
             } else {
                 uint2 pk;
-                pk.x = pack_bf16x2(v0, v1);
-                pk.y = pack_bf16x2(v2, v3);
+                pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(dst) = pk;
             }
         }
 }
-
 
 // ------------------------------------------------------------------------------------------------ TN: C[M,N] += A[K,M]^T B[K,N]
 // The weight gradients (dW = dy^T x: K = T B = 32000 rows, M and N a few hundred to a few thousand) on the same schedule.  Both
@@ -455,13 +482,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
 
 using namespace asr;
 
-// 1 if asr_gemm_nt_8ph serves the product (K a multiple of 64, whole groups of four columns, aligned operands, 32-bit byte offsets)
+// 1 if asr_gemm_nt_8ph serves the product (K a multiple of 8, whole groups of four columns, 16-byte aligned rows, 32-bit byte offsets)
 extern "C" int asr_gemm_nt_8ph_ok(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, const float* bias, int M, int N, int K,
                                   int out_bf16) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K < 64 || (K & 63) || (N & 3)) return 0;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K < 64 || (K & 7) || (N & 3)) return 0;
     if (lda < K || ldb < K || ldc < N || (lda & 7) || (ldb & 7) || (ldc & 3)) return 0;
-    if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return 0;
-    if (((uintptr_t)C) & (out_bf16 ? 7 : 15)) return 0;
+    if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C)) & 15) return 0;
     if (bias && (((uintptr_t)bias) & 15)) return 0;
     if ((unsigned long long)M * lda * 2 >= (1ull << 31) || (unsigned long long)N * ldb * 2 >= (1ull << 31)) return 0;
     return 1;
@@ -475,16 +501,19 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     const unsigned a_bytes = (unsigned)((unsigned long long)M * lda * 2), b_bytes = (unsigned)((unsigned long long)N * ldb * 2);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
-    if (out_bf16)
-        hipLaunchKernelGGL(gemm8::gemm_nt_8ph_kernel<uint16_t>, dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda,
-                           (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes);
-    else
-        hipLaunchKernelGGL(gemm8::gemm_nt_8ph_kernel<float>, dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda,
-                           (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes);
+#define ASR8_LAUNCH(T, CT, KT_)                                                                                                     \
+    hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
+                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes)
+    const bool kt = (K & 63) != 0;
+    if (out_bf16) { if (kt) ASR8_LAUNCH(uint16_t, uint16_t, true); else ASR8_LAUNCH(uint16_t, uint16_t, false); }
+    else          { if (kt) ASR8_LAUNCH(float, float, true); else ASR8_LAUNCH(float, float, false); }
+#undef ASR8_LAUNCH
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

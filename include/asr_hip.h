@@ -149,7 +149,7 @@ int asr_edit_distance(void* stream, const int32_t* ref, const int32_t* ref_len, 
  */
 int asr_gemm_nt(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                 int M, int N, int K, int out_bf16);
-/* asr_gemm_nt_8ph: the same product (no element-load fall-back: K % 64 == 0, N % 4 == 0, lda / ldb multiples of 8, 16-byte aligned
+/* asr_gemm_nt_8ph: the same product (no element-load fall-back: K % 8 == 0, N % 4 == 0, lda / ldb multiples of 8, ldc of 4, 16-byte aligned
  * bases, operands below 2 GiB -- asr_gemm_nt_8ph_ok says whether a call qualifies) on the 256 x 256 tile kernel with eight waves in
  * two staggered groups (csrc/gemm8.hip); asr_gemm_nt routes the long-K products of the model to it. */
 int asr_gemm_nt_8ph_ok(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, const float* bias, int M, int N, int K,

@@ -60,11 +60,12 @@ def test_gemm_nt_many_tiles(device, M, N, K, bias_on, out_dtype):
 
 @pytest.mark.parametrize("M,N,K,bias_on,lda", [(256, 256, 64, False, None), (300, 260, 192, True, None), (1000, 384, 320, False, None), (777, 132, 448, True, None),
                                                 (513, 1024, 1024, True, 1088), (255, 4, 64, False, None), (8000, 512, 3072, True, None), (4096, 1280, 1024, False, None),
-                                                (32000, 3072, 512, True, None)])
+                                                (32000, 3072, 512, True, None), (700, 264, 72, True, None), (4000, 320, 3000, False, None), (300, 12, 200, True, None)])
 @pytest.mark.parametrize("out_dtype", [BF16, F32])
 def test_gemm_nt_8ph(device, M, N, K, bias_on, lda, out_dtype):
     """asr_gemm_nt_8ph (csrc/gemm8.hip: 256 x 256 tile, eight waves in two staggered groups, four half tiles of LDS-DMA in flight) called
-    directly: one K step, an odd number of K steps, ragged M and N (a last column tile of 4), strided rows, bias, both output types --
+    directly: one K step, an odd number of K steps, K not a multiple of 64 (the logit gradient's 3000), ragged M and N (a last column tile
+    of 4 or 12), strided rows, bias, both output types --
     against the float32 product of the same bf16 operands on the GPU"""
     from asr import _ops
     g = torch.Generator().manual_seed(M + N + K)
