@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // from the defaults exist for measurements and for the tests that pin the non-default kernels; nothing in a normal run sets them.
 // Keys (default): nt_8ph (1: the 256 x 256 / eight-wave NT kernel of gemm8.hip wherever it qualifies), nt_wide (-1: convolutions only), nt_wide_force (0), nt_persist (1), nt_persist_min (256), nt_persist_grid (0),
 // tn_8ph (1: the eight-wave TN kernel of gemm8.hip wherever it qualifies), tn_vec (1), tn256 (1), tn_group_target (1152), fwd_ring (1), gru_poll_delay (-1: per-shape table), gru_fwd_rows (8; 4: two half-slab workgroups per CU),
-// conv_direct (1), conv_mp_parts (0: by size), conv_mp_frame (1), fbank_fast (1; 0: the one-workgroup-per-frame feature kernels) -- and, read by the Python layer
+// conv_8ph (1: the eight-wave implicit convolution of gemm8.hip for more than 128 output columns), conv_direct (1), conv_mp_parts (0: by size), conv_mp_frame (1), fbank_fast (1; 0: the one-workgroup-per-frame feature kernels) -- and, read by the Python layer
 // (asr/_lib.py: debug_flag), tn_group (1), gru_gates_f16 (1), side_join (0), side_priority (0), conv_mp (1).  DESIGN.md section 13.4 documents them.
 static inline int debug_flag(const char* key, int dflt) {
     const char* e = getenv("ASR_DEBUG");

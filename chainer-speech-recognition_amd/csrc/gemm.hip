@@ -1770,6 +1770,15 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
     const long long M = (long long)Tr * B * Hr;
     const int K = ldw;                  // row pitch of W = K of the GEMM: KH*KW*Cs, or more with empty (zero) taps behind
     if (ldw < KH * KW * Cs) return ASR_ERR_BAD_ARG;
+    {
+        // the eight-wave kernel of csrc/gemm8.hip for the wide products -- more than 128 output columns, channels a multiple of 64 -- in front
+        // of the LDS-resident kernel (tools/time_conv8.py, T = 1000, B = 32, 13 rows, 3 x 5 taps, us, LDS-resident / eight-wave:
+        // 256 -> 512 channels 1769 / 1189, 128 -> 512 981 / 662, 256 -> 256 956 / 643, 512 -> 256 1724 / 1227: 0.83 - 0.95 -> 1.24 - 1.38 PFLOP/s).
+        // ASR_DEBUG conv_8ph=0 (or an explicit nt_wide): never
+        static const int c8 = debug_flag("conv_8ph", 1);
+        if (c8 && nt_wide_mode() == -1 && N > 128 && asr_conv_nt_8ph_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N))
+            return asr_conv_nt_8ph(stream_, x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, sgn, Tr, Hr, N);
+    }
     // the kernel with the activation block resident in LDS (conv_direct.hip; at most 128 channels of it at a time, more in passes):
     // T=1000, B=32, us, implicit GEMM / direct: 64 -> 64 channels 111 / 67, 128 -> 64 (a backward-data) 206 / 166, 128 -> 256 595 / 483,
     // 128 -> 512 1085 / 938, 64 -> 128 138 / 134, 256 -> 128 544 / 462, 512 -> 128 1040 / 884, 256 -> 256 998 / 902

@@ -73,10 +73,18 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 
 // KT: K is a multiple of 8 but not of 64 (the logit gradient's K = V = 3000): the chunks of the last K step that lie beyond K are
 // fetched from beyond the buffers' ends, i.e. as zeros -- both operands.
-template <typename OutT, bool KT>
+// CONV: operand A is the activation tensor (Ts, B, Hs, Cs) of an implicit convolution (gemm.hip: ConvDesc): row r = (t, b, h) over the
+// row space (Tr, B, Hr), column k = (kh, kw, c); A[r][k] = x[t + sgn (kw - pt)][b][h + sgn (kh - ph)][c], zero outside the tensor.
+// Cs % 64 == 0: a K step lies inside ONE tap, so the tap walk is scalar state -- one per A half, each advanced by its own issues, which
+// come in K order -- and a lane adds a uniform offset to its row's own address and checks two ranges; a row outside the tensor or an
+// empty tap (K may be padded, and the loop's re-fetches beyond K walk on into empty taps) gets an offset beyond the buffer: zeros.
+struct ConvDesc8 {
+    int B, Hs, Cs, Ts, KH, KW, ph, pt, sgn, Hr;
+};
+template <typename OutT, bool KT, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
                                                             OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes) {
+                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes, ConvDesc8 cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // waves 4 (M) x 2 (N): a wave owns 64 rows x 128 columns = 4 x 8 MFMA tiles; waves i and i + 4 (one SIMD) are wm and wm + 2
@@ -97,6 +105,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
     unsigned oa[2][2], ob[2][2];            // [half][i]: byte offset of this thread's source chunk at k = 0
     int kc[2];                              // KT: first k of the slot's chunk inside a K step
+    int cth[2][2];                          // CONV: (t << 8) | h of the slot's row; rows beyond M get a t far below zero
+    int tw_kh[2] = {0, 0}, tw_kw[2] = {0, 0}, tw_ci[2] = {0, 0};      // CONV: tap of the next K step each A half issues
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int s = i * 512 + tid, rho = s >> 3, c = (s & 7) ^ (rho & 7);
@@ -105,7 +115,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         for (int h = 0; h < 2; ++h) {
             // A half h: LDS row rho = wm' * 32 + rr  <-  row m0 + wm' * 64 + h * 32 + rr
             const int grow = m0 + (rho >> 5) * 64 + h * 32 + (rho & 31);
-            oa[h][i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
+            if (CONV) {
+                const int rc = grow < M ? grow : 0;
+                const int hh = rc % cd.Hr, tb = rc / cd.Hr, bb = tb % cd.B, tt = tb / cd.B;
+                cth[h][i] = (grow < M ? tt : -(1 << 20)) * 256 + hh;
+                oa[h][i] = (unsigned)((tt * cd.B + bb) * cd.Hs + hh) * (unsigned)(cd.Cs * 2) + (unsigned)(c * 16);
+            } else {
+                oa[h][i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
+            }
             // B half h: LDS row rho = wn' * 64 + j * 16 + r  <-  column n0 + wn' * 128 + 8 r + (4 h + j)
             const int gcol = n0 + (rho >> 6) * 128 + 8 * (rho & 15) + 4 * h + ((rho >> 4) & 3);
             ob[h][i] = (unsigned)min(gcol, N - 1) * (unsigned)(ldb * 2) + (unsigned)(c * 16);
@@ -117,7 +134,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
         const int so = kt * 128;
         const bool d0 = KT && kt * 64 + kc[0] >= K, d1 = KT && kt * 64 + kc[1] >= K;
-        if (KIND < 2) {
+        if (KIND < 2 && CONV) {
+            constexpr int H = KIND & 1;
+            const int dt = cd.sgn * (tw_kw[H] - cd.pt), dh = cd.sgn * (tw_kh[H] - cd.ph);
+            const int delta = ((dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci[H]) * 2;
+            const bool tap_ok = tw_kh[H] < cd.KH;
+            tw_ci[H] += 64;
+            if (tw_ci[H] >= cd.Cs) { tw_ci[H] = 0; if (++tw_kw[H] == cd.KW) { tw_kw[H] = 0; ++tw_kh[H]; } }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ti = (cth[H][i] >> 8) + dt, hi = (cth[H][i] & 255) + dh;
+                const bool ok = tap_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                lds_dma16(rsrc_a, base + i * 8192, ok ? oa[H][i] + (unsigned)delta : 0xfffffff0u, 0);
+            }
+        } else if (KIND < 2) {
             lds_dma16(rsrc_a, base, d0 ? 0xfffffff0u : oa[KIND & 1][0], so);
             lds_dma16(rsrc_a, base + 8192, d1 ? 0xfffffff0u : oa[KIND & 1][1], so);
         } else {
@@ -501,15 +531,15 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     const unsigned a_bytes = (unsigned)((unsigned long long)M * lda * 2), b_bytes = (unsigned)((unsigned long long)N * ldb * 2);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
 #define ASR8_LAUNCH(T, CT, KT_)                                                                                                     \
-    hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
-                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes)
+    hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_, false>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
+                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{})
     const bool kt = (K & 63) != 0;
     if (out_bf16) { if (kt) ASR8_LAUNCH(uint16_t, uint16_t, true); else ASR8_LAUNCH(uint16_t, uint16_t, false); }
     else          { if (kt) ASR8_LAUNCH(float, float, true); else ASR8_LAUNCH(float, float, false); }
@@ -560,6 +590,41 @@ extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const
         attr = true;
     }
     hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// asr_conv_nt's products on the eight-wave kernel: the implicit convolution of gemm.hip (same arguments) with Cs % 64 == 0.
+extern "C" int asr_conv_nt_8ph_ok(const void* x, const void* W, int ldw, const void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
+                                  int Cs, int KH, int KW, int Tr, int Hr, int N) {
+    if (!x || !W || !out || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0 || N <= 0) return 0;
+    if ((Cs & 63) || (ldw & 63) || ldw < KH * KW * Cs || (ldw % Cs) || (N & 3) || Hs >= 256) return 0;
+    if ((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)out)) & 15) return 0;
+    if (bias && (((uintptr_t)bias) & 15)) return 0;
+    if ((unsigned long long)Ts * B * Hs * Cs * 2 >= 0x7ffffff0ull || (unsigned long long)N * ldw * 2 >= (1ull << 31) || (long long)Tr * B * Hr > 0x7fffffffLL) return 0;
+    return 1;
+}
+
+extern "C" int asr_conv_nt_8ph(void* stream_, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B,
+                               int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
+    if (sgn != 1 && sgn != -1) return ASR_ERR_BAD_ARG;
+    if (!asr_conv_nt_8ph_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N)) return ASR_ERR_UNSUPPORTED;
+    const int M = Tr * B * Hr, K = ldw;
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    const unsigned a_bytes = (unsigned)((unsigned long long)Ts * B * Hs * Cs * 2), b_bytes = (unsigned)((unsigned long long)N * ldw * 2);
+    const gemm8::ConvDesc8 cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, sgn, Hr};
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<uint16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8ph_kernel<float, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        attr = true;
+    }
+    if (out_bf16)
+        hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<uint16_t, false, true>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_,
+                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (uint16_t*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd);
+    else
+        hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<float, false, true>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_,
+                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (float*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -204,6 +204,13 @@ int asr_conv_weight_pack(void* stream, const float* W, void* dst_bf16, int Co, i
  * asr_conv_weight_pack_bwd: dst[ci][(kh*KW + kw)*Co + co] = W[co][ci][kh][kw] as bf16. */
 int asr_conv_nt(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B,
                 int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+/* asr_conv_nt_8ph: the same implicit convolution on the eight-wave kernel of csrc/gemm8.hip (Cs and the row pitch of W multiples of 64,
+ * N % 4 == 0, Hs < 256, 16-byte aligned operands: asr_conv_nt_8ph_ok); asr_conv_nt routes the products with more than 128 output
+ * columns that the LDS-resident kernel does not take to it. */
+int asr_conv_nt_8ph_ok(const void* x, const void* W, int ldw, const void* out, int out_bf16, const float* bias, int Ts, int B, int Hs, int Cs,
+                       int KH, int KW, int Tr, int Hr, int N);
+int asr_conv_nt_8ph(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
+                    int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
 /* The same product with the activation block of a tile resident in LDS (csrc/conv_direct.hip): one workgroup = one utterance x 256 / Hr
  * time steps x all Hr heights x 64 or 128 output columns; the (Tt + KW - 1) x (Hr + KH - 1) x Cs activations it can touch are loaded
  * once instead of once per tap.  bf16 output, Cs in {32, 64, 128, 256}, ldw % 32 == 0; asr_conv_direct_ok says whether a shape is

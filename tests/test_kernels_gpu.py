@@ -918,6 +918,37 @@ def test_implicit_conv_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph
     assert _rel(gW.cpu(), gW_ref.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True), (12, 2, 6, 256, 64, 3, 5, 1, True),
+                                                          (9, 2, 7, 64, 68, 1, 3, 0, False), (200, 8, 13, 256, 512, 3, 5, 1, True), (77, 2, 1, 64, 72, 1, 1, 0, True)])
+def test_conv_nt_8ph_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
+    """asr_conv_nt_8ph (csrc/gemm8.hip: the implicit convolution on the eight-wave kernel, tap walk as scalar state per operand half)
+    against im2col + GEMM, forward and backward-data, float32 and bf16 outputs; causal and symmetric time padding, a 1 x 1 kernel"""
+    from asr import _ops
+    rs = np.random.RandomState(T + Ci)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(BF16)
+    W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.1).astype(np.float32)).to(device)
+    bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
+    w16 = _ops.conv_weight_pack(W)
+    col = _ops.im2col(x, (x.stride(0), x.stride(1), x.stride(2), x.stride(3)), T, B, Hin, Ci, KH, KW, ph, pt, Tout)
+    ref = _ops.gemm_nt(col, w16, bias, torch.float32)
+    K = KH * KW * Ci
+    w16c = w16 if K % 64 == 0 else _ops.conv_weight_pack(W, Kp=(K + 63) // 64 * 64)      # (empty taps behind: the K step of the kernel)
+    got = _ops.conv_nt_8ph(x, w16c, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got.cpu(), ref.cpu()) < 1e-5
+    got16 = _ops.conv_nt_8ph(x, w16c, bias, BF16, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got16.float().cpu(), ref.cpu()) < 1e-2
+    if Co % 64 == 0:                        # backward-data: the gradient's channels are the K side
+        gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(BF16)
+        wb = _ops.conv_weight_pack_bwd(W)
+        if wb.shape[1] % 64 == 0 and Ci % 4 == 0:
+            ref_dx = _ops.conv_nt(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin)
+            got_dx = _ops.conv_nt_8ph(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin)
+            assert _rel(got_dx.cpu(), ref_dx.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
                                                           (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
                                                           (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),
