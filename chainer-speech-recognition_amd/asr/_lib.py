@@ -101,6 +101,8 @@ SIGNATURES = {
     "asr_conv_weight_pack": (c_int, [c_void_p] * 3 + [c_int] * 6),
     "asr_conv_weight_grad_unpack": (c_int, [c_void_p] * 3 + [c_int] * 6),
     "asr_conv_tn_acc": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
+    "asr_conv_tn_8ph_ok": (c_int, [c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 10),
+    "asr_conv_tn_acc_8ph": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
     "asr_conv_tn_copies": (c_int, [c_int] * 4),
     "asr_conv_tn_acc_copies": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 13),
     "asr_conv_weight_grad_unpack_copies": (c_int, [c_void_p, c_void_p, c_int, c_void_p] + [c_int] * 6),

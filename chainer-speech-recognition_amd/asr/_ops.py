@@ -190,6 +190,16 @@ def conv_tn_acc(g2, x, scratch, KH, KW, pad_h, pad_t, Tr, Hr):
     check(rc, "asr_conv_tn_acc_copies")
 
 
+def conv_tn_acc_8ph(g2, x, scratch, KH, KW, pad_h, pad_t, Tr, Hr):
+    """conv_tn_acc on the eight-wave kernel only (asr_conv_tn_acc_8ph: tests and timings; asr_conv_tn_acc dispatches by itself)"""
+    Ts, B, Hs, Cs = x.shape
+    Co = g2.shape[1]
+    assert tuple(scratch.shape) == (Co, KH * KW * Cs) and scratch.is_contiguous()
+    rc = _lib.lib().asr_conv_tn_acc_8ph(stream(), ptr(g2), g2.stride(0), ptr(x), ptr(scratch), scratch.shape[-1], Co, Ts, B, Hs, Cs, KH, KW,
+                                        pad_h, pad_t, Tr, Hr)
+    check(rc, "asr_conv_tn_acc_8ph")
+
+
 ACT_KINDS = {"relu": 0, "clipped_relu": 1, "leaky_relu": 2, "elu": 3, "sigmoid": 4, "tanh": 5, "hard_sigmoid": 6,
              "softplus": 7}
 

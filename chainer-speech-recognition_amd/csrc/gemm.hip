@@ -1628,7 +1628,7 @@ extern "C" int asr_gemm_tn_acc(void* stream_, const void* A, int lda, const void
         // the eight-wave kernel of csrc/gemm8.hip (tools/time_tn8.py: 32000 x 3000 x 320 116 -> 102 us, 416000 x 256 x 1920 554 -> 382;
         // the small dense gradients 640 x 512 / 640 x 320 tie); ASR_DEBUG tn_8ph=0 / tn256=2: never
         static const int use8 = debug_flag("tn_8ph", 1), tn256_forced = debug_flag("tn256", 1);
-        if (use8 && tn256_forced != 2 && K >= 2048 && (long long)M * N >= 256 * 256 && asr_gemm_tn_8ph_ok(A, lda, B, ldb, C, ldc, M, N, K)) {
+        if (use8 && tn256_forced != 2 && K >= 2048 && M >= 192 && N >= 192 && asr_gemm_tn_8ph_ok(A, lda, B, ldb, C, ldc, M, N, K)) {
             const void* a1[1] = {A};
             const void* b1[1] = {B};
             float* c1[1] = {C};
@@ -1723,6 +1723,14 @@ extern "C" int asr_conv_tn_acc_copies(void* stream_, const void* g, int ldg, con
     if (copies == 8 && asr_conv_tn_copies(Co, Cs, KH, KW) != 8) return ASR_ERR_BAD_ARG;
     if ((Cs & 7) || K > 0x7fffffffLL || (((uintptr_t)x) & 15)) return ASR_ERR_UNSUPPORTED;
     hipStream_t stream = (hipStream_t)stream_;
+    {
+        // the eight-wave kernel of csrc/gemm8.hip for the large gradients (at least one 256 x 256 tile's worth of outputs);
+        // ASR_DEBUG tn_8ph=0 / tn256=2: never
+        static const int use8 = debug_flag("tn_8ph", 1), tn256_forced = debug_flag("tn256", 1);
+        if (use8 && tn256_forced != 2 && copies == 1 && Co >= 192 && N >= 192 && K >= 2048 &&      // (64 -> 128 channels, half-empty 256-row tiles: 147 -> 185 us)
+            asr_conv_tn_8ph_ok(g, ldg, x, C, ldc, Co, Ts, B, Hs, Cs, KH, KW, Tr, Hr))
+            return asr_conv_tn_acc_8ph(stream_, g, ldg, x, C, ldc, Co, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, Tr, Hr);
+    }
     const ConvDesc cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
     if (tn256_ok(Co, ldg, 8, g, x, true)) {
         const int t2m = cdiv(Co, T2M), t2n = cdiv(N, T2N);

@@ -334,7 +334,12 @@ __device__ __forceinline__ void lds_tr8(u32x2& f, unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF) : "memory");
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split) {
+// CONV: operand B is the virtual im2col matrix of the activation tensor x (Ts, B, Hs, Cs): row k = (t, b, h) over the output positions
+// (Tr, B, Hr), column n = (kh, kw, c) -- the weight gradient of a convolution without a column matrix in memory.  A loader slot's
+// columns never change, so its tap and channel are loop invariant; its row walks on by 64 positions per issue (incremental (t, b, h)
+// with carries: no division in the loop).  One product per launch (grp.n == 1; P.B = x, P.ldb unused).
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split, ConvDesc8 cd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
@@ -362,8 +367,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
     // ---- loader: slot s = i * 512 + tid = (k row kr = s / 16, position s % 16) holds chunk (s % 16) ^ 2 (kr % 8); the K advance
     // goes into the VECTOR offset (the range check of a raw buffer access does not see the scalar offset): rows beyond K read zeros
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)((unsigned)K * (unsigned)lda * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)((unsigned)K * (unsigned)ldb * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)B, 0, CONV ? (int)((unsigned)cd.Ts * (unsigned)cd.B * (unsigned)cd.Hs * (unsigned)cd.Cs * 2u) : (int)((unsigned)K * (unsigned)ldb * 2u), 0x00020000);
     unsigned oa[2][2], ob[2][2];
+    int cv_ci[2][2], cv_dt[2][2], cv_dh[2][2], cv_t[2][2], cv_b[2][2], cv_h[2][2];      // CONV: [B half][slot]
+    bool cv_ok[2][2];
+    const int inc_h = CONV ? 64 % cd.Hr : 0, inc_b = CONV ? (64 / cd.Hr) % cd.B : 0, inc_t = CONV ? (64 / cd.Hr) / cd.B : 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int s = i * 512 + tid, kr = s >> 4, c = (s & 15) ^ ((kr & 7) << 1);
@@ -374,7 +383,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
             oa[h][i] = m < M ? (unsigned)(kbeg + kr) * (unsigned)(lda * 2) + (unsigned)(m * 2) : 0xfffffff0u;
             // B half h: chunk c = 8 columns of the N-wave c / 4: n0 + (c / 4) 64 + h 32 + (c % 4) 8
             const int n = n0 + (c >> 2) * 64 + h * 32 + (c & 3) * 8;
-            ob[h][i] = n < N ? (unsigned)(kbeg + kr) * (unsigned)(ldb * 2) + (unsigned)(n * 2) : 0xfffffff0u;
+            if (CONV) {
+                const int tap = n / cd.Cs, kh = tap / cd.KW, kw = tap - kh * cd.KW;
+                cv_ci[h][i] = n - tap * cd.Cs;
+                cv_dt[h][i] = kw - cd.pt;
+                cv_dh[h][i] = kh - cd.ph;
+                cv_ok[h][i] = n < N && kh < cd.KH;
+                const int gk = kbeg + kr;
+                cv_h[h][i] = gk % cd.Hr;
+                const int tb = gk / cd.Hr;
+                cv_b[h][i] = tb % cd.B;
+                cv_t[h][i] = tb / cd.B;
+                ob[h][i] = 0u;
+            } else {
+                ob[h][i] = n < N ? (unsigned)(kbeg + kr) * (unsigned)(ldb * 2) + (unsigned)(n * 2) : 0xfffffff0u;
+            }
         }
     }
     const unsigned stepa = (unsigned)(lda * 128), stepb = (unsigned)(ldb * 128);      // 64 k rows in bytes
@@ -386,6 +409,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
             const unsigned v0 = oa[KIND & 1][0], v1 = oa[KIND & 1][1];
             lds_dma16(rsrc_a, base, v0 == 0xfffffff0u ? v0 : v0 + ko, 0);
             lds_dma16(rsrc_a, base + 8192, v1 == 0xfffffff0u ? v1 : v1 + ko, 0);
+        } else if (CONV) {
+            constexpr int H = KIND & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int t = cv_t[H][i], b = cv_b[H][i], hq = cv_h[H][i];
+                {   // the same slot of the next K step (issues of one half come in K order; beyond the last step the walk simply goes on)
+                    int hh = hq + inc_h;
+                    const int c1 = hh >= cd.Hr;
+                    hh -= c1 ? cd.Hr : 0;
+                    int bb = b + inc_b + c1;
+                    const int c2 = bb >= cd.B;
+                    bb -= c2 ? cd.B : 0;
+                    cv_h[H][i] = hh; cv_b[H][i] = bb; cv_t[H][i] = t + inc_t + c2;
+                }
+                const int ti = t + cv_dt[H][i], hi = hq + cv_dh[H][i];
+                const bool ok = cv_ok[H][i] && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                const unsigned v = (unsigned)(((ti * cd.B + b) * cd.Hs + hi) * cd.Cs + cv_ci[H][i]) * 2u;
+                lds_dma16(rsrc_b, base + i * 8192, ok ? v : 0xfffffff0u, 0);
+            }
         } else {
             const unsigned ko = (unsigned)kt * stepb;
             const unsigned v0 = ob[KIND & 1][0], v1 = ob[KIND & 1][1];
@@ -586,10 +628,10 @@ extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const
     const int items = tiles * splits, grid = 8 * cdiv(items, 8);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split);
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<false>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, gemm8::ConvDesc8{});
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -625,6 +667,49 @@ extern "C" int asr_conv_nt_8ph(void* stream_, const void* x, const void* W, int 
     else
         hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<float, false, true>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_,
                            (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (float*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// asr_conv_tn_acc on the eight-wave kernel: C[Co, KH KW Cs] += g[(t, b, h), Co]^T . im2col(x)
+extern "C" int asr_conv_tn_8ph_ok(const void* g, int ldg, const void* x, const float* C, int ldc, int Co, int Ts, int B, int Hs, int Cs, int KH,
+                                  int KW, int Tr, int Hr) {
+    if (!g || !x || !C || Co <= 0 || Ts <= 0 || B <= 0 || Hs <= 0 || Cs <= 0 || KH <= 0 || KW <= 0 || Tr <= 0 || Hr <= 0) return 0;
+    const int N = KH * KW * Cs;
+    const long long K = (long long)Tr * B * Hr;
+    if ((Co & 7) || (Cs & 7) || (ldg & 7) || ldg < Co || ldc < N) return 0;
+    if ((((uintptr_t)g) | ((uintptr_t)x)) & 15) return 0;
+    if (K > 0x7fffffffLL || (unsigned long long)K * ldg * 2 >= (1ull << 31) || (unsigned long long)Ts * B * Hs * Cs * 2 >= 0x7ffffff0ull) return 0;
+    return 1;
+}
+
+extern "C" int asr_conv_tn_acc_8ph(void* stream_, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B, int Hs,
+                                   int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr) {
+    if (!asr_conv_tn_8ph_ok(g, ldg, x, C, ldc, Co, Ts, B, Hs, Cs, KH, KW, Tr, Hr)) return ASR_ERR_UNSUPPORTED;
+    const int N = KH * KW * Cs, K = Tr * B * Hr;
+    gemm8::Tn8Group grp{};
+    gemm8::Tn8Prob& q = grp.p[0];
+    q.A = (const uint16_t*)g; q.B = (const uint16_t*)x; q.C = C;
+    q.lda = ldg; q.ldb = 0; q.ldc = ldc; q.M = Co; q.N = N; q.K = K;
+    q.tiles_n = cdiv(N, 256);
+    const int tiles = cdiv(Co, 256) * q.tiles_n;
+    q.tile_end = tiles;
+    grp.n = 1;
+    static const int target = debug_flag("tn8_items", 256);
+    int splits = target / tiles;
+    if (splits < 1) splits = 1;
+    const int max_splits = cdiv(K, 512);
+    if (splits > max_splits) splits = max_splits;
+    const int k_per_split = cdiv(cdiv(K, splits), 64) * 64;
+    splits = cdiv(K, k_per_split);
+    const int items = tiles * splits, grid = 8 * cdiv(items, 8);
+    const gemm8::ConvDesc8 cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, +1, Hr};
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -245,6 +245,12 @@ int asr_conv_weight_pack_bwd(void* stream, const float* W, void* dst, int Co, in
  * pitch of the scratch rows (>= Ci; 0 = Ci). */
 int asr_conv_tn_acc(void* stream, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B, int Hs,
                     int Cs, int KH, int KW, int pad_h, int pad_t, int Tr, int Hr);
+/* asr_conv_tn_acc_8ph: the same weight gradient on the eight-wave kernel of csrc/gemm8.hip (Co, Cs, ldg multiples of 8, 16-byte aligned
+ * operands: asr_conv_tn_8ph_ok); asr_conv_tn_acc routes qualifying calls with at least 256 x 256 outputs to it. */
+int asr_conv_tn_8ph_ok(const void* g, int ldg, const void* x, const float* C, int ldc, int Co, int Ts, int B, int Hs, int Cs, int KH, int KW,
+                       int Tr, int Hr);
+int asr_conv_tn_acc_8ph(void* stream, const void* g, int ldg, const void* x, float* C, int ldc, int Co, int Ts, int B, int Hs, int Cs, int KH,
+                        int KW, int pad_h, int pad_t, int Tr, int Hr);
 int asr_conv_weight_grad_unpack(void* stream, const float* scratch, float* gW, int Co, int Ci, int KH, int KW, int Kp, int Cs);
 /* Few output tiles -> hundreds of K splits adding into the same few KB (first layer: 91 of 166 us were the atomics): with
  * asr_conv_tn_copies(...) == 8 the caller hands a zeroed scratch of 8 x (Co, ldc) floats, every XCD adds into its own copy, and

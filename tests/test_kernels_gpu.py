@@ -949,6 +949,27 @@ def test_conv_nt_8ph_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, 
             assert _rel(got_dx.cpu(), ref_dx.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 256, 3, 5, 1, True), (17, 2, 6, 32, 96, 3, 5, 1, True), (9, 2, 7, 64, 72, 1, 3, 0, False),
+                                                          (200, 8, 13, 128, 256, 3, 5, 1, True), (77, 2, 1, 64, 72, 1, 1, 0, True), (120, 5, 38, 8, 64, 3, 5, 0, True)])
+def test_conv_tn_8ph_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
+    """asr_conv_tn_acc_8ph (csrc/gemm8.hip: the weight gradient without a column matrix, the im2col rows walked incrementally per loader
+    slot) against gemm_tn_acc on the materialised column matrix -- small-integer operands give exact sums --, accumulated on top of what
+    is there; padded taps, a 1 x 1 kernel, 8 input channels (one tap per 16-byte chunk)"""
+    from asr import _ops
+    rs = np.random.RandomState(T + Ci + Co)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randint(-3, 4, size=(T, B, Hin, Ci)).astype(np.float32)).to(device).to(BF16)
+    gy = torch.from_numpy(rs.randint(-3, 4, size=(Tout, B, Hout, Co)).astype(np.float32)).to(device).to(BF16)
+    col = _ops.im2col(x, (x.stride(0), x.stride(1), x.stride(2), x.stride(3)), T, B, Hin, Ci, KH, KW, ph, pt, Tout)
+    K = KH * KW * Ci
+    ref = (gy.reshape(-1, Co).float().T @ col.float())[:, :K] + 2.0
+    got = torch.full((Co, K), 2.0, device=device)
+    _ops.conv_tn_acc_8ph(gy.reshape(-1, Co), x, got, KH, KW, ph, pt, Tout, Hout)
+    assert torch.equal(got.cpu(), ref.cpu())
+
+
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (17, 2, 6, 32, 96, 3, 5, 1, True),
                                                           (9, 2, 7, 64, 64, 1, 3, 0, False), (300, 4, 13, 64, 128, 3, 5, 0, True),
                                                           (23, 3, 13, 64, 256, 3, 5, 1, True), (11, 2, 7, 128, 192, 3, 5, 1, True),

@@ -36,3 +36,26 @@ for Ci, Co in [(256, 512), (128, 512), (256, 256), (512, 256)]:
             torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 5 * 1e3)
         print("%-18s %d -> %d channels forward: %.0f us (%.0f TFLOP/s)  [ASR_DEBUG=%s]" % (name, Ci, Co, best, fl / best / 1e6, os.environ.get("ASR_DEBUG", "")))
+print("weight gradients (asr_conv_tn_acc routed / asr_conv_tn_acc_8ph):")
+for Ci, Co in [(256, 512), (128, 256), (128, 512), (64, 128)]:
+    x = torch.randn(T, B, H, Ci).to(dev).to(BF16)
+    gy = torch.randn(T * B * H, Co).to(dev).to(BF16)
+    acc = torch.zeros(Co, KH * KW * Ci, device=dev)
+    fns = {"conv_tn_acc (routed)": lambda: _ops.conv_tn_acc(gy, x, acc, KH, KW, ph, pt, T, H)}
+    if os.environ.get("ASR_DEBUG", "") == "":
+        fns["conv_tn_acc_8ph"] = lambda: _ops.conv_tn_acc_8ph(gy, x, acc, KH, KW, ph, pt, T, H)
+    fl = 2.0 * T * B * H * Co * Ci * KH * KW
+    for name, fn in fns.items():
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        best = 1e9
+        for rnd in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 5 * 1e3)
+        print("%-22s %d -> %d channels: %.0f us (%.0f TFLOP/s)  [ASR_DEBUG=%s]" % (name, Ci, Co, best, fl / best / 1e6, os.environ.get("ASR_DEBUG", "")))
