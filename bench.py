@@ -696,7 +696,9 @@ def time_cnn_config(args, nconv, dev, steps=10):
                        % ("4 conv layers" if nconv <= 4 else "wide branch (8 conv layers)", B, T, V,
                           "IEEE half MFMA operands / activations (libasr_hip_f16.so), dynamic loss scaling" if half else "bf16 (see dtype_note)"),
            "dtype": "fp16" if half else "bf16", "steps_attempted": attempted, "steps_applied": applied, "loss_scale": scale[0],
-           "loss_scale_overflows": scale[1], "adam_alpha": alpha, "note": note,
+           "loss_scale_overflows": scale[1], "adam_alpha": alpha, "adam_alpha_requested": 1e-3,
+           "comparable_to_baseline": alpha == 1e-3,      # False: the recipe does not train in IEEE half at the BASELINE learning rate
+           "note": note,
            "ms_per_step": dt / steps * 1e3, "utterances_per_s": B * steps / dt, "steps": steps, "step_spread": spread,
            "final_loss": float(loss.item()),
            "gflop_per_utterance": 3 * 2.0 * macs * T / 1e9,
@@ -1066,8 +1068,10 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "dtype_note": "bf16 MFMA operands / activations, float32 accumulation, master weights, optimiser state, statistics, logits and "
                          "CTC.  The fp16 of BASELINE configs[4] is the IEEE-half build of the same kernels (libasr_hip_f16.so, ASR_ACT=f16, "
-                         "with chainer's loss_scaling on the device): extra_configs.cnn_*_fp16, measured in child processes; the "
-                         "recurrences (configs[1], this line) are bfloat16-only (DESIGN.md 13.9)",
+                         "with chainer's loss_scaling on the device): extra_configs.cnn_*_fp16, measured in child processes (the wide 8-layer "
+                         "recipe does NOT train in half at the BASELINE alpha = 1e-3 -- its entry says comparable_to_baseline: false and is "
+                         "measured at 1e-5; bf16 is the supported format there); the recurrences (configs[1], this line) are bfloat16-only "
+                         "(DESIGN.md 13.9)",
            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
            "config": {"workload": ("BASELINE configs[1]: 2xconv + 4xBiGRU-512 + dense + LayerNorm + CTC train step, "
                                    "B=%d/GPU, T=%d, 3x40 features, V=%d, labels 40..120" % (B, T, V)) if args.config == "ds2" else
