@@ -759,13 +759,12 @@ def pmc_traffic_of_this_build():
 def sq_profile():
     """per-kernel SQ counter summary of a `bench.py` step (rocprofv3 --pmc passes condensed by tools/pmc_sq.py into profiles/): a
     process cannot read its own PMC counters, so the line quotes the committed pass of this same command"""
-    for name in ("r04_pmc_sq.json", "r03_pmc_sq.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            try:
-                return json.load(open(path)), "profiles/" + name
-            except ValueError:
-                pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")), reverse=True):
+        try:
+            return json.load(open(path)), "profiles/" + os.path.basename(path)
+        except ValueError:
+            pass
     return None, None
 
 
