@@ -84,9 +84,17 @@ struct ConvDesc8 {
 template <typename OutT, bool KT, bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
                                                             OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
-                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes, ConvDesc8 cd) {
+                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes, ConvDesc8 cd, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Short K, several rounds of tiles per CU: every workgroup of a round reaches its 128 KB of stores at the same moment, the chip
+    // alternates between "everybody computes" and "everybody stores", and the stores of a round take as long as its K loop.  A start
+    // delay that differs between the workgroups of the FIRST round (stagger x 0 .. 7 units of ~1 us by workgroup id / 8 % 8; later
+    // workgroups start when a CU comes free and inherit the spread) lets one CU's stores run beside the others' K loops.
+    if (stagger > 0 && blockIdx.x < 256) {
+        const int n = (int)((blockIdx.x >> 3) & 7) * stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     // waves 4 (M) x 2 (N): a wave owns 64 rows x 128 columns = 4 x 8 MFMA tiles; waves i and i + 4 (one SIMD) are wm and wm + 2
     const int wm = wid >> 1, wn = wid & 1;
     // tiles: XCD x (= bid % 8 under round-robin dispatch; a locality hint only) takes a contiguous range of tile ids, so the column tiles of a
@@ -581,7 +589,9 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     }
 #define ASR8_LAUNCH(T, CT, KT_)                                                                                                     \
     hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_, false>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
-                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{})
+                       (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{}, stagger)
+    static const int stagger_env = debug_flag("nt8_stagger", 0);
+    const int stagger = (tiles_m * tiles_n > 256 && K <= 1024) ? stagger_env : 0;
     const bool kt = (K & 63) != 0;
     if (out_bf16) { if (kt) ASR8_LAUNCH(uint16_t, uint16_t, true); else ASR8_LAUNCH(uint16_t, uint16_t, false); }
     else          { if (kt) ASR8_LAUNCH(float, float, true); else ASR8_LAUNCH(float, float, false); }
@@ -663,10 +673,10 @@ extern "C" int asr_conv_nt_8ph(void* stream_, const void* x, const void* W, int 
     }
     if (out_bf16)
         hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<uint16_t, false, true>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_,
-                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (uint16_t*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd);
+                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (uint16_t*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd, 0);
     else
         hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<float, false, true>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_,
-                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (float*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd);
+                           (const uint16_t*)x, 0, (const uint16_t*)W, ldw, (float*)out, N, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, cd, 0);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
