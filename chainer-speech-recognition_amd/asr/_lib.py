@@ -75,6 +75,8 @@ SIGNATURES = {
     "asr_conv_nt": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
     "asr_conv_nt_8ph_ok": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9),
     "asr_conv_nt_8ph": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
+    "asr_conv_nt_8pn_ok": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 9),
+    "asr_conv_nt_8pn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p] + [c_int] * 12),
     "asr_conv_direct_ok": (c_int, [c_int] * 11),
     "asr_conv_direct_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p] + [c_int] * 12),
     "asr_conv_mp_ok": (c_int, [c_int] * 5),

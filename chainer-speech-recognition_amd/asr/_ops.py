@@ -857,6 +857,17 @@ def conv_nt_8ph(x, W2, bias, out_dtype, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     return out
 
 
+def conv_nt_8pn(x, W2, bias, out_dtype, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
+    """conv_nt on the narrow eight-wave kernel only (N <= 128; csrc/gemm8.hip): tests / tools"""
+    Ts, B, Hs, Cs = x.shape
+    N = W2.shape[0]
+    out = torch.empty((Tr * B * Hr, N), dtype=out_dtype, device=x.device)
+    rc = _lib.lib().asr_conv_nt_8pn(stream(), ptr(x), ptr(W2), W2.shape[1], ptr(out), _is_bf16(out), ptr(bias), Ts, B, Hs, Cs, KH, KW,
+                                    pad_h, pad_t, int(sgn), Tr, Hr, N)
+    check(rc, "asr_conv_nt_8pn")
+    return out
+
+
 def conv_direct_nt(x, W2, bias, KH, KW, pad_h, pad_t, sgn, Tr, Hr):
     """conv_nt through the LDS-resident kernel (csrc/conv_direct.hip), bf16 out; raises where asr_conv_direct_ok says no (tests / tools:
     asr_conv_nt dispatches by itself)"""

@@ -1786,6 +1786,12 @@ extern "C" int asr_conv_nt(void* stream_, const void* x, const void* W, int ldw,
         static const int c8 = debug_flag("conv_8ph", 1);
         if (c8 && nt_wide_mode() == -1 && N > 128 && asr_conv_nt_8ph_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N))
             return asr_conv_nt_8ph(stream_, x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, sgn, Tr, Hr, N);
+        // its narrow form (256 x 64 / 256 x 128 tiles) where the LDS-resident kernel needs several passes over the channels
+        // (tools/time_conv8n.py: backward-data 256 -> 128 channels 527 -> 470 us, 512 -> 128 967 -> 904; with up to 128 channels the
+        // LDS-resident kernel stays ahead: 64 -> 128 115 against 199, 128 -> 64 176 against 198 -- a narrow tile is bound by operand fill)
+        if (c8 && nt_wide_mode() == -1 && N <= 128 && N >= 64 && Cs >= 256 &&
+            asr_conv_nt_8pn_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N))
+            return asr_conv_nt_8pn(stream_, x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, pad_h, pad_t, sgn, Tr, Hr, N);
     }
     // the kernel with the activation block resident in LDS (conv_direct.hip; at most 128 channels of it at a time, more in passes):
     // T=1000, B=32, us, implicit GEMM / direct: 64 -> 64 channels 111 / 67, 128 -> 64 (a backward-data) 206 / 166, 128 -> 256 595 / 483,

@@ -311,6 +311,214 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, narrow: N <= 128
+// Products with few output columns (backward-data of a convolution into 64 or 128 input channels: M = T B H rows, K = taps x channels)
+// waste three quarters of a 256 x 256 tile.  Tile 256 x TNW (64 or 128), waves 8 (M) x 1 (N): a wave owns 32 rows x all columns, the two
+// groups of four waves (waves i and i + 4 share a SIMD) again run one barrier apart.  A K step of 64 is ONE phase at TNW = 64 (12 fragment
+// reads, 16 MFMAs) and TWO at TNW = 128 (the B halves; A stays in registers).  Such a tile is bound by operand fill (40 KB per 128 MFMAs at
+// TNW = 64), so the ring is as deep as LDS allows: TNW = 64: four stages of 40 KiB (all 160 KiB), a K step is issued two phases ahead and
+// restaged two phases after its last read; TNW = 128: three stages of 48 KiB, half a K step (A rows 0 .. 127 + B half 0, then the rest)
+// issued per phase, two K steps ahead.  `vmcnt` leaves exactly the last two phases' issues in flight (5 resp. 6 instructions per thread).
+template <typename OutT, bool CONV, int TNW>
+__global__ __launch_bounds__(512, 2) void gemm_nt_8pn_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
+                                                            OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                            int tiles_m, unsigned a_bytes, unsigned b_bytes, ConvDesc8 cd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NJ = TNW / 16;                              // column tiles of a wave
+    constexpr int A_BYTES = 256 * 128, B_BYTES = TNW * 128, STAGE = A_BYTES + B_BYTES, NSTAGE = TNW == 64 ? 4 : 3;
+    constexpr int BG = TNW / 64;                              // LDS-DMA instructions per thread for a K step of B
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wg;
+    {
+        const int nwg = tiles_m, qq = nwg >> 3, rr = nwg & 7, x = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        wg = (x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq) + idx;      // contiguous row panels per XCD (the taps' re-reads stay in one L2)
+    }
+    const int m0 = wg * 256;
+    const int nk = K >> 6;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+    // loader: A slot s = i * 512 + tid (i < 4): LDS row s / 8 = tile row, position s % 8 holds chunk (s % 8) ^ (row % 8);
+    // B slot s = i * 512 + tid (i < BG): LDS row rho = j * 16 + r  <-  column G r + j % G + (j / G) 16 G, G = min(NJ, 8) columns per lane run
+    unsigned oa[4], ob[BG];
+    int cth[4];
+    int tw_kh = 0, tw_kw = 0, tw_ci = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = i * 512 + tid, rho = s >> 3, c = (s & 7) ^ (rho & 7);
+        const int grow = m0 + rho;
+        if (CONV) {
+            const int rc = grow < M ? grow : 0;
+            const int hh = rc % cd.Hr, tb = rc / cd.Hr, bb = tb % cd.B, tt = tb / cd.B;
+            cth[i] = (grow < M ? tt : -(1 << 20)) * 256 + hh;
+            oa[i] = (unsigned)((tt * cd.B + bb) * cd.Hs + hh) * (unsigned)(cd.Cs * 2) + (unsigned)(c * 16);
+        } else {
+            cth[i] = 0;
+            oa[i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
+        }
+    }
+    constexpr int G = NJ < 8 ? NJ : 8;
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int s = i * 512 + tid, rho = s >> 3, c = (s & 7) ^ (rho & 7);
+        const int j = rho >> 4, r_ = rho & 15;
+        const int gcol = G * r_ + (j % G) + (j / G) * (16 * G);
+        ob[i] = (unsigned)min(gcol, N - 1) * (unsigned)(ldb * 2) + (unsigned)(c * 16);
+    }
+    // A part `part` (TNW = 128: rows 128 part .. + 127 = slots 2 part, 2 part + 1; TNW = 64: part < 0 = all four slots) of the NEXT K step in
+    // K order; CONV: the tap state advances when the K step's last part has been issued
+    auto issue_a = [&](int stage, int part, bool last_part, int kt) {
+        char* base = smem + stage * STAGE + wid * 1024;
+        int dt = 0, dh = 0, delta = 0;
+        bool tap_ok = true;
+        if (CONV) {
+            dt = cd.sgn * (tw_kw - cd.pt); dh = cd.sgn * (tw_kh - cd.ph);
+            delta = ((dt * cd.B * cd.Hs + dh) * cd.Cs + tw_ci) * 2;
+            tap_ok = tw_kh < cd.KH;
+            if (last_part) { tw_ci += 64; if (tw_ci >= cd.Cs) { tw_ci = 0; if (++tw_kw == cd.KW) { tw_kw = 0; ++tw_kh; } } }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (part >= 0 && (i >> 1) != part) continue;
+            if (CONV) {
+                const int ti = (cth[i] >> 8) + dt, hi = (cth[i] & 255) + dh;
+                const bool ok = tap_ok && (unsigned)ti < (unsigned)cd.Ts && (unsigned)hi < (unsigned)cd.Hs;
+                lds_dma16(rsrc_a, base + i * 8192, ok ? oa[i] + (unsigned)delta : 0xfffffff0u, 0);
+            } else {
+                lds_dma16(rsrc_a, base + i * 8192, oa[i], kt * 128);
+            }
+        }
+    };
+    auto issue_b = [&](int stage, int half, int kt) {          // half < 0: all of B (TNW = 64)
+        char* base = smem + stage * STAGE + A_BYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            if (half < 0 || i == half) lds_dma16(rsrc_b, base + i * 8192, ob[i], kt * 128);
+    };
+
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned al0 = lds0 + (unsigned)((wid * 32 + r) * 128 + ((q ^ (r & 7)) << 4)), al1 = al0 ^ 64u;
+    const unsigned bl0 = lds0 + (unsigned)(A_BYTES + r * 128 + ((q ^ (r & 7)) << 4)), bl1 = bl0 ^ 64u;
+
+    f32x4 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag a[2][2], b[4][2];
+    auto read_a = [&](unsigned so) {
+        lds_rd16<0>(a[0][0], al0 + so); lds_rd16<0>(a[0][1], al1 + so);
+        lds_rd16<2048>(a[1][0], al0 + so); lds_rd16<2048>(a[1][1], al1 + so);
+    };
+    auto read_b = [&](unsigned so, auto half_c) {              // column tiles 4 half .. 4 half + 3
+        constexpr int HO = decltype(half_c)::value * 8192;
+        lds_rd16<HO + 0 * 2048>(b[0][0], bl0 + so); lds_rd16<HO + 0 * 2048>(b[0][1], bl1 + so);
+        lds_rd16<HO + 1 * 2048>(b[1][0], bl0 + so); lds_rd16<HO + 1 * 2048>(b[1][1], bl1 + so);
+        lds_rd16<HO + 2 * 2048>(b[2][0], bl0 + so); lds_rd16<HO + 2 * 2048>(b[2][1], bl1 + so);
+        lds_rd16<HO + 3 * 2048>(b[3][0], bl0 + so); lds_rd16<HO + 3 * 2048>(b[3][1], bl1 + so);
+    };
+    auto mfma16 = [&](auto j0_c) {
+        constexpr int J0 = decltype(j0_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[i][J0 + j]);
+    };
+#define ASR8N_LOAD_END()                                                                                   \
+    do {                                                                                                   \
+        if (TNW == 64) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");                        \
+        else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");                                  \
+    } while (0)
+
+    // prologue: K steps 0 and 1 (the re-fetches beyond K go on into empty taps / the clamped last step)
+    issue_a(0, -1, true, 0);
+    issue_b(0, -1, 0);
+    issue_a(1 % NSTAGE, -1, true, min(1, nk - 1));
+    issue_b(1 % NSTAGE, -1, min(1, nk - 1));
+    if (TNW == 64) asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    const int grp = wid >> 2;
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");
+    int st = 0, st2 = 2 % NSTAGE;                              // stage of K step t, of K step t + 2
+    for (int t = 0; t < nk; ++t) {
+        const int t2 = min(t + 2, nk - 1);
+        const unsigned so = (unsigned)(st * STAGE);
+        if (TNW == 64) {
+            read_b(so, ASR8_C(0));
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(so);
+            issue_a(st2, -1, true, t2);
+            issue_b(st2, -1, t2);
+            ASR8N_LOAD_END();
+            ASR8_COMPUTE_BEGIN();
+            mfma16(ASR8_C(0));
+            ASR8_COMPUTE_END();
+        } else {
+            read_b(so, ASR8_C(0));
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(so);
+            issue_a(st2, 0, false, t2);
+            issue_b(st2, 0, t2);
+            ASR8N_LOAD_END();
+            ASR8_COMPUTE_BEGIN();
+            mfma16(ASR8_C(0));
+            ASR8_COMPUTE_END();
+            read_b(so, ASR8_C(1));
+            issue_a(st2, 1, true, t2);
+            issue_b(st2, 1, t2);
+            ASR8N_LOAD_END();
+            ASR8_COMPUTE_BEGIN();
+            mfma16(ASR8_C((NJ > 4 ? 4 : 0)));
+            ASR8_COMPUTE_END();
+        }
+        st = st == NSTAGE - 1 ? 0 : st + 1;
+        st2 = st2 == NSTAGE - 1 ? 0 : st2 + 1;
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: acc[i][j][reg] = C[m0 + wid 32 + i 16 + 4 q + reg][G r + j % G + (j / G) 16 G]
+    const int row0 = m0 + wid * 32 + 4 * q;
+    const bool c16 = (ldc & 7) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + i * 16 + reg;
+            if (row >= M) continue;
+#pragma unroll
+            for (int gq = 0; gq < NJ / G; ++gq) {
+                const int col = G * r + gq * (16 * G);
+                if (col >= N) continue;
+                OutT* dst = C + (size_t)row * ldc + col;
+                float v[G];
+#pragma unroll
+                for (int j = 0; j < G; ++j) v[j] = acc[i][gq * G + j][reg] + ((bias && col + j < N) ? bias[col + j] : 0.f);
+                if (sizeof(OutT) == 4) {
+#pragma unroll
+                    for (int j = 0; j < G; j += 4)
+                        if (col + j < N) *reinterpret_cast<float4*>(dst + j) = make_float4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+                } else if (G == 8 && c16 && col + 7 < N) {
+                    uint4 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.z = pack_bf16x2(v[G == 8 ? 4 : 0], v[G == 8 ? 5 : 1]); pk.w = pack_bf16x2(v[G == 8 ? 6 : 2], v[G == 8 ? 7 : 3]);
+                    *reinterpret_cast<uint4*>(dst) = pk;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < G; j += 4)
+                        if (col + j < N) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(v[j], v[j + 1]); pk.y = pack_bf16x2(v[j + 2], v[j + 3]);
+                            *reinterpret_cast<uint2*>(dst + j) = pk;
+                        }
+                }
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ TN: C[M,N] += A[K,M]^T B[K,N]
 // The weight gradients (dW = dy^T x: K = T B = 32000 rows, M and N a few hundred to a few thousand) on the same schedule.  Both
 // operands are k-strided in memory, so the LDS images keep the memory order -- a half tile is 64 k rows x 128 columns (256 B per row) --
@@ -720,6 +928,39 @@ extern "C" int asr_conv_tn_acc_8ph(void* stream_, const void* g, int ldg, const 
         attr = true;
     }
     hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
+}
+
+// the narrow form (N <= 128) of asr_conv_nt_8ph: same arguments
+extern "C" int asr_conv_nt_8pn_ok(const void* x, const void* W, int ldw, const void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
+                                  int Cs, int KH, int KW, int Tr, int Hr, int N) {
+    if (N > 128) return 0;
+    return asr_conv_nt_8ph_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N);
+}
+
+extern "C" int asr_conv_nt_8pn(void* stream_, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B,
+                               int Hs, int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N) {
+    if (sgn != 1 && sgn != -1) return ASR_ERR_BAD_ARG;
+    if (!asr_conv_nt_8pn_ok(x, W, ldw, out, out_bf16, bias, Ts, B, Hs, Cs, KH, KW, Tr, Hr, N)) return ASR_ERR_UNSUPPORTED;
+    const int M = Tr * B * Hr, K = ldw;
+    const int tiles_m = cdiv(M, 256);
+    const unsigned a_bytes = (unsigned)((unsigned long long)Ts * B * Hs * Cs * 2), b_bytes = (unsigned)((unsigned long long)N * ldw * 2);
+    const gemm8::ConvDesc8 cd{B, Hs, Cs, Ts, KH, KW, pad_h, pad_t, sgn, Hr};
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pn_kernel<uint16_t, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pn_kernel<float, true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 40960);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pn_kernel<uint16_t, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+        (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pn_kernel<float, true, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 49152);
+        attr = true;
+    }
+#define ASR8N(T, CT, W_, LDS)                                                                                                        \
+    hipLaunchKernelGGL((gemm8::gemm_nt_8pn_kernel<T, true, W_>), dim3(tiles_m), dim3(512), LDS, (hipStream_t)stream_, (const uint16_t*)x, 0, \
+                       (const uint16_t*)W, ldw, (CT*)out, N, bias, M, N, K, tiles_m, a_bytes, b_bytes, cd)
+    if (N <= 64) { if (out_bf16) ASR8N(uint16_t, uint16_t, 64, 4 * 40960); else ASR8N(float, float, 64, 4 * 40960); }
+    else         { if (out_bf16) ASR8N(uint16_t, uint16_t, 128, 3 * 49152); else ASR8N(float, float, 128, 3 * 49152); }
+#undef ASR8N
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -211,6 +211,11 @@ int asr_conv_nt_8ph_ok(const void* x, const void* W, int ldw, const void* out, i
                        int KH, int KW, int Tr, int Hr, int N);
 int asr_conv_nt_8ph(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
                     int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
+/* asr_conv_nt_8pn: the narrow form (N <= 128 output columns: 256 x 64 / 256 x 128 tiles) of the same kernel family */
+int asr_conv_nt_8pn_ok(const void* x, const void* W, int ldw, const void* out, int out_bf16, const float* bias, int Ts, int B, int Hs, int Cs,
+                       int KH, int KW, int Tr, int Hr, int N);
+int asr_conv_nt_8pn(void* stream, const void* x, const void* W, int ldw, void* out, int out_bf16, const float* bias, int Ts, int B, int Hs,
+                    int Cs, int KH, int KW, int pad_h, int pad_t, int sgn, int Tr, int Hr, int N);
 /* The same product with the activation block of a tile resident in LDS (csrc/conv_direct.hip): one workgroup = one utterance x 256 / Hr
  * time steps x all Hr heights x 64 or 128 output columns; the (Tt + KW - 1) x (Hr + KH - 1) x Cs activations it can touch are loaded
  * once instead of once per tap.  bf16 output, Cs in {32, 64, 128, 256}, ldw % 32 == 0; asr_conv_direct_ok says whether a shape is

@@ -949,6 +949,40 @@ def test_conv_nt_8ph_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, 
             assert _rel(got_dx.cpu(), ref_dx.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 128, 3, 5, 0, True), (41, 3, 11, 128, 64, 3, 5, 0, True), (9, 2, 7, 64, 64, 1, 3, 0, False),
+                                                          (300, 4, 13, 64, 128, 3, 5, 1, True), (77, 2, 1, 64, 72, 1, 1, 0, True), (150, 4, 13, 128, 40, 3, 5, 1, True),
+                                                          (33, 2, 5, 192, 100, 3, 3, 1, False)])
+def test_conv_nt_8pn_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
+    """asr_conv_nt_8pn (csrc/gemm8.hip: the narrow tiles, 256 x 64 with a four-stage ring that takes all of LDS, 256 x 128 with three
+    stages) against im2col + GEMM, forward (N = Co <= 128) and -- where the gradient's channels are a multiple of 64 -- backward-data
+    (N = Ci), float32 and bf16 outputs, ragged N"""
+    from asr import _ops
+    rs = np.random.RandomState(T + Ci + 1)
+    pt = KW - 1
+    Tout = T if causal else T + 2 * pt - KW + 1
+    Hout = Hin + 2 * ph - KH + 1
+    x = torch.from_numpy(rs.randn(T, B, Hin, Ci).astype(np.float32)).to(device).to(BF16)
+    W = torch.from_numpy((rs.randn(Co, Ci, KH, KW) * 0.1).astype(np.float32)).to(device)
+    bias = torch.from_numpy(rs.randn(Co).astype(np.float32)).to(device)
+    w16 = _ops.conv_weight_pack(W)
+    col = _ops.im2col(x, (x.stride(0), x.stride(1), x.stride(2), x.stride(3)), T, B, Hin, Ci, KH, KW, ph, pt, Tout)
+    ref = _ops.gemm_nt(col, w16, bias, torch.float32)
+    K = KH * KW * Ci
+    w16c = w16 if K % 64 == 0 else _ops.conv_weight_pack(W, Kp=(K + 63) // 64 * 64)
+    got = _ops.conv_nt_8pn(x, w16c, bias, torch.float32, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got.cpu(), ref.cpu()) < 1e-5
+    got16 = _ops.conv_nt_8pn(x, w16c, bias, BF16, KH, KW, ph, pt, +1, Tout, Hout)
+    assert _rel(got16.float().cpu(), ref.cpu()) < 1e-2
+    if Co % 64 == 0 and Ci <= 128 and Ci % 4 == 0:
+        gy = torch.from_numpy(rs.randn(Tout, B, Hout, Co).astype(np.float32)).to(device).to(BF16)
+        wb = _ops.conv_weight_pack_bwd(W)
+        if wb.shape[1] % 64 == 0:
+            dcol = _ops.gemm_nt(gy.reshape(-1, Co), _ops.conv_weight_pack(W, transpose=True), None, torch.float32)
+            ref_dx = _ops.col2im(dcol.to(BF16), T, B, Hin, Ci, KH, KW, ph, pt, Tout).float().reshape(-1, Ci)
+            got_dx = _ops.conv_nt_8pn(gy, wb, None, torch.float32, KH, KW, ph, pt, -1, T, Hin)
+            assert _rel(got_dx.cpu(), ref_dx.cpu()) < 2e-2      # the reference path rounds dcol to bf16 before the gather
+
+
 @pytest.mark.parametrize("T,B,Hin,Ci,Co,KH,KW,ph,causal", [(23, 3, 13, 64, 256, 3, 5, 1, True), (17, 2, 6, 32, 96, 3, 5, 1, True), (9, 2, 7, 64, 72, 1, 3, 0, False),
                                                           (200, 8, 13, 128, 256, 3, 5, 1, True), (77, 2, 1, 64, 72, 1, 1, 0, True), (120, 5, 38, 8, 64, 3, 5, 0, True)])
 def test_conv_tn_8ph_matches_im2col_gemm(device, T, B, Hin, Ci, Co, KH, KW, ph, causal):
