@@ -1008,6 +1008,13 @@ def main():
 
     comm = None
     if world > 1 or os.environ.get("ASR_BENCH_FORCE_COMM") == "1":      # the latter: exercise the RCCL path on one GPU
+        if world == 1:          # a bare shell: the env:// rendezvous of a single rank
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port))):
+                os.environ.setdefault(k, v)
         from asr.parallel import Communicator
         comm = Communicator(os.environ.get("ASR_BENCH_BACKEND", "nccl"))
         comm.measure = True
