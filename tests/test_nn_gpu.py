@@ -76,6 +76,38 @@ def test_full_size_feature_batch(device):
     assert d.max() <= 5e-4 and (d > 2e-4).sum() <= 3 and float(np.sqrt((d ** 2).mean())) <= 3e-5
 
 
+def test_mel_band_table_and_its_fallbacks(device):
+    """asr_specgram_bands with the band table (the shipped path), without one (dense rows read from memory) and with a matrix the table
+    cannot hold (80 filters > 64): the same log-mel values to the last bits of the float32 sums, and the one-workgroup-per-frame kernels (ASR_DEBUG fbank_fast=0's path, reached here through a frame
+    step that is not a multiple of 4) agree with them to float32 rounding"""
+    from asr import fft
+    rs = np.random.RandomState(5)
+    B, N = 3, 12000
+    sig = torch.from_numpy(np.round(rs.randn(B, N) * 3000).astype(np.int16)).to(device)
+    lens = torch.tensor([N, 9000, 4321], dtype=torch.int32, device=device)
+    window = torch.tensor(np.hanning(512), dtype=F32, device=device)
+    for nfilt in (40, 80):
+        fb = torch.tensor(fft.get_filterbanks(nfilt, 512, 16000), dtype=F32, device=device)
+        frames = [fft.num_frames(int(n), 512, 160) for n in lens.cpu()]
+        nfr = torch.tensor(frames, dtype=torch.int32, device=device)
+        bands = fft.mel_bands(fb)
+        table = bands.cpu()
+        assert (int(table[64]) >= 0) == (nfilt <= 64)                       # len8[0] = -1: "did not fit"
+        _, with_table = fft._specgram(sig, lens, nfr, max(frames), 512, 160, 512, 0.97, window, fb, False, bands)
+        _, dense = fft._specgram(sig, lens, nfr, max(frames), 512, 160, 512, 0.97, window, fb, False, None)
+        for b in range(B):
+            diff = float((with_table[b, :frames[b]] - dense[b, :frames[b]]).abs().max())
+            assert diff <= 4e-6, (nfilt, b, diff)      # (log-mel ~ 7 .. 20: last-bit differences of the float32 sums)
+        # frame step 162 (not a multiple of 4): the general kernel; same framing arithmetic on the host
+        frames2 = [fft.num_frames(int(n), 512, 162) for n in lens.cpu()]
+        nfr2 = torch.tensor(frames2, dtype=torch.int32, device=device)
+        ps_fast, _ = fft._specgram(sig, lens, nfr, max(frames), 512, 160, 512, 0.97, window, None, True)
+        ps_gen, _ = fft._specgram(sig[:, :N - 2].contiguous(), torch.clamp(lens, max=N - 2), nfr2, max(frames2), 512, 162, 512, 0.97, window, None, True)
+        assert ps_gen.shape[1] == max(frames2) and torch.isfinite(ps_gen[0, :frames2[0]]).all()
+        # frame 0 starts at sample 0 in both framings: identical input, two different kernels
+        np.testing.assert_allclose(ps_gen[:, 0].cpu().numpy(), ps_fast[:, 0].cpu().numpy(), rtol=2e-4, atol=float(ps_fast[:, 0].max()) * 1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ SRU
 @pytest.mark.parametrize("name", ["tanh", "linear"])
 def test_sru_forward_golden(device, golden_dir, name):
