@@ -262,6 +262,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
     if (grp == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the re-fetches beyond K still write LDS: drained before the workgroup leaves)
 
+    if (stagger < 0) {          // what-if (ASR_DEBUG nt8_stagger=-1: timing only, results invalid): no stores except one dword per wave
+        if (lane == 0) reinterpret_cast<float*>(C)[(size_t)blockIdx.x * 8 + wid] = acc[0][0][0] + acc[3][7][3];
+        return;
+    }
     // ---- epilogue: acc[I][J][reg] = C[m0 + wm * 64 + I * 16 + 4 q + reg][n0 + wn * 128 + 8 r + J]: 16 bytes of bf16 (32 of f32) per lane
     // and row, the 16 lanes of a row 256 (512) contiguous bytes; 16 store instructions per lane (the store tail is issue-bound: 8-byte
     // stores, 32 per lane, took as long as the eight K steps of a K = 512 product)
@@ -799,7 +803,7 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_, false>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
                        (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{}, stagger)
     static const int stagger_env = debug_flag("nt8_stagger", 0);
-    const int stagger = (tiles_m * tiles_n > 256 && K <= 1024) ? stagger_env : 0;
+    const int stagger = (stagger_env < 0 || (tiles_m * tiles_n > 256 && K <= 1024)) ? stagger_env : 0;
     const bool kt = (K & 63) != 0;
     if (out_bf16) { if (kt) ASR8_LAUNCH(uint16_t, uint16_t, true); else ASR8_LAUNCH(uint16_t, uint16_t, false); }
     else          { if (kt) ASR8_LAUNCH(float, float, true); else ASR8_LAUNCH(float, float, false); }
