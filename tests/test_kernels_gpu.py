@@ -469,8 +469,12 @@ def test_fused_maxout_pool_equals_the_two_kernels(device, T, B, H, C, k):
         db = torch.ones(2 * C, device=device)
         dx2 = _ops.maxout2_pool_bwd(xd, gy, k, db)
         assert torch.equal(dx2, dx_ref)
-        ref = 1.0 + dx_ref.float().reshape(-1, 2 * C).sum(0)
-        assert torch.allclose(db, ref, rtol=1e-5, atol=1e-4)
+        cols = dx_ref.double().reshape(-1, 2 * C)
+        ref = 1.0 + cols.sum(0)
+        # float32 atomics in launch order: exact for bf16 gradients of this size, rounding for f16 ones (ASR_ACT=f16: 11-bit
+        # mantissas, 182400 rows) -- bounded by a few ulp of the column's sum of magnitudes; a dropped round is off by the sum itself
+        tol = 1e-4 + 2e-7 * float(cols.abs().sum(0).max())
+        assert float((db.double() - ref).abs().max()) <= tol
     else:
         assert C == 24
 
