@@ -315,6 +315,275 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
         }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, persistent: short K, many tiles
+// With K = 512 a tile's K loop is eight steps (11 us) and what surrounds it costs as much again (tools/nt8_k_sweep.py: ~45 us of a 122 us
+// product): the workgroup's 128 KB of output leave after its K loop, the workgroup may only end when the last store is acknowledged, and
+// its successor on the CU starts with an empty pipeline.  This form keeps ONE workgroup per CU for the whole product:
+//  * the K steps of its tiles are ONE stream: the loader walks on into the next tile's operands while the last steps of the current one
+//    are computed (where the one-tile kernel re-fetches the last step as a dummy);
+//  * a finished tile leaves IN PIECES during the first K step of the next one, beside the partner group's MFMAs on the same SIMD (a bulk
+//    epilogue between the tiles cost 3.8 us per tile in vector instructions alone, what-if in profiles/r05_gemm8_ab.txt): the load segment
+//    of phase 0 converts and stores the wave's rows I = 0, 1 (quadrants 0 and 1 rewrite them in phases 0 and 1), that of phase 2 its rows
+//    I = 2, 3 -- whole 16-byte pieces of a row per lane, 256 (512) contiguous bytes per 16 lanes: quadrant-wise 8-byte pieces, the two
+//    halves of a 16-byte chunk written phases apart, ran SLOWER than the one-tile kernel (partial lines leave L2 before their other half
+//    arrives) -- and the load segment of phase p re-initialises quadrant p;
+//  * the bias is the accumulators' INITIAL value (read from the 32 KiB of LDS the operand ring leaves free, by inline asm like the
+//    fragments: a vector load in the loop would make hipcc drain the ring), so a piece is a conversion and a store;
+//  * `vmcnt` counts loads and stores together, in order.  The schedule's rule -- at the end of a load segment everything but the four
+//    youngest half tiles is complete -- becomes vmcnt(8 + stores issued since the fourth-youngest half tile): with 8 (bf16) stores in
+//    phases 0 and 2: 16, 16, 24, 16 in the K step that carries the pieces and 16, 8, 8, 8 in the one after it (f32, 16 stores: 24, 24, 40,
+//    24 | 24, 8, 8, 8).  A piece's stores come BEFORE its segment's LDS-DMA instructions and are always the same number of instructions:
+//    rows and columns that do not exist get an offset beyond the buffer, never a branch.  A piece's stores must be acknowledged three
+//    phases after they were issued; that wait is what is left of the store tail.
+// K % 64 == 0, K >= 128, N <= 8192 (bf16 output: N % 8 == 0, ldc % 8 == 0), C below 4 GiB.  Tiles: XCD x owns a contiguous range of tile ids (column tiles of a row panel meet in
+// one L2); its S = gridDim / 8 workgroups take tiles beg + slot, beg + slot + S, ...
+#define ASR8P_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+#define ASR8P_LOAD_END(H1, H2, F1, F2)                                                          \
+    do {                                                                                        \
+        if (mode == 0) ASR8P_WAIT(8);                                                           \
+        else if (mode == 1) { if (ES == 4) ASR8P_WAIT(F1); else ASR8P_WAIT(H1); }               \
+        else { if (ES == 4) ASR8P_WAIT(F2); else ASR8P_WAIT(H2); }                              \
+    } while (0)
+template <typename OutT>
+__global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb,
+                                                            OutT* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K,
+                                                            int tiles_m, int tiles_n, unsigned a_bytes, unsigned b_bytes, unsigned c_bytes,
+                                                            int whatif) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = (int)sizeof(OutT);
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nk = K >> 6;
+    int tile, tile_end;
+    const int S = (int)(gridDim.x >> 3);
+    {
+        const int nwg = tiles_m * tiles_n, qq = nwg >> 3, rr = nwg & 7, x = blockIdx.x & 7;
+        const int beg = x < rr ? x * (qq + 1) : rr * (qq + 1) + (x - rr) * qq;
+        tile_end = beg + (x < rr ? qq + 1 : qq);
+        tile = beg + (int)(blockIdx.x >> 3);
+    }
+    if (tile >= tile_end) return;
+    float* sbias = reinterpret_cast<float*>(smem + LDS_BYTES);
+    for (int i = tid; i < N; i += 512) sbias[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+
+    // ---- loader (slots as in gemm_nt_8ph_kernel): offsets of the current tile and of the workgroup's next one
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (int)c_bytes, 0x00020000);
+    // a slot's source offset = (its own row / column + chunk: one register per operand) + (tile, half, i: scalar), clamped to the
+    // operand's last row / column per issue: no per-tile vector state, the workgroup's current and next tile are four scalars
+    const int c16 = (((tid & 7) ^ ((tid >> 3) & 7)) << 4);
+    const unsigned arow_off = (unsigned)(((tid >> 8) * 64 + ((tid >> 3) & 31)) * (lda * 2) + c16);         // rows + i * 128 + h * 32
+    const unsigned bcol_off = (unsigned)((8 * ((tid >> 3) & 15) + ((tid >> 7) & 3)) * (ldb * 2) + c16);    // columns + i * 128 + 4 h
+    const unsigned amax = (unsigned)(M - 1) * (unsigned)(lda * 2) + (unsigned)c16, bmax = (unsigned)(N - 1) * (unsigned)(ldb * 2) + (unsigned)c16;
+    int ctm = tile / tiles_n, ctn = tile - ctm * tiles_n;                 // current tile
+    int xtm, xtn;                                                         // the next one (the current one again when there is none: a dummy re-fetch)
+    auto next_coords = [&]() {
+        const int nt = tile + S < tile_end ? tile + S : tile;
+        xtm = nt / tiles_n;
+        xtn = nt - xtm * tiles_n;
+    };
+    next_coords();
+    // kt counts from the current tile's first K step: kt >= nk is K step kt - nk of the next tile (nk >= 2: never beyond that one)
+    auto issue = [&](auto kind_c, auto par_c, int kt) {
+        constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, H = KIND & 1;
+        char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
+        const bool nx = kt >= nk;
+        const int so = (nx ? kt - nk : kt) * 128;
+        if (KIND < 2) {
+            const unsigned s0 = (unsigned)(((nx ? xtm : ctm) * 256 + H * 32) * (lda * 2)), s1 = s0 + (unsigned)(128 * lda * 2);
+            lds_dma16(rsrc_a, base, min(arow_off + s0, amax), so);
+            lds_dma16(rsrc_a, base + 8192, min(arow_off + s1, amax), so);
+        } else {
+            const unsigned s0 = (unsigned)(((nx ? xtn : ctn) * 256 + 4 * H) * (ldb * 2)), s1 = s0 + (unsigned)(128 * ldb * 2);
+            lds_dma16(rsrc_b, base, min(bcol_off + s0, bmax), so);
+            lds_dma16(rsrc_b, base + 8192, min(bcol_off + s1, bmax), so);
+        }
+    };
+
+    const int q = lane >> 4, r = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned al0 = lds0 + (unsigned)((wm * 32 + r) * 128 + ((q ^ (r & 7)) << 4)), al1 = al0 ^ 64u;
+    const unsigned bl0 = lds0 + (unsigned)((wn * 64 + r) * 128 + ((q ^ (r & 7)) << 4)), bl1 = bl0 ^ 64u;
+    const unsigned sb0 = lds0 + (unsigned)LDS_BYTES;
+
+    f32x4 acc[4][8];
+    Frag a[2][2], b0[4][2], b1[4][2];
+    auto read_a = [&](auto par_c, auto h_c) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
+        const unsigned p0 = al0 + PAR * 4 * HALF, p1 = al1 + PAR * 4 * HALF;
+        lds_rd16<H * HALF + 0 * 2048>(a[0][0], p0); lds_rd16<H * HALF + 0 * 2048>(a[0][1], p1);
+        lds_rd16<H * HALF + 1 * 2048>(a[1][0], p0); lds_rd16<H * HALF + 1 * 2048>(a[1][1], p1);
+    };
+    auto read_b = [&](auto par_c, auto h_c, Frag (&b)[4][2]) {
+        constexpr int PAR = decltype(par_c)::value, H = decltype(h_c)::value;
+        const unsigned p0 = bl0 + PAR * 4 * HALF, p1 = bl1 + PAR * 4 * HALF;
+        lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][0], p0); lds_rd16<(2 + H) * HALF + 0 * 2048>(b[0][1], p1);
+        lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][0], p0); lds_rd16<(2 + H) * HALF + 1 * 2048>(b[1][1], p1);
+        lds_rd16<(2 + H) * HALF + 2 * 2048>(b[2][0], p0); lds_rd16<(2 + H) * HALF + 2 * 2048>(b[2][1], p1);
+        lds_rd16<(2 + H) * HALF + 3 * 2048>(b[3][0], p0); lds_rd16<(2 + H) * HALF + 3 * 2048>(b[3][1], p1);
+    };
+    auto quadrant = [&](auto i0_c, auto j0_c, const Frag (&b)[4][2]) {
+        constexpr int I0 = decltype(i0_c)::value, J0 = decltype(j0_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[I0 + i][J0 + j] = ASR_MFMA_16x16x32(a[i][ks].v, b[j][ks].v, acc[I0 + i][J0 + j]);
+    };
+
+    // ---- pieces.  acc[I][J][reg] = C[tm 256 + wm 64 + I 16 + 4 q + reg][tn 256 + wn 128 + 8 r + J], the bias already inside.
+    // Quadrant (I0, J0) = rows I0, I0 + 1 x columns J0 .. J0 + 3: a lane's four columns are 8 (16) contiguous bytes.  The store's scalar
+    // offset carries the tile and the row (the range check of a raw buffer access sees only the vector offset + immediate: a lane whose
+    // row or columns do not exist gets a vector offset beyond the buffer).
+    int ptm = 0, ptn = 0;                                       // the tile the pieces belong to
+    int ntn = 0;                                                // column tile of the tile being computed (bias of a re-initialised quadrant)
+    const unsigned vc = (unsigned)((4 * q * ldc + wn * 128 + 8 * r) * ES);
+    auto bias_read = [&](auto j0_c, f32x4& bv) {
+        constexpr int J0 = decltype(j0_c)::value;
+        const unsigned ad = sb0 + (unsigned)(min(ntn * 256 + wn * 128 + 8 * r + J0, N - 4) * 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bv) : "v"(ad) : "memory");
+    };
+    // rows I0, I0 + 1 (x 4 q + reg) of the tile the pieces belong to, all eight columns of the lane: 8 (bf16: 16 bytes per row) or 16
+    // (f32: two 16-byte halves) store instructions, never fewer
+    auto rows_store = [&](auto i0_c) {
+        constexpr int I0 = decltype(i0_c)::value;
+        const int rlim = M - (ptm * 256 + wm * 64), clim = N - (ptn * 256 + wn * 128);
+        const bool cok0 = 8 * r < clim, cok1 = 8 * r + 4 < clim;
+        const unsigned sbase = (unsigned)(((ptm * 256 + wm * 64) * ldc + ptn * 256) * ES);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr_ = (I0 + i) * 16 + reg;
+                const bool rok = (4 * q < rlim - rr_) & (whatif != 1);      // (scalar right side: no per-row lane constants)
+                const unsigned so = sbase + (unsigned)(rr_ * ldc * ES);
+                const f32x4 v0 = (f32x4){acc[I0 + i][0][reg], acc[I0 + i][1][reg], acc[I0 + i][2][reg], acc[I0 + i][3][reg]};
+                const f32x4 v1 = (f32x4){acc[I0 + i][4][reg], acc[I0 + i][5][reg], acc[I0 + i][6][reg], acc[I0 + i][7][reg]};
+                if (ES == 4) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsrc_c, (int)((rok & cok0) ? vc : 0xfffffff0u), (int)so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsrc_c, (int)((rok & cok1) ? vc + 16u : 0xfffffff0u), (int)so, 0);
+                } else {            // (N % 8 == 0 here: a lane's eight columns exist together)
+                    const u32x4 pk = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_c, (int)((rok & cok0) ? vc : 0xfffffff0u), (int)so, 0);
+                }
+            }
+    };
+    auto piece_init = [&](auto i0_c, auto j0_c, const f32x4& bv) {
+        constexpr int I0 = decltype(i0_c)::value, J0 = decltype(j0_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[I0 + i][J0 + jj] = (f32x4){bv[jj], bv[jj], bv[jj], bv[jj]};
+    };
+    // phase p of the K step after a tile's end: quadrant p starts again from the new tile's bias; before that the old tile's rows leave --
+    // rows I = 0, 1 in phase 0 (quadrants 0 and 1 rewrite them in phases 0 and 1), rows I = 2, 3 in phase 2 (quadrants 2 and 3)
+#define ASR8P_PIECE(I0, J0, STORE)                                       \
+    if (mode == 1) {                                                     \
+        f32x4 bv_;                                                       \
+        bias_read(ASR8_C(J0), bv_);                                      \
+        if (STORE) rows_store(ASR8_C(I0));                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        piece_init(ASR8_C(I0), ASR8_C(J0), bv_);                         \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    }
+    auto kstep = [&](auto par_c, int t, int mode_in) {
+        constexpr int PAR = decltype(par_c)::value;
+        const int mode = whatif == 2 ? 0 : mode_in;         // (what-if 2, timing only: no pieces, the plain schedule's waits)
+        // (A0, B0)
+        read_a(ASR8_C(PAR), ASR8_C(0));
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(ASR8_C(PAR), ASR8_C(0), b0);
+        ASR8P_PIECE(0, 0, true)
+        ASR8_ISSUE(3, PAR ^ 1, t + 1);
+        ASR8P_LOAD_END(16, 16, 24, 24);
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+        // (A0, B1)
+        read_b(ASR8_C(PAR), ASR8_C(1), b1);
+        ASR8P_PIECE(0, 4, false)
+        ASR8_ISSUE(1, PAR ^ 1, t + 1);
+        ASR8P_LOAD_END(16, 8, 24, 8);
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(0), ASR8_C(4), b1);
+        ASR8_COMPUTE_END();
+        // (A1, B1)
+        read_a(ASR8_C(PAR), ASR8_C(1));
+        ASR8P_PIECE(2, 4, true)
+        ASR8_ISSUE(0, PAR, t + 2);
+        ASR8P_LOAD_END(24, 8, 40, 8);
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(2), ASR8_C(4), b1);
+        ASR8_COMPUTE_END();
+        // (A1, B0)
+        ASR8P_PIECE(2, 0, false)
+        ASR8_ISSUE(2, PAR, t + 2);
+        ASR8P_LOAD_END(16, 8, 24, 8);
+        ASR8_COMPUTE_BEGIN();
+        quadrant(ASR8_C(2), ASR8_C(0), b0);
+        ASR8_COMPUTE_END();
+    };
+
+    // the first tile's accumulators start from its bias
+    ntn = ctn;
+    {
+        f32x4 bq0, bq1;
+        bias_read(ASR8_C(0), bq0);
+        bias_read(ASR8_C(4), bq1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        piece_init(ASR8_C(0), ASR8_C(0), bq0); piece_init(ASR8_C(2), ASR8_C(0), bq0);
+        piece_init(ASR8_C(0), ASR8_C(4), bq1); piece_init(ASR8_C(2), ASR8_C(4), bq1);
+    }
+    {   // prologue: K step 0 whole, A0 and B0 of step 1
+        ASR8_ISSUE(0, 0, 0);
+        ASR8_ISSUE(2, 0, 0);
+        ASR8_ISSUE(3, 0, 0);
+        ASR8_ISSUE(1, 0, 0);
+        ASR8_ISSUE(0, 1, 1);
+        ASR8_ISSUE(2, 1, 1);
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    }
+    const int grp = wm >> 1;
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");
+    // a tile's end (between two K steps; no barrier in here, the two groups pass it one barrier apart): the tile becomes the one its
+    // pieces belong to, the next tile's offsets move up, the one after it is worked out.  false: that was the workgroup's last tile.
+    auto tile_end_work = [&]() -> bool {
+        ptm = ctm;
+        ptn = ctn;
+        tile += S;
+        if (tile >= tile_end) return false;
+        ctm = xtm;
+        ctn = xtn;
+        ntn = ctn;
+        next_coords();
+        return true;
+    };
+    int t = 0, mode = 0;
+    for (;;) {
+        kstep(ASR8_C(0), t, mode);
+        mode = mode == 1 ? 2 : 0;
+        if (++t == nk) { t = 0; mode = 1; if (!tile_end_work()) break; }
+        kstep(ASR8_C(1), t, mode);
+        mode = mode == 1 ? 2 : 0;
+        if (++t == nk) { t = 0; mode = 1; if (!tile_end_work()) break; }
+    }
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
+    // the last tile leaves at once; the zero fills of the tile that does not exist still write LDS: drained before the workgroup ends
+    if (whatif != 2) {
+        rows_store(ASR8_C(0));
+        rows_store(ASR8_C(2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#undef ASR8P_PIECE
+#undef ASR8P_LOAD_END
+#undef ASR8P_WAIT
+
 // ------------------------------------------------------------------------------------------------ NT, narrow: N <= 128
 // Products with few output columns (backward-data of a convolution into 64 or 128 input channels: M = T B H rows, K = taps x channels)
 // waste three quarters of a 256 x 256 tile.  Tile 256 x TNW (64 or 128), waves 8 (M) x 1 (N): a wave owns 32 rows x all columns, the two
@@ -559,7 +828,7 @@ __device__ __forceinline__ void lds_tr8(u32x2& f, unsigned addr) {
 // columns never change, so its tap and channel are loop invariant; its row walks on by 64 positions per issue (incremental (t, b, h)
 // with carries: no division in the loop).  One product per launch (grp.n == 1; P.B = x, P.ldb unused).
 template <bool CONV>
-__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split, ConvDesc8 cd) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split, ConvDesc8 cd, int whatif) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
@@ -756,16 +1025,49 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
     float* __restrict__ C = P.C;
     const int ldc = P.ldc;
     const int col0 = n0 + wn * 64 + (lane & 15), row0 = m0 + wm * 128 + 4 * (lane >> 4);
+    if (whatif == 1) {          // what-if (ASR_DEBUG tn8_whatif=1: timing only, results invalid): one atomic per wave instead of the tile's
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (lane == 0 && row0 < M && col0 < N) atomicAdd(C + (size_t)row0 * ldc + col0, sum);
+        return;
+    }
+    if (whatif == 2) {          // the accumulator's own layout: an atomic instruction = 4 rows x 16 columns (four 64-byte pieces)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = row0 + i * 16 + reg;
+                if (row >= M) continue;
+                float* dst = C + (size_t)row * ldc + col0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (col0 + j * 16 < N) atomicAdd(dst + j * 16, acc[i][j][reg]);
+            }
+        return;
+    }
+    // 4 x 4 transpose between the lane's 16-lane group (row group g) and the column tile j (two lane-swap instructions per pair of
+    // registers): afterwards register j' holds row 4 j' + reg and lane l column l of the wave's 64 -- an atomic instruction = 256
+    // contiguous bytes of one row
+    const int colL = n0 + wn * 64 + lane, rowb = m0 + wm * 128;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int row = row0 + i * 16 + reg;
-            if (row >= M) continue;
-            float* dst = C + (size_t)row * ldc + col0;
+            unsigned r0 = __float_as_uint(acc[i][0][reg]), r1 = __float_as_uint(acc[i][1][reg]);
+            unsigned r2 = __float_as_uint(acc[i][2][reg]), r3 = __float_as_uint(acc[i][3][reg]);
+            auto s02 = __builtin_amdgcn_permlane32_swap(r0, r2, false, false);
+            auto s13 = __builtin_amdgcn_permlane32_swap(r1, r3, false, false);
+            auto s01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+            auto s23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+            const unsigned v[4] = {s01[0], s01[1], s23[0], s23[1]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col0 + j * 16 < N) atomicAdd(dst + j * 16, acc[i][j][reg]);
+            for (int jp = 0; jp < 4; ++jp) {
+                const int row = rowb + i * 16 + 4 * jp + reg;
+                if (row < M && colL < N) atomicAdd(C + (size_t)row * ldc + colL, __uint_as_float(v[jp]));
+            }
         }
 }
 
@@ -802,6 +1104,26 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
 #define ASR8_LAUNCH(T, CT, KT_)                                                                                                     \
     hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_, false>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
                        (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{}, stagger)
+    // the persistent form for short K and more tiles than CUs (ASR_DEBUG nt_8pp=0: the one-tile-per-workgroup kernel everywhere)
+    static const int pp = debug_flag("nt_8pp", 1), pp_kmax = debug_flag("nt8pp_kmax", 1024), pp_whatif = debug_flag("nt8pp_whatif", 0);
+    const unsigned long long c_total = ((unsigned long long)(M - 1) * ldc + N) * (out_bf16 ? 2 : 4);
+    if (pp && (K & 63) == 0 && K >= 128 && K <= pp_kmax && tiles_m * tiles_n > 256 && N <= 8192 && c_total < 0xfffffff0ull &&
+        (!out_bf16 || ((N & 7) == 0 && (ldc & 7) == 0))) {
+        static bool attr_pp = false;
+        if (!attr_pp) {
+            (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pp_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES + 32768);
+            (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pp_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES + 32768);
+            attr_pp = true;
+        }
+        if (out_bf16)
+            hipLaunchKernelGGL((gemm8::gemm_nt_8pp_kernel<uint16_t>), dim3(256), dim3(512), gemm8::LDS_BYTES + 32768, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (uint16_t*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, (unsigned)c_total, pp_whatif);
+        else
+            hipLaunchKernelGGL((gemm8::gemm_nt_8pp_kernel<float>), dim3(256), dim3(512), gemm8::LDS_BYTES + 32768, stream, (const uint16_t*)A, lda,
+                               (const uint16_t*)B, ldb, (float*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, (unsigned)c_total, pp_whatif);
+        ASR_LAUNCH_CHECK();
+        return ASR_OK;
+    }
     static const int stagger_env = debug_flag("nt8_stagger", 0);
     const int stagger = (stagger_env < 0 || (tiles_m * tiles_n > 256 && K <= 1024)) ? stagger_env : 0;
     const bool kt = (K & 63) != 0;
@@ -853,7 +1175,8 @@ extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const
         (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<false>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, gemm8::ConvDesc8{});
+    static const int whatif = debug_flag("tn8_whatif", 0);
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<false>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, gemm8::ConvDesc8{}, whatif);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -931,7 +1254,7 @@ extern "C" int asr_conv_tn_acc_8ph(void* stream_, const void* g, int ldg, const 
         (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd);
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd, 0);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }

@@ -106,6 +106,37 @@ def test_gemm_nt_8ph_exact_and_repeatable(device):
     assert _rel(first.float().cpu(), (a.float() @ b.float().T).cpu()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K,bias_on,lda", [(32000, 3000, 320, True, None), (20037, 1100, 192, True, None), (16640, 4100, 128, False, None),
+                                                (70000, 260, 256, True, 320), (32000, 3072, 384, True, None), (9000, 8192, 640, True, None)])
+@pytest.mark.parametrize("out_dtype", [BF16, F32])
+def test_gemm_nt_8ph_persistent_form(device, M, N, K, bias_on, lda, out_dtype):
+    """more tiles than CUs and K <= 1024: asr_gemm_nt_8ph runs gemm_nt_8pp_kernel (one workgroup per CU walks its tiles as ONE stream of K
+    steps, stores in the middle of it): odd and even numbers of K steps per tile (the LDS parity then flips from tile to tile), ragged last
+    row and column tiles, workgroups with one tile more than others (395 tiles), strided rows, the bias out of LDS up to N = 8192;
+    small integers make every output exact, so a K step taken from the neighbouring tile or a store of a half-cleared accumulator shows"""
+    from asr import _ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, lda or K), generator=g).float().to(device, BF16)[:, :K]
+    b = torch.randint(-3, 4, (N, K), generator=g).float().to(device, BF16)
+    bias = torch.randint(-8, 9, (N,), generator=g).float().to(device) if bias_on else None
+    out = _ops.gemm_nt_8ph(a, b, bias, out_dtype)
+    ref = a.float() @ b.float().T
+    if bias_on:
+        ref = ref + bias
+    if out_dtype == F32:
+        assert torch.equal(out, ref)
+    else:
+        assert torch.equal(out, ref.to(BF16))
+    # and on random operands, twice: the same bits, the float32 product within rounding
+    a = torch.randn(M, K, generator=g).to(device, BF16)
+    b = torch.randn(N, K, generator=g).to(device, BF16)
+    first = _ops.gemm_nt_8ph(a, b, bias, out_dtype).clone()
+    torch.empty(1 << 24, device=device).fill_(1.0)
+    assert torch.equal(_ops.gemm_nt_8ph(a, b, bias, out_dtype), first)
+    ref = a.float() @ b.float().T + (bias if bias_on else 0.0)
+    assert _rel(first.float().cpu(), ref.cpu()) < (2e-5 if out_dtype == F32 else 4e-3)
+
+
 def test_nt_kernels_without_the_8ph_kernel_in_a_forced_process():
     """asr_gemm_nt routes qualifying products to the 256 x 256 / eight-wave kernel; ASR_DEBUG nt_8ph=0 (read once per process) keeps the
     kernels it replaced (persistent 256 x 128, 128 x 128) under the NT tests of this file"""
