@@ -335,13 +335,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
 //    24 | 24, 8, 8, 8).  A piece's stores come BEFORE its segment's LDS-DMA instructions and are always the same number of instructions:
 //    rows and columns that do not exist get an offset beyond the buffer, never a branch.  A piece's stores must be acknowledged three
 //    phases after they were issued; that wait is what is left of the store tail.
-// K % 64 == 0, K >= 128, N <= 8192 (bf16 output: N % 8 == 0, ldc % 8 == 0), C below 4 GiB.  Tiles: XCD x owns a contiguous range of tile ids (column tiles of a row panel meet in
+// K % 64 == 0, K >= 128 (an odd K / 64 is padded with a K step of zeros: parity and mode of a K step are compile-time constants),
+// N <= 8192 (bf16 output: N % 8 == 0, ldc % 8 == 0), C below 4 GiB.  Tiles: XCD x owns a contiguous range of tile ids (column tiles of a row panel meet in
 // one L2); its S = gridDim / 8 workgroups take tiles beg + slot, beg + slot + S, ...
 #define ASR8P_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_barrier" ::: "memory")
+// (MODE is a compile-time constant: a K step with run-time tests in its load segments lost 6 us of a 104 us product to them)
 #define ASR8P_LOAD_END(H1, H2, F1, F2)                                                          \
     do {                                                                                        \
-        if (mode == 0) ASR8P_WAIT(8);                                                           \
-        else if (mode == 1) { if (ES == 4) ASR8P_WAIT(F1); else ASR8P_WAIT(H1); }               \
+        if (MODE == 0) ASR8P_WAIT(8);                                                           \
+        else if (MODE == 1) { if (ES == 4) ASR8P_WAIT(F1); else ASR8P_WAIT(H1); }               \
         else { if (ES == 4) ASR8P_WAIT(F2); else ASR8P_WAIT(H2); }                              \
     } while (0)
 template <typename OutT>
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
     constexpr int ES = (int)sizeof(OutT);
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    const int nk = K >> 6;
+    const int nk = ((K >> 6) + 1) & ~1;         // an even number of K steps per tile; an odd K / 64 gets one more, fetched as zeros
     int tile, tile_end;
     const int S = (int)(gridDim.x >> 3);
     {
@@ -390,15 +392,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
         constexpr int KIND = decltype(kind_c)::value, PAR = decltype(par_c)::value, H = KIND & 1;
         char* base = smem + (PAR * 4 + KIND) * HALF + wid * 1024;
         const bool nx = kt >= nk;
-        const int so = (nx ? kt - nk : kt) * 128;
+        const int ks = nx ? kt - nk : kt;
+        const int so = ks * 128;
+        const bool pad = ks * 64 >= K;              // (uniform) the padding K step: beyond the buffer, i.e. zeros
         if (KIND < 2) {
             const unsigned s0 = (unsigned)(((nx ? xtm : ctm) * 256 + H * 32) * (lda * 2)), s1 = s0 + (unsigned)(128 * lda * 2);
-            lds_dma16(rsrc_a, base, min(arow_off + s0, amax), so);
-            lds_dma16(rsrc_a, base + 8192, min(arow_off + s1, amax), so);
+            lds_dma16(rsrc_a, base, pad ? 0xfffffff0u : min(arow_off + s0, amax), so);
+            lds_dma16(rsrc_a, base + 8192, pad ? 0xfffffff0u : min(arow_off + s1, amax), so);
         } else {
             const unsigned s0 = (unsigned)(((nx ? xtn : ctn) * 256 + 4 * H) * (ldb * 2)), s1 = s0 + (unsigned)(128 * ldb * 2);
-            lds_dma16(rsrc_b, base, min(bcol_off + s0, bmax), so);
-            lds_dma16(rsrc_b, base + 8192, min(bcol_off + s1, bmax), so);
+            lds_dma16(rsrc_b, base, pad ? 0xfffffff0u : min(bcol_off + s0, bmax), so);
+            lds_dma16(rsrc_b, base + 8192, pad ? 0xfffffff0u : min(bcol_off + s1, bmax), so);
         }
     };
 
@@ -452,14 +456,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
         constexpr int I0 = decltype(i0_c)::value;
         const int rlim = M - (ptm * 256 + wm * 64), clim = N - (ptn * 256 + wn * 128);
         const bool cok0 = 8 * r < clim, cok1 = 8 * r + 4 < clim;
-        const unsigned sbase = (unsigned)(((ptm * 256 + wm * 64) * ldc + ptn * 256) * ES);
+        const unsigned sbase = ((unsigned)(ptm * 256 + wm * 64) * (unsigned)ldc + (unsigned)(ptn * 256)) * (unsigned)ES;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int rr_ = (I0 + i) * 16 + reg;
                 const bool rok = (4 * q < rlim - rr_) & (whatif != 1);      // (scalar right side: no per-row lane constants)
-                const unsigned so = sbase + (unsigned)(rr_ * ldc * ES);
+                const unsigned so = sbase + (unsigned)rr_ * (unsigned)ldc * (unsigned)ES;
                 const f32x4 v0 = (f32x4){acc[I0 + i][0][reg], acc[I0 + i][1][reg], acc[I0 + i][2][reg], acc[I0 + i][3][reg]};
                 const f32x4 v1 = (f32x4){acc[I0 + i][4][reg], acc[I0 + i][5][reg], acc[I0 + i][6][reg], acc[I0 + i][7][reg]};
                 if (ES == 4) {
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
     // phase p of the K step after a tile's end: quadrant p starts again from the new tile's bias; before that the old tile's rows leave --
     // rows I = 0, 1 in phase 0 (quadrants 0 and 1 rewrite them in phases 0 and 1), rows I = 2, 3 in phase 2 (quadrants 2 and 3)
 #define ASR8P_PIECE(I0, J0, STORE)                                       \
-    if (mode == 1) {                                                     \
+    if (MODE == 1) {                                                     \
         f32x4 bv_;                                                       \
         bias_read(ASR8_C(J0), bv_);                                      \
         if (STORE) rows_store(ASR8_C(I0));                               \
@@ -490,9 +494,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
         piece_init(ASR8_C(I0), ASR8_C(J0), bv_);                         \
         __builtin_amdgcn_sched_barrier(0);                               \
     }
-    auto kstep = [&](auto par_c, int t, int mode_in) {
-        constexpr int PAR = decltype(par_c)::value;
-        const int mode = whatif == 2 ? 0 : mode_in;         // (what-if 2, timing only: no pieces, the plain schedule's waits)
+    // MODE 1: the first K step of a tile (pieces), 2: the second (the waits still count the pieces' stores), 0: any other
+    auto kstep = [&](auto par_c, auto mode_c, int t) {
+        constexpr int PAR = decltype(par_c)::value, MODE = decltype(mode_c)::value;
         // (A0, B0)
         read_a(ASR8_C(PAR), ASR8_C(0));
         __builtin_amdgcn_sched_barrier(0);
@@ -528,17 +532,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
         ASR8_COMPUTE_END();
     };
 
-    // the first tile's accumulators start from its bias
+    // The workgroup's first tile is not special: it "follows" a tile below the matrix's last row, whose pieces are stores beyond the buffer
+    // (dropped by the range check, counted by vmcnt like any other), and takes its bias in its first K step like every tile.
     ntn = ctn;
-    {
-        f32x4 bq0, bq1;
-        bias_read(ASR8_C(0), bq0);
-        bias_read(ASR8_C(4), bq1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        piece_init(ASR8_C(0), ASR8_C(0), bq0); piece_init(ASR8_C(2), ASR8_C(0), bq0);
-        piece_init(ASR8_C(0), ASR8_C(4), bq1); piece_init(ASR8_C(2), ASR8_C(4), bq1);
-    }
+    ptm = tiles_m;
+    ptn = 0;
     {   // prologue: K step 0 whole, A0 and B0 of step 1
         ASR8_ISSUE(0, 0, 0);
         ASR8_ISSUE(2, 0, 0);
@@ -563,21 +561,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
         next_coords();
         return true;
     };
-    int t = 0, mode = 0;
+    // an EVEN number of K steps per tile: the LDS parity of a K step is then a compile-time constant as well
     for (;;) {
-        kstep(ASR8_C(0), t, mode);
-        mode = mode == 1 ? 2 : 0;
-        if (++t == nk) { t = 0; mode = 1; if (!tile_end_work()) break; }
-        kstep(ASR8_C(1), t, mode);
-        mode = mode == 1 ? 2 : 0;
-        if (++t == nk) { t = 0; mode = 1; if (!tile_end_work()) break; }
+        kstep(ASR8_C(0), ASR8_C(1), 0);
+        kstep(ASR8_C(1), ASR8_C(2), 1);
+        for (int t = 2; t < nk; t += 2) {
+            kstep(ASR8_C(0), ASR8_C(0), t);
+            kstep(ASR8_C(1), ASR8_C(0), t + 1);
+        }
+        if (!tile_end_work()) break;
     }
     if (grp == 0) asm volatile("s_barrier" ::: "memory");
     // the last tile leaves at once; the zero fills of the tile that does not exist still write LDS: drained before the workgroup ends
-    if (whatif != 2) {
-        rows_store(ASR8_C(0));
-        rows_store(ASR8_C(2));
-    }
+    rows_store(ASR8_C(0));
+    rows_store(ASR8_C(2));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 #undef ASR8P_PIECE

@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(32000, 3072, 512, "bf16"), (32000, 3072, 384, "bf16"), (32000, 3000, 320, "f32"), (32000, 640, 512, "bf16"), (32000, 512, 640, "bf16"),
-          (32000, 3072, 1024, "bf16"), (32000, 3072, 128, "bf16"), (32000, 3072, 256, "bf16"), (352000, 256, 960, "bf16"), (8192, 8192, 1024, "bf16")]
+          (32000, 3072, 1024, "bf16"), (32000, 3072, 128, "bf16"), (32000, 3072, 256, "bf16"), (352000, 256, 960, "bf16"), (8192, 8192, 1024, "bf16"), (32000, 3072, 2048, "bf16"), (32000, 3000, 320, "bf16")]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.join(ROOT, "chainer-speech-recognition_amd"))
