@@ -1498,11 +1498,16 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         // The 256 x 256 tile / eight-wave kernel of csrc/gemm8.hip wherever it qualifies (K % 64 == 0, N % 4 == 0, aligned) -- measured against
         // the kernels below (tools/time_nt8.py, us, same process, alternating): 32000 x 512 x 3072 118 -> 73, x 3072 x 512 122 -> 106, x 384 x 3072
         // 109 -> 72, x 3072 x 384 104 -> 92, x 3000 x 320 (f32) 151 -> 121, x 512 x 640 32 -> 25, 8192^3 1082 -> 753 (1017 -> 1460 TFLOP/s) -- except
-        // where short K meets a ragged last column tile (32000 x 640 x 512: a third 256-wide tile for 128 columns, 34 -> 36).
+        // where short K meets a ragged last column tile (32000 x 640 x 512: a third 256-wide tile for 128 columns, 34 -> 36 with one tile
+        // per workgroup; its persistent form -- more tiles than CUs, K <= 1024: gemm_nt_8pp_kernel -- takes that one too, 35 -> 30: up to
+        // 25 % of padding there).  With more tiles than CUs and K <= 1024 the products above run: x 3072 x 512 116 -> 91, x 3072 x 384
+        // 99 -> 73 (tools/ab_nt8pp.py).
         // ASR_DEBUG nt_8ph=0: never (comparison, and the tests that pin the kernels below).
-        static const int use8 = debug_flag("nt_8ph", 1);
+        static const int use8 = debug_flag("nt_8ph", 1), use8pp = debug_flag("nt_8pp", 1);
         const long long n_padded = (long long)cdiv(N, 256) * 256;
-        if (use8 && nt_wide_mode() <= 0 && (K >= 1024 || n_padded * 10 <= (long long)N * 11) && M >= 256 &&
+        const bool persistent = use8pp && (K & 63) == 0 && K >= 128 && K <= 1024 && (long long)cdiv(M, 256) * cdiv(N, 256) > 256 && N <= 8192 &&
+                                (!out_bf16 || ((N & 7) == 0 && (ldc & 7) == 0));
+        if (use8 && nt_wide_mode() <= 0 && (K >= 1024 || n_padded * 10 <= (long long)N * 11 || (persistent && n_padded * 4 <= (long long)N * 5)) && M >= 256 &&
             asr_gemm_nt_8ph_ok(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16))
             return asr_gemm_nt_8ph(stream_, A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16);
     }

@@ -13,7 +13,7 @@ import json
 import sys
 
 CUS, SIMDS, XCDS = 256, 4, 8
-KEEP = ("gemm_nt_8ph_kernel", "gemm_tn_8ph_kernel", "specgram512_kernel", "deltas_tile_kernel", "merge_dirs", "gemm_nt256p_kernel", "gemm_nt256_kernel", "gemm_nt_kernel", "gemm_nt_wide_kernel", "gemm_tn_kernel", "gemm_tn_vec_kernel", "gemm_tn256_kernel",
+KEEP = ("gemm_nt_8ph_kernel", "gemm_nt_8pp_kernel", "gemm_nt_8pn_kernel", "gemm_tn_8ph_kernel", "specgram512_kernel", "deltas_tile_kernel", "merge_dirs", "gemm_nt256p_kernel", "gemm_nt256_kernel", "gemm_nt_kernel", "gemm_nt_wide_kernel", "gemm_tn_kernel", "gemm_tn_vec_kernel", "gemm_tn256_kernel",
         "lattice_kernel", "fwd_persistent_io_kernel", "bwd_ps_kernel", "bwd_wide_kernel", "ctcln::bwd_kernel", "rows_kernel",
         "fwd_rows_f32_kernel", "sru::", "maxout2_pool", "adam_ctl_kernel", "convf::", "conv_direct")
 
