@@ -151,7 +151,9 @@ int asr_gemm_nt(void* stream, const void* A, int lda, const void* B, int ldb, vo
                 int M, int N, int K, int out_bf16);
 /* asr_gemm_nt_8ph: the same product (no element-load fall-back: K % 8 == 0, N % 4 == 0, lda / ldb multiples of 8, ldc of 4, 16-byte aligned
  * bases, operands below 2 GiB -- asr_gemm_nt_8ph_ok says whether a call qualifies) on the 256 x 256 tile kernel with eight waves in
- * two staggered groups (csrc/gemm8.hip); asr_gemm_nt routes the long-K products of the model to it. */
+ * two staggered groups (csrc/gemm8.hip); asr_gemm_nt routes the model's products to it.  With more than 256 tiles and K % 64 == 0,
+ * 128 <= K <= 1024 (N <= 8192; bf16 output: N and ldc multiples of 8) it runs as ONE persistent workgroup per CU that walks its tiles as one
+ * stream of K steps (gemm_nt_8pp_kernel): the forward projections of a recurrent layer (chainer.links.NStepBiGRU's W x, asr/nn/nn.py:3). */
 int asr_gemm_nt_8ph_ok(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, const float* bias, int M, int N, int K,
                        int out_bf16);
 int asr_gemm_nt_8ph(void* stream, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias, int M, int N, int K,
