@@ -825,7 +825,7 @@ __device__ __forceinline__ void lds_tr8(u32x2& f, unsigned addr) {
 // columns never change, so its tap and channel are loop invariant; its row walks on by 64 positions per issue (incremental (t, b, h)
 // with carries: no division in the loop).  One product per launch (grp.n == 1; P.B = x, P.ldb unused).
 template <bool CONV>
-__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split, ConvDesc8 cd, int whatif) {
+__global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int tiles, int k_per_split, ConvDesc8 cd, int whatif, int splits, int stag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
@@ -845,9 +845,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
     const int lda = P.lda, ldb = P.ldb, M = P.M, N = P.N, K = P.K;
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
-    const int kbeg = split * k_per_split;
+    // K splits of unequal length (stag rows per step, a multiple of 64: split s is k_per_split + stag (2 s - splits + 1) rows long): the
+    // workgroups of a launch start together, and with equal lengths all of them reach their 256 KB of float atomics together -- 63 MB at
+    // the chip-wide atomic rate with nothing computing beside them (40 of 194 us for a GRU layer's weight gradients).  Staggered, the
+    // atomics of the splits that end first run beside the K loops of the others.
+    const int kbeg = split * k_per_split + stag * split * (split - splits);
+    const int klen = k_per_split + stag * (2 * split - splits + 1);
     if (kbeg >= K) return;
-    const int kend = min(K, kbeg + k_per_split);
+    const int kend = min(K, kbeg + klen);
     const int nk = (kend - kbeg + 63) >> 6;
 
     // ---- loader: slot s = i * 512 + tid = (k row kr = s / 16, position s % 16) holds chunk (s % 16) ^ 2 (kr % 8); the K advance
@@ -1068,6 +1073,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
         }
 }
 
+// rows per stagger step of a launch's K splits (0: equal splits).  One split's workgroups (one per tile) add tiles x 256 KB at ~1.5 TB/s
+// (tiles x 0.175 us) while a K step of 64 rows takes a workgroup ~1.4 us: consecutive splits should end that far apart, i.e. differ by
+// 2 stag = tiles x 8 rows, rounded to whole K steps -- as long as the shortest split keeps three quarters of the mean.
+// ASR_DEBUG tn8_stag: -1 (this rule), 0 (equal splits), n > 0 (n K steps of difference between consecutive splits).
+static inline int tn8_stagger(int tiles, int splits, int k_per_split) {
+    static const int forced = debug_flag("tn8_stag", -1);
+    if (splits < 2 || forced == 0) return 0;
+    int steps = forced > 0 ? forced : (tiles * 8 + 32) / 64;            // K steps between consecutive splits (= 2 stag / 64)
+    if (steps < 1) return 0;
+    // stag (2 s - splits + 1) must be a multiple of 64 for every s: an even number of K steps when `splits` is even (odd multipliers)
+    int stag = (splits & 1) ? steps * 32 : ((steps + 1) / 2) * 64;
+    if (splits & 1) stag = ((stag + 63) / 64) * 64;                     // (odd splits: even multipliers -- whole K steps of 64 keep it simple)
+    while (stag > 0 && (long long)stag * (splits - 1) * 4 > k_per_split) stag -= 64;
+    return stag > 0 ? stag : 0;
+}
+
 }  // namespace gemm8
 }  // namespace asr
 
@@ -1173,7 +1194,9 @@ extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const
         attr = true;
     }
     static const int whatif = debug_flag("tn8_whatif", 0);
-    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<false>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, gemm8::ConvDesc8{}, whatif);
+    const int stag = gemm8::tn8_stagger(tiles, splits, k_per_split);
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<false>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, gemm8::ConvDesc8{}, whatif,
+                       splits, stag);
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
@@ -1251,7 +1274,8 @@ extern "C" int asr_conv_tn_acc_8ph(void* stream_, const void* g, int ldg, const 
         (void)hipFuncSetAttribute((const void*)gemm8::gemm_tn_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd, 0);
+    hipLaunchKernelGGL(gemm8::gemm_tn_8ph_kernel<true>, dim3(grid), dim3(512), gemm8::LDS_BYTES, (hipStream_t)stream_, grp, tiles, k_per_split, cd, 0, splits,
+                       gemm8::tn8_stagger(tiles, splits, k_per_split));
     ASR_LAUNCH_CHECK();
     return ASR_OK;
 }
