@@ -1073,6 +1073,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_8ph_kernel(Tn8Group grp, int t
         }
 }
 
+// K splits of a launch.  A work item's K loop takes ~1.42 us per 64 rows, its 256 KB of float atomics ~0.175 us of the chip-wide atomic
+// rate, and a launch's items all add at its end: K / (64 S) x 1.42 + tiles S x 0.175 us is smallest at S = sqrt(0.127 K / tiles) -- fewer
+// items than CUs where few tiles meet a short K (a dense layer's 640 x 512 gradient over 32000 rows: 26 splits = 156 items instead of 42
+// = 252: 62.6 -> 52 us, tools/tn8_small.py); otherwise one item per CU (`target` = ASR_DEBUG tn8_items, 256) and at least 8 K steps each.
+static inline int tn8_splits(int tiles, int kmax) {
+    static const int target = debug_flag("tn8_items", 256), model = debug_flag("tn8_split_model", 1);
+    int splits = target / tiles;
+    if (model) {
+        int s = 1;
+        while ((long long)(s + 1) * (s + 1) * tiles * 1000 <= 127LL * kmax) ++s;      // floor(sqrt(0.127 kmax / tiles))
+        if (s < splits) splits = s;
+    }
+    if (splits < 1) splits = 1;
+    const int max_splits = (kmax + 511) / 512;
+    return splits > max_splits ? max_splits : splits;
+}
+
 // rows per stagger step of a launch's K splits (0: equal splits).  One split's workgroups (one per tile) add tiles x 256 KB at ~1.5 TB/s
 // (tiles x 0.175 us) while a K step of 64 rows takes a workgroup ~1.4 us: consecutive splits should end that far apart, i.e. differ by
 // 2 stag = tiles x 8 rows, rounded to whole K steps -- as long as the shortest split keeps three quarters of the mean.
@@ -1180,11 +1197,7 @@ extern "C" int asr_gemm_tn_acc_group_8ph(void* stream_, int n, const void* const
     }
     grp.n = n;
     // one workgroup per CU holds a whole CU (128 KiB of LDS): K splits so that about every CU gets one item, each split a multiple of 64 rows
-    static const int target = debug_flag("tn8_items", 256);
-    int splits = target / tiles;
-    if (splits < 1) splits = 1;
-    const int max_splits = cdiv(kmax, 512);                  // at least 8 K steps per item
-    if (splits > max_splits) splits = max_splits;
+    int splits = gemm8::tn8_splits(tiles, kmax);
     const int k_per_split = cdiv(cdiv(kmax, splits), 64) * 64;
     splits = cdiv(kmax, k_per_split);
     const int items = tiles * splits, grid = 8 * cdiv(items, 8);
@@ -1260,11 +1273,7 @@ extern "C" int asr_conv_tn_acc_8ph(void* stream_, const void* g, int ldg, const 
     const int tiles = cdiv(Co, 256) * q.tiles_n;
     q.tile_end = tiles;
     grp.n = 1;
-    static const int target = debug_flag("tn8_items", 256);
-    int splits = target / tiles;
-    if (splits < 1) splits = 1;
-    const int max_splits = cdiv(K, 512);
-    if (splits > max_splits) splits = max_splits;
+    int splits = gemm8::tn8_splits(tiles, K);
     const int k_per_split = cdiv(cdiv(K, splits), 64) * 64;
     splits = cdiv(K, k_per_split);
     const int items = tiles * splits, grid = 8 * cdiv(items, 8);
