@@ -569,7 +569,12 @@ def time_features(dev, B=32, N=160672, iters=50):
     for _ in range(3):
         pair()
     torch.cuda.synchronize()
+    # The host needs 40 - 150 us to queue a pair (two ctypes calls + two allocations; a busy box more): timed as they are queued, the
+    # events would measure the host.  A one-wave delay kernel holds the stream while all `iters` pairs are queued behind it; the first
+    # event sits behind the delay, so the interval is the kernels alone.
+    from asr import _lib
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _lib.check(_lib.lib().asr_stream_delay(_lib.stream(), min(100000, 400 * iters)), "asr_stream_delay")
     e0.record()
     for _ in range(iters):
         pair()
