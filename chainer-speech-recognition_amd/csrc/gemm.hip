@@ -1506,7 +1506,7 @@ extern "C" int asr_gemm_nt(void* stream_, const void* A, int lda, const void* B,
         static const int use8 = debug_flag("nt_8ph", 1), use8pp = debug_flag("nt_8pp", 1);
         const long long n_padded = (long long)cdiv(N, 256) * 256;
         const bool persistent = use8pp && (K & 63) == 0 && K >= 128 && K <= 1024 && (long long)cdiv(M, 256) * cdiv(N, 256) > 256 && N <= 8192 &&
-                                (!out_bf16 || ((N & 7) == 0 && (ldc & 7) == 0));
+                                out_bf16 && (N & 7) == 0 && (ldc & 7) == 0;
         if (use8 && nt_wide_mode() <= 0 && (K >= 1024 || n_padded * 10 <= (long long)N * 11 || (persistent && n_padded * 4 <= (long long)N * 5)) && M >= 256 &&
             asr_gemm_nt_8ph_ok(A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16))
             return asr_gemm_nt_8ph(stream_, A, lda, B, ldb, C, ldc, bias, M, N, K, out_bf16);

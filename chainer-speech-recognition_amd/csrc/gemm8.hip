@@ -61,6 +61,16 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds, 16, voffset, soffset, 0, 0);
 }
 
+// Behind every raw buffer store of this file.  A 16-byte store reads its data registers over several cycles after issue, and a vector
+// instruction that writes one of them must keep a distance (the ISA's "VMEM store of more than 64 bits -> write of its data VGPRs" wait
+// states).  hipcc inserts those for global stores but NOT for a buffer store with an SGPR soffset (LLVM's hazard recogniser exempts that
+// form), and the register allocator did put the next store's address into the first data register of the store in front of it:
+// `buffer_store_dwordx4 v[64:67], ...` / `v_cndmask_b32 v64, ...` back to back stored the ADDRESS in lanes 12 - 15 of a row now and then
+// (float32 logits, 400 of 24.6 M elements; found by exact-integer tests on an output pre-filled with NaN: tools/_dbg_f32map.py).
+#define ASR8_STORE_FENCE()                          \
+    __builtin_amdgcn_sched_barrier(0);              \
+    asm volatile("s_nop 3" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0)
 #define ASR8_LOAD_END() asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory")
 #define ASR8_COMPUTE_BEGIN()                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
@@ -131,8 +141,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
             } else {
                 oa[h][i] = (unsigned)min(grow, M - 1) * (unsigned)(lda * 2) + (unsigned)(c * 16);
             }
-            // B half h: LDS row rho = wn' * 64 + j * 16 + r  <-  column n0 + wn' * 128 + 8 r + (4 h + j)
-            const int gcol = n0 + (rho >> 6) * 128 + 8 * (rho & 15) + 4 * h + ((rho >> 4) & 3);
+            // B half h: LDS row rho = wn' * 64 + j * 16 + r  <-  column n0 + wn' * 128 + 8 r + (4 h + j): a lane's eight accumulator columns
+            // are 16 contiguous bytes of bf16.  Float32 output: column n0 + wn' * 128 + 64 h + 4 r + j instead -- a lane's four columns of
+            // one half are 16 contiguous bytes and the 16 lanes of a row 256 contiguous bytes per store instruction (with eight columns
+            // per lane a 16-byte store covered every other 16 bytes of 512: two half-dense instructions per row)
+            const int gcol = sizeof(OutT) == 4 ? n0 + (rho >> 6) * 128 + 64 * h + 4 * (rho & 15) + ((rho >> 4) & 3)
+                                               : n0 + (rho >> 6) * 128 + 8 * (rho & 15) + 4 * h + ((rho >> 4) & 3);
             ob[h][i] = (unsigned)min(gcol, N - 1) * (unsigned)(ldb * 2) + (unsigned)(c * 16);
         }
     }
@@ -269,15 +283,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
     // ---- epilogue: acc[I][J][reg] = C[m0 + wm * 64 + I * 16 + 4 q + reg][n0 + wn * 128 + 8 r + J]: 16 bytes of bf16 (32 of f32) per lane
     // and row, the 16 lanes of a row 256 (512) contiguous bytes; 16 store instructions per lane (the store tail is issue-bound: 8-byte
     // stores, 32 per lane, took as long as the eight K steps of a K = 512 product)
-    const int col = n0 + wn * 128 + 8 * r;
+    constexpr bool F32MAP = sizeof(OutT) == 4;                  // float32: columns J = 4 .. 7 of a lane lie 64 columns behind J = 0 .. 3
+    constexpr int SECOND = F32MAP ? 64 : 4;
+    const int col = n0 + wn * 128 + (F32MAP ? 4 : 8) * r;
     if (col >= N) return;
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool full = col + 7 < N;                              // (N % 4 == 0: a lane's eight columns exist as 8 or as the first 4)
+    const bool full = col + SECOND + 3 < N;                     // (N % 4 == 0: a lane's eight columns exist as 8 or as the first 4)
     if (bias) {
         const float4 ba = *reinterpret_cast<const float4*>(bias + col);
         bv[0] = ba.x; bv[1] = ba.y; bv[2] = ba.z; bv[3] = ba.w;
         if (full) {
-            const float4 bb = *reinterpret_cast<const float4*>(bias + col + 4);
+            const float4 bb = *reinterpret_cast<const float4*>(bias + col + SECOND);
             bv[4] = bb.x; bv[5] = bb.y; bv[6] = bb.z; bv[7] = bb.w;
         }
     }
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8ph_kernel(const uint16_t* __r
             for (int j = 0; j < 8; ++j) v[j] = acc[i][j][reg] + bv[j];
             if (sizeof(OutT) == 4) {
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                if (full) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                if (full) *reinterpret_cast<float4*>(dst + SECOND) = make_float4(v[4], v[5], v[6], v[7]);
             } else if (full && c16) {
                 uint4 pk;
                 pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]);
@@ -377,7 +393,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
     // operand's last row / column per issue: no per-tile vector state, the workgroup's current and next tile are four scalars
     const int c16 = (((tid & 7) ^ ((tid >> 3) & 7)) << 4);
     const unsigned arow_off = (unsigned)(((tid >> 8) * 64 + ((tid >> 3) & 31)) * (lda * 2) + c16);         // rows + i * 128 + h * 32
-    const unsigned bcol_off = (unsigned)((8 * ((tid >> 3) & 15) + ((tid >> 7) & 3)) * (ldb * 2) + c16);    // columns + i * 128 + 4 h
+    constexpr bool F32MAP = ES == 4;        // float32 output: the column map of gemm_nt_8ph_kernel's float32 form (dense 16-byte stores)
+    constexpr int BH = F32MAP ? 64 : 4, BR = F32MAP ? 4 : 8;
+    const unsigned bcol_off = (unsigned)((BR * ((tid >> 3) & 15) + ((tid >> 7) & 3)) * (ldb * 2) + c16);    // columns + i * 128 + BH h
     const unsigned amax = (unsigned)(M - 1) * (unsigned)(lda * 2) + (unsigned)c16, bmax = (unsigned)(N - 1) * (unsigned)(ldb * 2) + (unsigned)c16;
     int ctm = tile / tiles_n, ctn = tile - ctm * tiles_n;                 // current tile
     int xtm, xtn;                                                         // the next one (the current one again when there is none: a dummy re-fetch)
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
             lds_dma16(rsrc_a, base, pad ? 0xfffffff0u : min(arow_off + s0, amax), so);
             lds_dma16(rsrc_a, base + 8192, pad ? 0xfffffff0u : min(arow_off + s1, amax), so);
         } else {
-            const unsigned s0 = (unsigned)(((nx ? xtn : ctn) * 256 + 4 * H) * (ldb * 2)), s1 = s0 + (unsigned)(128 * ldb * 2);
+            const unsigned s0 = (unsigned)(((nx ? xtn : ctn) * 256 + BH * H) * (ldb * 2)), s1 = s0 + (unsigned)(128 * ldb * 2);
             lds_dma16(rsrc_b, base, pad ? 0xfffffff0u : min(bcol_off + s0, bmax), so);
             lds_dma16(rsrc_b, base + 8192, pad ? 0xfffffff0u : min(bcol_off + s1, bmax), so);
         }
@@ -444,10 +462,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
     // row or columns do not exist gets a vector offset beyond the buffer).
     int ptm = 0, ptn = 0;                                       // the tile the pieces belong to
     int ntn = 0;                                                // column tile of the tile being computed (bias of a re-initialised quadrant)
-    const unsigned vc = (unsigned)((4 * q * ldc + wn * 128 + 8 * r) * ES);
+    const unsigned vc = (unsigned)((4 * q * ldc + wn * 128 + BR * r) * ES);
     auto bias_read = [&](auto j0_c, f32x4& bv) {
         constexpr int J0 = decltype(j0_c)::value;
-        const unsigned ad = sb0 + (unsigned)(min(ntn * 256 + wn * 128 + 8 * r + J0, N - 4) * 4);
+        const unsigned ad = sb0 + (unsigned)(min(ntn * 256 + wn * 128 + BR * r + (J0 ? BH : 0), N - 4) * 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(bv) : "v"(ad) : "memory");
     };
     // rows I0, I0 + 1 (x 4 q + reg) of the tile the pieces belong to, all eight columns of the lane: 8 (bf16: 16 bytes per row) or 16
@@ -455,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
     auto rows_store = [&](auto i0_c) {
         constexpr int I0 = decltype(i0_c)::value;
         const int rlim = M - (ptm * 256 + wm * 64), clim = N - (ptn * 256 + wn * 128);
-        const bool cok0 = 8 * r < clim, cok1 = 8 * r + 4 < clim;
+        const bool cok0 = BR * r < clim, cok1 = BR * r + BH < clim;
         const unsigned sbase = ((unsigned)(ptm * 256 + wm * 64) * (unsigned)ldc + (unsigned)(ptn * 256)) * (unsigned)ES;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -468,10 +486,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8pp_kernel(const uint16_t* __r
                 const f32x4 v1 = (f32x4){acc[I0 + i][4][reg], acc[I0 + i][5][reg], acc[I0 + i][6][reg], acc[I0 + i][7][reg]};
                 if (ES == 4) {
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), rsrc_c, (int)((rok & cok0) ? vc : 0xfffffff0u), (int)so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsrc_c, (int)((rok & cok1) ? vc + 16u : 0xfffffff0u), (int)so, 0);
+                    ASR8_STORE_FENCE();
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), rsrc_c, (int)((rok & cok1) ? vc + (unsigned)(BH * ES) : 0xfffffff0u), (int)so, 0);
+                    ASR8_STORE_FENCE();
                 } else {            // (N % 8 == 0 here: a lane's eight columns exist together)
                     const u32x4 pk = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
                     __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc_c, (int)((rok & cok0) ? vc : 0xfffffff0u), (int)so, 0);
+                    ASR8_STORE_FENCE();
                 }
             }
     };
@@ -1140,10 +1161,13 @@ extern "C" int asr_gemm_nt_8ph(void* stream_, const void* A, int lda, const void
     hipLaunchKernelGGL((gemm8::gemm_nt_8ph_kernel<T, KT_, false>), dim3(tiles_m * tiles_n), dim3(512), gemm8::LDS_BYTES, stream, (const uint16_t*)A, lda, \
                        (const uint16_t*)B, ldb, (CT*)C, ldc, bias, M, N, K, tiles_m, tiles_n, a_bytes, b_bytes, gemm8::ConvDesc8{}, stagger)
     // the persistent form for short K and more tiles than CUs (ASR_DEBUG nt_8pp=0: the one-tile-per-workgroup kernel everywhere)
-    static const int pp = debug_flag("nt_8pp", 1), pp_kmax = debug_flag("nt8pp_kmax", 1024), pp_whatif = debug_flag("nt8pp_whatif", 0);
+    // float32 output (the logits: 384 MB) is bound by its stores in either form and the one-tile kernel is the faster one there (119.5
+    // against 123 us; ASR_DEBUG nt8pp_f32=1 runs the persistent form for it: tests)
+    static const int pp = debug_flag("nt_8pp", 1), pp_kmax = debug_flag("nt8pp_kmax", 1024), pp_whatif = debug_flag("nt8pp_whatif", 0),
+                     pp_f32 = debug_flag("nt8pp_f32", 0);
     const unsigned long long c_total = ((unsigned long long)(M - 1) * ldc + N) * (out_bf16 ? 2 : 4);
     if (pp && (K & 63) == 0 && K >= 128 && K <= pp_kmax && tiles_m * tiles_n > 256 && N <= 8192 && c_total < 0xfffffff0ull &&
-        (!out_bf16 || ((N & 7) == 0 && (ldc & 7) == 0))) {
+        (out_bf16 ? ((N & 7) == 0 && (ldc & 7) == 0) : pp_f32 != 0)) {
         static bool attr_pp = false;
         if (!attr_pp) {
             (void)hipFuncSetAttribute((const void*)gemm8::gemm_nt_8pp_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES + 32768);

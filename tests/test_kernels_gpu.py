@@ -119,14 +119,16 @@ def test_gemm_nt_8ph_persistent_form(device, M, N, K, bias_on, lda, out_dtype):
     a = torch.randint(-3, 4, (M, lda or K), generator=g).float().to(device, BF16)[:, :K]
     b = torch.randint(-3, 4, (N, K), generator=g).float().to(device, BF16)
     bias = torch.randint(-8, 9, (N,), generator=g).float().to(device) if bias_on else None
-    out = _ops.gemm_nt_8ph(a, b, bias, out_dtype)
     ref = a.float() @ b.float().T
     if bias_on:
         ref = ref + bias
-    if out_dtype == F32:
-        assert torch.equal(out, ref)
-    else:
-        assert torch.equal(out, ref.to(BF16))
+    # five launches into an output pre-filled with NaN: every element written, and written with ITS value every time (a 16-byte buffer
+    # store whose first data register the next instruction overwrote stored an address in lanes 12 - 15 of a row now and then -- 400 of
+    # 24.6 M elements, one launch in a few: ASR8_STORE_FENCE in csrc/gemm8.hip)
+    for _ in range(5):
+        out = torch.full((M, N), float("nan"), dtype=out_dtype, device=device)
+        _ops.gemm_nt_8ph(a, b, bias, out_dtype, out)
+        assert torch.equal(out, ref if out_dtype == F32 else ref.to(BF16))
     # and on random operands, twice: the same bits, the float32 product within rounding
     a = torch.randn(M, K, generator=g).to(device, BF16)
     b = torch.randn(N, K, generator=g).to(device, BF16)
@@ -135,6 +137,17 @@ def test_gemm_nt_8ph_persistent_form(device, M, N, K, bias_on, lda, out_dtype):
     assert torch.equal(_ops.gemm_nt_8ph(a, b, bias, out_dtype), first)
     ref = a.float() @ b.float().T + (bias if bias_on else 0.0)
     assert _rel(first.float().cpu(), ref.cpu()) < (2e-5 if out_dtype == F32 else 4e-3)
+
+
+def test_persistent_nt_kernel_with_float32_output_in_a_forced_process():
+    """float32 products go to the one-tile kernel by default (bound by their stores either way); ASR_DEBUG nt8pp_f32=1 (read once per
+    process) runs the persistent form on them: the float32 cases of the test above through gemm_nt_8pp_kernel<float>"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ASR_DEBUG="nt8pp_f32=1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-m", "gpu", "-x", "-q",
+                          "-k", "test_gemm_nt_8ph_persistent_form and out_dtype1"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_nt_kernels_without_the_8ph_kernel_in_a_forced_process():
